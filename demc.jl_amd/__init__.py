@@ -1,0 +1,17 @@
+"""demc.jl_amd -- MI355X-native DEMCz chain-update engine behind the call surface of
+chrished/DEMC.jl (``demcopt``, ``demcz_sample``, ``demcz_anneal``, ``MC``).
+
+The directory name has a dot, so import it through the repo-root alias module::
+
+    import demc_jl_amd as demc
+    mc, Z = demc.demcz_sample(demc.MvNormalTarget(mu, Sigma), Zinit, demc.demcopt(5, N=1024))
+
+All computation below the generation loop runs in ``libdemcz_hip.so`` (HIP, gfx950) through the
+C ABI of ``include/demcz.h``; there is no CPU fallback.
+"""
+from ._lib import DemczError, build, LIB_PATH, SYMBOLS          # noqa: F401
+from .engine import HipEngine, selftest_draws                   # noqa: F401
+from .targets import MvNormalTarget, IsoQuadTarget, LinRegSSETarget, is_device_target   # noqa: F401
+from .sampler import (MC, DEMCopt, demcopt, demcz_sample, demcz_anneal, tempbaseline,   # noqa: F401
+                      Sharding, DEFAULT_ADAPT)
+from . import workloads                                         # noqa: F401

@@ -1,0 +1,937 @@
+// demcz_capi.hip -- the C ABI of include/demcz.h over the kernels of demcz_kernels.h.
+// Host side of the seam src/demcz.jl:30-33 / src/demcz_anneal.jl:39-42 (see the header).
+// There is no CPU fallback: without a HIP device every entry point fails with
+// DEMCZ_ERR_NO_DEVICE.
+#include "../../include/demcz.h"
+#include "demcz_kernels.h"
+
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace demcz;
+
+static thread_local std::string g_create_error;
+
+struct demcz_handle {
+    demcz_config cfg{};
+    int lanes = 1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // host copies of the small tables
+    std::vector<int32_t> block_offsets, block_indices, slot_of;
+    std::vector<double> eps;
+    int64_t S = 0;            // Philox blocks per generation
+    bool full_block = false;
+    // device buffers
+    double* dZ = nullptr;
+    double* dX = nullptr;
+    double* dlp = nullptr;
+    double* dchain = nullptr;
+    double* dlogobj = nullptr;
+    unsigned int* dchanged = nullptr;
+    double* dtemp = nullptr;
+    int64_t temp_cap = 0;
+    int32_t* d_block_offsets = nullptr;
+    int32_t* d_slot_of = nullptr;
+    double* d_eps = nullptr;
+    double* d_mu = nullptr;
+    double* d_Wp = nullptr;
+    double* d_design = nullptr;
+    double* d_y = nullptr;
+    // scratch for reductions
+    double* d_scratch = nullptr;
+    int64_t scratch_cap = 0;
+    double* d_stage = nullptr;     // host-visible staging for small results / uploads
+    int64_t stage_cap = 0;
+    // state
+    int64_t M = 0;
+    int64_t g_done = 0;
+    int64_t g0 = 0;           // history origin
+    bool has_state = false;
+    int64_t launches = 0;
+    bool external_append = false;
+    // host-closure mode
+    double* dXprop = nullptr;
+    double* dlogu = nullptr;
+    double* dlp_before = nullptr;
+    bool proposal_pending = false;
+    bool gen_open = false;
+    // multi-GPU
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+    double* d_gather = nullptr;
+};
+
+#define HIPCHK(h, expr)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                        \
+            return DEMCZ_ERR_HIP;                                                                \
+        }                                                                                        \
+    } while (0)
+
+#define NCCLCHK(h, expr)                                                                         \
+    do {                                                                                         \
+        ncclResult_t r_ = (expr);                                                                \
+        if (r_ != ncclSuccess) {                                                                 \
+            (h)->err = std::string(#expr) + ": " + ncclGetErrorString(r_);                       \
+            return DEMCZ_ERR_HIP;                                                                \
+        }                                                                                        \
+    } while (0)
+
+static int32_t fail(demcz_handle* h, int32_t code, const std::string& msg)
+{
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+static int64_t blockstep_nblk(int b)
+{
+    const int nn = (b == 1) ? 1 : b;
+    return 1 + (nn + 1) / 2 + 1;
+}
+
+extern "C" int32_t demcz_abi_version(void) { return DEMCZ_ABI_VERSION; }
+
+extern "C" const char* demcz_last_error(const demcz_handle* h)
+{
+    return h ? h->err.c_str() : g_create_error.c_str();
+}
+
+template <class T>
+static hipError_t dev_alloc_copy(T** dst, const T* src, size_t n, hipStream_t s)
+{
+    hipError_t e = hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (n) e = hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyHostToDevice, s);
+    return e;
+}
+
+static void free_all(demcz_handle* h)
+{
+    void* bufs[] = {h->dZ, h->dX, h->dlp, h->dchain, h->dlogobj, h->dchanged, h->dtemp, h->d_block_offsets,
+                    h->d_slot_of, h->d_eps, h->d_mu, h->d_Wp, h->d_design, h->d_y, h->d_scratch, h->dXprop,
+                    h->dlogu, h->dlp_before, h->d_gather};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (h->d_stage) (void)hipHostFree(h->d_stage);
+    if (h->comm) (void)ncclCommDestroy(h->comm);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+}
+
+extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
+{
+    if (!out || !cfg) return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_create: null argument");
+    *out = nullptr;
+    if (cfg->N < 1 || cfg->d < 1 || cfg->d > MAX_D || cfg->K < 1 || cfg->Mcap < 2 || cfg->Gcap < 0 ||
+        cfg->Nblocks < 1 || !cfg->block_offsets || !cfg->block_indices || !cfg->eps_scale || cfg->chain_id0 < 0)
+        return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT,
+                    "demcz_create: need N>=1, 1<=d<=64, K>=1, Mcap>=2, Gcap>=0, Nblocks>=1 and block/eps tables");
+    if (cfg->lanes_per_chain != 0 && cfg->lanes_per_chain != 1)
+        return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_create: lanes_per_chain must be 0 or 1 in this build");
+    const int d = cfg->d;
+    // validate blocks: offsets ascending, indices within range and unique inside a block
+    if (cfg->block_offsets[0] != 0) return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT, "block_offsets[0] must be 0");
+    for (int ib = 0; ib < cfg->Nblocks; ++ib) {
+        const int a = cfg->block_offsets[ib], b = cfg->block_offsets[ib + 1];
+        if (b <= a || b - a > d) return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT, "empty or oversized block");
+        for (int t = a; t < b; ++t) {
+            if (cfg->block_indices[t] < 0 || cfg->block_indices[t] >= d)
+                return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT, "block index out of range");
+            for (int u = a; u < t; ++u)
+                if (cfg->block_indices[u] == cfg->block_indices[t])
+                    return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT, "duplicate index inside a block");
+        }
+    }
+    switch (cfg->target_kind) {
+    case DEMCZ_TARGET_MVNORMAL:
+        if (!cfg->mu || !cfg->W) return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT, "MVNORMAL needs mu and W");
+        break;
+    case DEMCZ_TARGET_ISO_QUAD:
+        if (!cfg->mu) return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT, "ISO_QUAD needs mu");
+        break;
+    case DEMCZ_TARGET_LINREG_SSE:
+        if (!cfg->design || !cfg->yobs || cfg->nobs < 1)
+            return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT, "LINREG_SSE needs design, yobs, nobs>=1");
+        break;
+    case DEMCZ_TARGET_HOST_CALLBACK: break;
+    default: return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT, "unknown target_kind");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, DEMCZ_ERR_NO_DEVICE, "demcz_create: no HIP device visible (there is no CPU fallback)");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev)
+        return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_create: device_id out of range");
+
+    demcz_handle* h = new demcz_handle();
+    h->cfg = *cfg;
+    h->lanes = 1;
+    auto bail = [&](int32_t code) {
+        g_create_error = h->err;
+        free_all(h);
+        delete h;
+        return code;
+    };
+#define CRCHK(expr)                                                                              \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            h->err = std::string(#expr) + ": " + hipGetErrorString(e_);                          \
+            return bail(DEMCZ_ERR_HIP);                                                          \
+        }                                                                                        \
+    } while (0)
+    CRCHK(hipSetDevice(cfg->device_id));
+    if (cfg->stream) {
+        h->stream = (hipStream_t)cfg->stream;
+    } else {
+        CRCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+    }
+    h->block_offsets.assign(cfg->block_offsets, cfg->block_offsets + cfg->Nblocks + 1);
+    h->block_indices.assign(cfg->block_indices, cfg->block_indices + h->block_offsets.back());
+    h->eps.assign(cfg->eps_scale, cfg->eps_scale + d);
+    h->slot_of.assign((size_t)cfg->Nblocks * d, -1);
+    h->S = 0;
+    for (int ib = 0; ib < cfg->Nblocks; ++ib) {
+        const int a = h->block_offsets[ib], b = h->block_offsets[ib + 1];
+        for (int t = a; t < b; ++t) h->slot_of[(size_t)ib * d + h->block_indices[t]] = t - a;
+        h->S += blockstep_nblk(b - a);
+    }
+    h->full_block = (cfg->Nblocks == 1 && h->block_offsets[1] == d);
+    if (h->full_block)
+        for (int p = 0; p < d; ++p) h->full_block = h->full_block && (h->block_indices[p] == p);
+    // no pointer of the caller's survives create
+    h->cfg.block_offsets = nullptr; h->cfg.block_indices = nullptr; h->cfg.eps_scale = nullptr;
+    h->cfg.mu = nullptr; h->cfg.W = nullptr; h->cfg.design = nullptr; h->cfg.yobs = nullptr; h->cfg.stream = nullptr;
+
+    const int64_t N = cfg->N;
+    CRCHK(hipMalloc((void**)&h->dZ, (size_t)cfg->Mcap * d * sizeof(double)));
+    CRCHK(hipMemsetAsync(h->dZ, 0, (size_t)cfg->Mcap * d * sizeof(double), h->stream));   // zeros(...) demcz.jl:11
+    CRCHK(hipMalloc((void**)&h->dX, (size_t)N * d * sizeof(double)));
+    CRCHK(hipMalloc((void**)&h->dlp, (size_t)N * sizeof(double)));
+    if (cfg->Gcap > 0) {
+        CRCHK(hipMalloc((void**)&h->dchain, (size_t)N * d * cfg->Gcap * sizeof(double)));
+        CRCHK(hipMalloc((void**)&h->dlogobj, (size_t)N * cfg->Gcap * sizeof(double)));
+        CRCHK(hipMemsetAsync(h->dchain, 0, (size_t)N * d * cfg->Gcap * sizeof(double), h->stream));   // demcz.jl:24
+        CRCHK(hipMemsetAsync(h->dlogobj, 0, (size_t)N * cfg->Gcap * sizeof(double), h->stream));
+    }
+    const int64_t ccap = std::max<int64_t>(cfg->Gcap, 1);
+    CRCHK(hipMalloc((void**)&h->dchanged, (size_t)ccap * sizeof(unsigned int)));
+    CRCHK(hipMemsetAsync(h->dchanged, 0, (size_t)ccap * sizeof(unsigned int), h->stream));
+    CRCHK(dev_alloc_copy(&h->d_block_offsets, h->block_offsets.data(), h->block_offsets.size(), h->stream));
+    CRCHK(dev_alloc_copy(&h->d_slot_of, h->slot_of.data(), h->slot_of.size(), h->stream));
+    CRCHK(dev_alloc_copy(&h->d_eps, h->eps.data(), h->eps.size(), h->stream));
+    std::vector<double> wp, design_rm;
+    if (cfg->target_kind == DEMCZ_TARGET_MVNORMAL || cfg->target_kind == DEMCZ_TARGET_ISO_QUAD)
+        CRCHK(dev_alloc_copy(&h->d_mu, cfg->mu, (size_t)d, h->stream));
+    if (cfg->target_kind == DEMCZ_TARGET_MVNORMAL) {
+        wp.resize((size_t)d * (d + 1) / 2);
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j <= i; ++j) wp[(size_t)i * (i + 1) / 2 + j] = cfg->W[i + (size_t)d * j];
+        CRCHK(dev_alloc_copy(&h->d_Wp, wp.data(), wp.size(), h->stream));
+    }
+    if (cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) {
+        design_rm.resize((size_t)cfg->nobs * d);
+        for (int64_t o = 0; o < cfg->nobs; ++o)
+            for (int j = 0; j < d; ++j) design_rm[(size_t)o * d + j] = cfg->design[o + cfg->nobs * j];
+        CRCHK(dev_alloc_copy(&h->d_design, design_rm.data(), design_rm.size(), h->stream));
+        CRCHK(dev_alloc_copy(&h->d_y, cfg->yobs, (size_t)cfg->nobs, h->stream));
+    }
+    if (cfg->target_kind == DEMCZ_TARGET_HOST_CALLBACK) {
+        CRCHK(hipMalloc((void**)&h->dXprop, (size_t)N * d * sizeof(double)));
+        CRCHK(hipMalloc((void**)&h->dlogu, (size_t)N * sizeof(double)));
+        CRCHK(hipMalloc((void**)&h->dlp_before, (size_t)N * sizeof(double)));
+    }
+    h->stage_cap = std::max<int64_t>(4096, (int64_t)d * (d + 1) + 64);
+    CRCHK(hipHostMalloc((void**)&h->d_stage, (size_t)h->stage_cap * sizeof(double), hipHostMallocDefault));
+    CRCHK(hipStreamSynchronize(h->stream));   // the host vectors above go out of scope
+#undef CRCHK
+    *out = h;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_destroy(demcz_handle* h)
+{
+    if (!h) return DEMCZ_OK;
+    (void)hipSetDevice(h->cfg.device_id);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    free_all(h);
+    delete h;
+    return DEMCZ_OK;
+}
+
+static TargetParams target_params(const demcz_handle* h)
+{
+    TargetParams tp;
+    tp.mu = h->d_mu; tp.Wp = h->d_Wp; tp.c0 = h->cfg.c0;
+    tp.design = h->d_design; tp.yobs = h->d_y; tp.nobs = h->cfg.nobs;
+    return tp;
+}
+
+static int32_t ensure_scratch(demcz_handle* h, int64_t n)
+{
+    if (n <= h->scratch_cap) return DEMCZ_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->d_scratch) HIPCHK(h, hipFree(h->d_scratch));
+    h->d_scratch = nullptr; h->scratch_cap = 0;
+    HIPCHK(h, hipMalloc((void**)&h->d_scratch, (size_t)n * sizeof(double)));
+    h->scratch_cap = n;
+    return DEMCZ_OK;
+}
+
+static int32_t launch_logp(demcz_handle* h, const double* X, int64_t ldX, int64_t n, double* out)
+{
+    const TargetParams tp = target_params(h);
+    const int bs = 64;
+    const dim3 grid((unsigned)((n + bs - 1) / bs));
+    switch (h->cfg.target_kind) {
+    case DEMCZ_TARGET_MVNORMAL:
+        hipLaunchKernelGGL(logp_kernel<TARGET_MVNORMAL>, grid, dim3(bs), 0, h->stream, tp, h->cfg.d, X, ldX, n, out); break;
+    case DEMCZ_TARGET_ISO_QUAD:
+        hipLaunchKernelGGL(logp_kernel<TARGET_ISO_QUAD>, grid, dim3(bs), 0, h->stream, tp, h->cfg.d, X, ldX, n, out); break;
+    case DEMCZ_TARGET_LINREG_SSE:
+        hipLaunchKernelGGL(logp_kernel<TARGET_LINREG_SSE>, grid, dim3(bs), 0, h->stream, tp, h->cfg.d, X, ldX, n, out); break;
+    default: return fail(h, DEMCZ_ERR_STATE, "host-callback target: pass logp explicitly");
+    }
+    HIPCHK(h, hipGetLastError());
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_set_state(demcz_handle* h, const double* X, const double* logp, const double* Z,
+                                   int64_t ldZ, int64_t M0)
+{
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (!X || !Z) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_set_state: X and Z are required");
+    if (M0 < 2) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_set_state: M0 >= 2 needed (two distinct archive rows, demcz.jl:176-179)");
+    if (M0 > h->cfg.Mcap || ldZ < M0) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_set_state: M0 exceeds Mcap or ldZ < M0");
+    if (!logp && h->cfg.target_kind == DEMCZ_TARGET_HOST_CALLBACK)
+        return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_set_state: host-callback target needs logp");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const int d = h->cfg.d;
+    const int64_t N = h->cfg.N;
+    HIPCHK(h, hipMemcpyAsync(h->dX, X, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpy2DAsync(h->dZ, (size_t)h->cfg.Mcap * sizeof(double), Z, (size_t)ldZ * sizeof(double),
+                               (size_t)M0 * sizeof(double), (size_t)d, hipMemcpyHostToDevice, h->stream));
+    if (logp) {
+        HIPCHK(h, hipMemcpyAsync(h->dlp, logp, (size_t)N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    } else {
+        int32_t rc = launch_logp(h, h->dX, N, N, h->dlp);
+        if (rc) return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->M = M0;
+    h->has_state = true;
+    h->proposal_pending = false;
+    h->gen_open = false;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_get_state(demcz_handle* h, double* X, double* logp, double* Z, int64_t ldZ, int64_t* M)
+{
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (!h->has_state) return fail(h, DEMCZ_ERR_STATE, "demcz_get_state: no state set");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const int d = h->cfg.d;
+    const int64_t N = h->cfg.N;
+    if (X) HIPCHK(h, hipMemcpyAsync(X, h->dX, (size_t)N * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (logp) HIPCHK(h, hipMemcpyAsync(logp, h->dlp, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (Z) {
+        if (ldZ < h->M) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_get_state: ldZ < M");
+        HIPCHK(h, hipMemcpy2DAsync(Z, (size_t)ldZ * sizeof(double), h->dZ, (size_t)h->cfg.Mcap * sizeof(double),
+                                   (size_t)h->M * sizeof(double), (size_t)d, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (M) *M = h->M;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_set_history_origin(demcz_handle* h, int64_t g0)
+{
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (g0 < 0) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_set_history_origin: g0 >= 0");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    h->g0 = g0;
+    const int64_t ccap = std::max<int64_t>(h->cfg.Gcap, 1);
+    HIPCHK(h, hipMemsetAsync(h->dchanged, 0, (size_t)ccap * sizeof(unsigned int), h->stream));
+    return DEMCZ_OK;
+}
+
+// ---- window launch dispatch ------------------------------------------------------------------
+template <int TARGET, int D>
+static void launch_window_d(const demcz_handle* h, const WindowParams& P, dim3 grid)
+{
+    if (h->full_block)
+        hipLaunchKernelGGL((window_kernel<TARGET, D, true>), grid, dim3(WINDOW_BS), 0, h->stream, P);
+    else
+        hipLaunchKernelGGL((window_kernel<TARGET, D, false>), grid, dim3(WINDOW_BS), 0, h->stream, P);
+}
+
+template <int TARGET>
+static void launch_window_generic(const demcz_handle* h, const WindowParams& P, dim3 grid)
+{
+    const size_t lds = (size_t)(3 * P.d + 1) * WINDOW_BS * sizeof(double);
+    hipLaunchKernelGGL(window_kernel_generic<TARGET>, grid, dim3(WINDOW_BS), lds, h->stream, P);
+}
+
+static int32_t launch_window(demcz_handle* h, const WindowParams& P)
+{
+    const dim3 grid((unsigned)((P.N + WINDOW_BS - 1) / WINDOW_BS));
+    const int d = P.d;
+    switch (h->cfg.target_kind) {
+    case DEMCZ_TARGET_MVNORMAL:
+        switch (d) {
+        case 2: launch_window_d<TARGET_MVNORMAL, 2>(h, P, grid); break;
+        case 3: launch_window_d<TARGET_MVNORMAL, 3>(h, P, grid); break;
+        case 4: launch_window_d<TARGET_MVNORMAL, 4>(h, P, grid); break;
+        case 5: launch_window_d<TARGET_MVNORMAL, 5>(h, P, grid); break;
+        case 8: launch_window_d<TARGET_MVNORMAL, 8>(h, P, grid); break;
+        case 10: launch_window_d<TARGET_MVNORMAL, 10>(h, P, grid); break;
+        case 20: launch_window_d<TARGET_MVNORMAL, 20>(h, P, grid); break;
+        default: launch_window_generic<TARGET_MVNORMAL>(h, P, grid); break;
+        }
+        break;
+    case DEMCZ_TARGET_ISO_QUAD:
+        switch (d) {
+        case 10: launch_window_d<TARGET_ISO_QUAD, 10>(h, P, grid); break;
+        default: launch_window_generic<TARGET_ISO_QUAD>(h, P, grid); break;
+        }
+        break;
+    case DEMCZ_TARGET_LINREG_SSE:
+        switch (d) {
+        case 10: launch_window_d<TARGET_LINREG_SSE, 10>(h, P, grid); break;
+        case 26: launch_window_d<TARGET_LINREG_SSE, 26>(h, P, grid); break;
+        default: launch_window_generic<TARGET_LINREG_SSE>(h, P, grid); break;
+        }
+        break;
+    default: return fail(h, DEMCZ_ERR_STATE, "demcz_run: host-callback target uses demcz_propose/accept_commit");
+    }
+    HIPCHK(h, hipGetLastError());
+    ++h->launches;
+    return DEMCZ_OK;
+}
+
+static int32_t append_after_window(demcz_handle* h)
+{
+    // the window kernel did not append (sharded or external): all-gather and scatter
+    const int d = h->cfg.d;
+    const int64_t N = h->cfg.N;
+    if (h->comm && h->nranks > 1) {
+        const int64_t total = N * h->nranks;
+        if (h->M + total > h->cfg.Mcap) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_run: Z capacity exceeded");
+        NCCLCHK(h, ncclAllGather(h->dX, h->d_gather, (size_t)N * d, ncclDouble, h->comm, h->stream));
+        const int64_t tot = total * d;
+        hipLaunchKernelGGL(append_gathered_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->dZ,
+                           h->cfg.Mcap, h->M, h->d_gather, N, h->nranks, d);
+        HIPCHK(h, hipGetLastError());
+        h->M += total;
+    }
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, double gamma, const double* temperature)
+{
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (!h->has_state) return fail(h, DEMCZ_ERR_STATE, "demcz_run: call demcz_set_state first");
+    if (g_from < 1 || g_to < g_from) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_run: need 1 <= g_from <= g_to");
+    if (h->cfg.target_kind == DEMCZ_TARGET_HOST_CALLBACK)
+        return fail(h, DEMCZ_ERR_STATE, "demcz_run: host-callback target uses demcz_propose/accept_commit");
+    const bool hist = h->cfg.Gcap > 0;
+    if (hist && (g_from - h->g0 - 1 < 0 || g_to - h->g0 > h->cfg.Gcap))
+        return fail(h, DEMCZ_ERR_CAPACITY, "demcz_run: generations outside the history window (demcz_set_history_origin)");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const int64_t G = g_to - g_from + 1;
+    const int K = h->cfg.K;
+    const bool sharded = (h->comm && h->nranks > 1);
+    const bool kernel_appends = !sharded && !h->external_append;
+    // capacity check for all appends of this call
+    {
+        const int64_t nb = g_to / K - (g_from - 1) / K;
+        const int64_t rows = h->cfg.N * (sharded ? h->nranks : 1);
+        if (!h->external_append && h->M + nb * rows > h->cfg.Mcap)
+            return fail(h, DEMCZ_ERR_CAPACITY, "demcz_run: Z row capacity (Mcap) would be exceeded");
+        if (h->external_append && nb > 1)
+            return fail(h, DEMCZ_ERR_STATE, "demcz_run: with external append a call may cross at most one K boundary, at its end");
+        if (h->external_append && nb == 1 && (g_to % K) != 0)
+            return fail(h, DEMCZ_ERR_STATE, "demcz_run: with external append the K boundary must be the last generation of the call");
+    }
+    if (temperature) {
+        if (G > h->temp_cap) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (h->dtemp) HIPCHK(h, hipFree(h->dtemp));
+            h->dtemp = nullptr; h->temp_cap = 0;
+            HIPCHK(h, hipMalloc((void**)&h->dtemp, (size_t)G * sizeof(double)));
+            h->temp_cap = G;
+        }
+        // stream-ordered behind earlier windows that still read dtemp
+        HIPCHK(h, hipMemcpyAsync(h->dtemp, temperature, (size_t)G * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));   // the caller may reuse its buffer on return
+    }
+    WindowParams P;
+    P.Z = h->dZ; P.Zw = h->dZ; P.Mcap = h->cfg.Mcap;
+    P.Xcur = h->dX; P.lpcur = h->dlp;
+    P.chain = hist ? h->dchain : nullptr; P.logobj = hist ? h->dlogobj : nullptr;
+    P.changed = h->dchanged;
+    P.N = h->cfg.N; P.chain_id0 = h->cfg.chain_id0; P.d = h->cfg.d;
+    P.gamma = gamma; P.seed = h->cfg.seed; P.S = h->S; P.Nblocks = h->cfg.Nblocks;
+    P.block_offsets = h->d_block_offsets; P.slot_of = h->d_slot_of; P.eps = h->d_eps;
+    P.tp = target_params(h);
+    int64_t g = g_from;
+    while (g <= g_to) {
+        const int64_t next_boundary = ((g - 1) / K + 1) * K;      // first multiple of K that is >= g
+        const int64_t w_end = std::min(next_boundary, g_to);
+        P.M = h->M;
+        P.g_first = g;
+        P.ngen = (int32_t)(w_end - g + 1);
+        P.slot_first = hist ? (g - h->g0 - 1) : 0;
+        P.temperature = temperature ? h->dtemp + (g - g_from) : nullptr;
+        const bool boundary = (w_end % K) == 0;
+        P.do_append = (boundary && kernel_appends) ? 1 : 0;
+        int32_t rc = launch_window(h, P);
+        if (rc) return rc;
+        if (boundary) {
+            if (kernel_appends) h->M += h->cfg.N;
+            else if (sharded) { rc = append_after_window(h); if (rc) return rc; }
+        }
+        g = w_end + 1;
+    }
+    h->g_done = g_to;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_synchronize(demcz_handle* h)
+{
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DEMCZ_OK;
+}
+
+static int32_t check_hist_range(demcz_handle* h, int64_t g_from, int64_t g_to, const char* who)
+{
+    if (h->cfg.Gcap <= 0) return fail(h, DEMCZ_ERR_STATE, std::string(who) + ": handle keeps no history (Gcap = 0)");
+    if (g_from < 1 || g_to < g_from || g_from - h->g0 - 1 < 0 || g_to - h->g0 > h->cfg.Gcap)
+        return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, std::string(who) + ": generations outside the history window");
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_get_history(demcz_handle* h, int64_t g_from, int64_t g_to, double* chain, double* log_obj)
+{
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    int32_t rc = check_hist_range(h, g_from, g_to, "demcz_get_history");
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const int64_t N = h->cfg.N, G = g_to - g_from + 1, s0 = g_from - h->g0 - 1;
+    const int d = h->cfg.d;
+    if (chain)
+        HIPCHK(h, hipMemcpyAsync(chain, h->dchain + (size_t)N * d * s0, (size_t)N * d * G * sizeof(double),
+                                 hipMemcpyDeviceToHost, h->stream));
+    if (log_obj)
+        HIPCHK(h, hipMemcpyAsync(log_obj, h->dlogobj + (size_t)N * s0, (size_t)N * G * sizeof(double),
+                                 hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_get_changed(demcz_handle* h, int64_t g_from, int64_t g_to, int64_t* changed)
+{
+    if (!h || !changed) return DEMCZ_ERR_INVALID_ARGUMENT;
+    int32_t rc = check_hist_range(h, g_from, g_to, "demcz_get_changed");
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const int64_t G = g_to - g_from + 1, s0 = g_from - h->g0 - 1;
+    std::vector<unsigned int> tmp((size_t)G);
+    HIPCHK(h, hipMemcpyAsync(tmp.data(), h->dchanged + s0, (size_t)G * sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int64_t i = 0; i < G; ++i) changed[i] = (int64_t)tmp[(size_t)i];
+    return DEMCZ_OK;
+}
+
+// ---- R-hat ---------------------------------------------------------------------------------------
+struct RhatPlan { int64_t N, w, s0, n, nd; int d, nchunk; double *S1, *S2, *mean_j, *s2_j, *sums; };
+
+static int32_t rhat_prepare(demcz_handle* h, int64_t g_from, int64_t g_to, RhatPlan& r, bool compute)
+{
+    int32_t rc = check_hist_range(h, g_from, g_to, "demcz_rhat");
+    if (rc) return rc;
+    r.N = h->cfg.N; r.w = g_to - g_from + 1; r.s0 = g_from - h->g0 - 1; r.d = h->cfg.d;
+    r.n = r.w / 2;                                            // utils.jl:4
+    if (r.n < 2) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_rhat: window needs at least 4 generations");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    r.nchunk = (int)std::min<int64_t>(std::max<int64_t>(1, r.n / 32), 32);
+    r.nd = r.N * r.d;
+    const int64_t need = 2 * (2 * r.nchunk * r.nd) + 2 * (2 * r.nd) + 4 * r.d;
+    rc = ensure_scratch(h, need);
+    if (rc) return rc;
+    r.S1 = h->d_scratch;
+    r.S2 = r.S1 + 2 * r.nchunk * r.nd;
+    r.mean_j = r.S2 + 2 * r.nchunk * r.nd;
+    r.s2_j = r.mean_j + 2 * r.nd;
+    r.sums = r.s2_j + 2 * r.nd;          // [0,d): stage 0 / grand mean; [d,3d): stage 1
+    if (compute) {
+        const int bs = 256;
+        const unsigned gx = (unsigned)((r.nd + bs - 1) / bs);
+        hipLaunchKernelGGL(rhat_moments_kernel, dim3(gx, 2 * r.nchunk), dim3(bs), 0, h->stream, h->dchain, r.N, r.d, r.s0, r.n, r.nchunk, r.S1, r.S2);
+        hipLaunchKernelGGL(rhat_chainstats_kernel, dim3(gx, 2), dim3(bs), 0, h->stream, h->dchain, r.N, r.d, r.s0, r.n, r.nchunk, r.S1, r.S2, r.mean_j, r.s2_j);
+        HIPCHK(h, hipGetLastError());
+    }
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_rhat_partial(demcz_handle* h, int64_t g_from, int64_t g_to, int32_t stage, const double* grand, double* out)
+{
+    if (!h || !out || (stage != 0 && stage != 1) || (stage == 1 && !grand)) return DEMCZ_ERR_INVALID_ARGUMENT;
+    RhatPlan r;
+    int32_t rc = rhat_prepare(h, g_from, g_to, r, true);
+    if (rc) return rc;
+    const int d = r.d;
+    if (stage == 0) {
+        hipLaunchKernelGGL(rhat_reduce_kernel, dim3(d), dim3(256), 0, h->stream, r.mean_j, r.s2_j, r.N, d, 0, (const double*)nullptr, r.sums);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(out, r.sums, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    } else {
+        HIPCHK(h, hipMemcpyAsync(r.sums, grand, (size_t)d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(rhat_reduce_kernel, dim3(d), dim3(256), 0, h->stream, r.mean_j, r.s2_j, r.N, d, 1, (const double*)r.sums, r.sums + d);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(out, r.sums + d, (size_t)2 * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_rhat(demcz_handle* h, int64_t g_from, int64_t g_to, double* rhat)
+{
+    if (!h || !rhat) return DEMCZ_ERR_INVALID_ARGUMENT;
+    RhatPlan r;
+    int32_t rc = rhat_prepare(h, g_from, g_to, r, true);
+    if (rc) return rc;
+    const int d = r.d;
+    const int64_t n = r.n;
+    const int64_t m = 2 * r.N * h->nranks;                   // utils.jl:5
+    const bool sharded = (h->comm && h->nranks > 1);
+    double* sums = r.sums;
+    hipLaunchKernelGGL(rhat_reduce_kernel, dim3(d), dim3(256), 0, h->stream, r.mean_j, r.s2_j, r.N, d, 0, (const double*)nullptr, sums);
+    HIPCHK(h, hipGetLastError());
+    if (sharded) NCCLCHK(h, ncclAllReduce(sums, sums, (size_t)d, ncclDouble, ncclSum, h->comm, h->stream));
+    // grand mean = sum_j mean_j / m   (all split-chains have equal length: utils.jl:10)
+    HIPCHK(h, hipMemcpyAsync(h->d_stage, sums, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int p = 0; p < d; ++p) h->d_stage[p] /= (double)m;
+    HIPCHK(h, hipMemcpyAsync(sums, h->d_stage, (size_t)d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(rhat_reduce_kernel, dim3(d), dim3(256), 0, h->stream, r.mean_j, r.s2_j, r.N, d, 1, (const double*)sums, sums + d);
+    HIPCHK(h, hipGetLastError());
+    if (sharded) NCCLCHK(h, ncclAllReduce(sums + d, sums + d, (size_t)2 * d, ncclDouble, ncclSum, h->comm, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_stage, sums + d, (size_t)2 * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int p = 0; p < d; ++p) {
+        const double B = (double)n / (double)(m - 1) * h->d_stage[p];                  // utils.jl:13
+        const double W = h->d_stage[d + p] / (double)m;                                // utils.jl:15
+        const double varhat = (double)(n - 1) / (double)n * W + B / (double)n;        // utils.jl:16
+        rhat[p] = std::sqrt(varhat / W);                                               // utils.jl:18
+    }
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_accept_ratio(demcz_handle* h, int64_t g_from, int64_t g_to, double* ratio)
+{
+    if (!h || !ratio) return DEMCZ_ERR_INVALID_ARGUMENT;
+    int32_t rc = check_hist_range(h, g_from, g_to, "demcz_accept_ratio");
+    if (rc) return rc;
+    const int64_t N = h->cfg.N, w = g_to - g_from + 1, s0 = g_from - h->g0 - 1;
+    if (w < 2) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_accept_ratio: need at least 2 generations");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    rc = ensure_scratch(h, N);
+    if (rc) return rc;
+    hipLaunchKernelGGL(changed_per_chain_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, h->stream, h->dlogobj, N, s0, w, h->d_scratch);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(ratio, h->d_scratch, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_mean_cov(demcz_handle* h, int64_t g_from, int64_t g_to, double* mean, double* cov)
+{
+    if (!h || !mean || !cov) return DEMCZ_ERR_INVALID_ARGUMENT;
+    int32_t rc = check_hist_range(h, g_from, g_to, "demcz_mean_cov");
+    if (rc) return rc;
+    const int64_t N = h->cfg.N, w = g_to - g_from + 1, s0 = g_from - h->g0 - 1;
+    const int d = h->cfg.d;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    rc = ensure_scratch(h, (int64_t)d * (d + 1) + d);
+    if (rc) return rc;
+    double* sums = h->d_scratch;
+    hipLaunchKernelGGL(meancov_kernel, dim3(d, d + 1), dim3(256), 0, h->stream, h->dchain, N, d, s0, w, sums);
+    HIPCHK(h, hipGetLastError());
+    std::vector<double> hs((size_t)d * (d + 1)), ref((size_t)d);
+    HIPCHK(h, hipMemcpyAsync(hs.data(), sums, hs.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpy2DAsync(ref.data(), sizeof(double), h->dchain + (size_t)N * d * s0, (size_t)N * sizeof(double),
+                               sizeof(double), (size_t)d, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const double cnt = (double)(N * w);
+    std::vector<double> dm((size_t)d);      // mean - ref
+    for (int p = 0; p < d; ++p) { dm[p] = hs[(size_t)p + (size_t)d * d] / cnt; mean[p] = ref[p] + dm[p]; }
+    for (int p = 0; p < d; ++p)
+        for (int q = 0; q < d; ++q) cov[p + d * q] = hs[(size_t)p + (size_t)d * q] / cnt - dm[p] * dm[q];   // utils.jl:104
+    return DEMCZ_OK;
+}
+
+// ---- host-closure mode -------------------------------------------------------------------------
+namespace demcz {
+__global__ void propose_kernel(const WindowParams P, int ib, uint64_t blk0, double* Xprop, double* logu)
+{
+    extern __shared__ double lds[];
+    const int64_t c = (int64_t)blockIdx.x * WINDOW_BS + threadIdx.x;
+    if (c >= P.N) return;
+    const int tid = threadIdx.x;
+    const int d = P.d;
+    rng_state st;
+    rng_seek(st, P.seed, (uint64_t)(P.chain_id0 + c), blk0);
+    uint64_t r1, r2, i1, i2;
+    rng_next(st, r1, r2);
+    draw_rows(r1, r2, (uint64_t)P.M, i1, i2);
+    const int b = P.block_offsets[ib + 1] - P.block_offsets[ib];
+    const int nn = (b == 1) ? 1 : b;
+    const int npairs = (nn + 1) / 2;
+    for (int pr = 0; pr < npairs; ++pr) {
+        rng_next(st, r1, r2);
+        double z0, z1;
+        normal_pair(r1, r2, z0, z1);
+        lds[(2 * pr) * WINDOW_BS + tid] = z0;
+        lds[(2 * pr + 1) * WINDOW_BS + tid] = z1;
+    }
+    const double scale = (b == 1) ? P.gamma : P.gamma / sqrt((double)(2 * b));
+    const int32_t* so = P.slot_of + ib * d;
+    for (int p = 0; p < d; ++p) {
+        const int t = so[p];
+        double xv = P.Xcur[c + P.N * p];
+        if (t >= 0) {
+            double diff = P.Z[(int64_t)i1 + P.Mcap * p] - P.Z[(int64_t)i2 + P.Mcap * p];
+            double zt = lds[((b == 1) ? 0 : t) * WINDOW_BS + tid];
+            double t1 = scale * diff;
+            double t2 = P.eps[p] * zt;
+            double delta = t1 + t2;
+            xv = xv + delta;
+        }
+        Xprop[c + P.N * p] = xv;
+    }
+    rng_next(st, r1, r2);
+    logu[c] = dm_log(u_open(r1));
+}
+
+__global__ void accept_commit_kernel(int64_t N, int d, double* Xcur, double* lpcur, const double* Xprop,
+                                     const double* lpprop, const double* logu, int has_T, double T)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    const double lp = lpcur[c], lpp = lpprop[c];
+    double dlt = lpp - lp;
+    if (has_T) dlt = dlt / T;
+    if (logu[c] < dlt) {
+        for (int p = 0; p < d; ++p) Xcur[c + N * p] = Xprop[c + N * p];
+        lpcur[c] = lpp;
+    }
+}
+
+__global__ void end_generation_kernel(int64_t N, int d, const double* Xcur, const double* lpcur, const double* lp_before,
+                                      double* chain, double* logobj, unsigned int* changed, int64_t slot,
+                                      double* Z, int64_t Mcap, int64_t M, int do_append)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool ch = false;
+    if (c < N) {
+        const double lp = lpcur[c];
+        for (int p = 0; p < d; ++p) {
+            const double xv = Xcur[c + N * p];
+            if (chain) chain[c + N * (p + (int64_t)d * slot)] = xv;
+            if (do_append) Z[M + c + Mcap * p] = xv;
+        }
+        if (logobj) logobj[c + N * slot] = lp;
+        ch = lp != lp_before[c];
+    }
+    const unsigned long long m = __ballot(ch);
+    if (m != 0ull && (unsigned)__lane_id() == (unsigned)__ffsll((long long)m) - 1u)
+        atomicAdd(&changed[slot], (unsigned int)__popcll(m));
+}
+}  // namespace demcz
+
+extern "C" int32_t demcz_propose(demcz_handle* h, int64_t g, int32_t ib, double gamma, double* Xprop)
+{
+    if (!h || !Xprop) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (h->cfg.target_kind != DEMCZ_TARGET_HOST_CALLBACK) return fail(h, DEMCZ_ERR_STATE, "demcz_propose: handle was not created with DEMCZ_TARGET_HOST_CALLBACK");
+    if (!h->has_state) return fail(h, DEMCZ_ERR_STATE, "demcz_propose: call demcz_set_state first");
+    if (g < 1 || ib < 0 || ib >= h->cfg.Nblocks) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_propose: bad generation or block");
+    if (h->proposal_pending) return fail(h, DEMCZ_ERR_STATE, "demcz_propose: previous proposal not committed");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const int64_t N = h->cfg.N;
+    const int d = h->cfg.d;
+    if (!h->gen_open) {
+        HIPCHK(h, hipMemcpyAsync(h->dlp_before, h->dlp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        h->gen_open = true;
+    }
+    int64_t off = 0;
+    for (int t = 0; t < ib; ++t) off += blockstep_nblk(h->block_offsets[t + 1] - h->block_offsets[t]);
+    WindowParams P{};
+    P.Z = h->dZ; P.Mcap = h->cfg.Mcap; P.M = h->M; P.Xcur = h->dX; P.N = N; P.chain_id0 = h->cfg.chain_id0; P.d = d;
+    P.gamma = gamma; P.seed = h->cfg.seed; P.block_offsets = h->d_block_offsets; P.slot_of = h->d_slot_of; P.eps = h->d_eps;
+    const uint64_t blk0 = (uint64_t)(g - 1) * (uint64_t)h->S + (uint64_t)off;
+    hipLaunchKernelGGL(propose_kernel, dim3((unsigned)((N + WINDOW_BS - 1) / WINDOW_BS)), dim3(WINDOW_BS),
+                       (size_t)(d + 1) * WINDOW_BS * sizeof(double), h->stream, P, (int)ib, blk0, h->dXprop, h->dlogu);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(Xprop, h->dXprop, (size_t)N * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->proposal_pending = true;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_accept_commit(demcz_handle* h, const double* logp_prop, const double* temperature)
+{
+    if (!h || !logp_prop) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (!h->proposal_pending) return fail(h, DEMCZ_ERR_STATE, "demcz_accept_commit: no pending proposal");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const int64_t N = h->cfg.N;
+    int32_t rc = ensure_scratch(h, N);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_scratch, logp_prop, (size_t)N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(accept_commit_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, N, h->cfg.d, h->dX,
+                       h->dlp, h->dXprop, h->d_scratch, h->dlogu, temperature ? 1 : 0, temperature ? *temperature : 1.0);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->proposal_pending = false;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_end_generation(demcz_handle* h, int64_t g)
+{
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (h->cfg.target_kind != DEMCZ_TARGET_HOST_CALLBACK) return fail(h, DEMCZ_ERR_STATE, "demcz_end_generation: host-callback handles only");
+    if (h->proposal_pending || !h->gen_open) return fail(h, DEMCZ_ERR_STATE, "demcz_end_generation: no open generation or uncommitted proposal");
+    const bool hist = h->cfg.Gcap > 0;
+    if (hist && (g - h->g0 - 1 < 0 || g - h->g0 > h->cfg.Gcap)) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_end_generation: outside the history window");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const int64_t N = h->cfg.N;
+    const bool boundary = (g % h->cfg.K) == 0;
+    const bool sharded = (h->comm && h->nranks > 1);
+    const bool kappend = boundary && !sharded && !h->external_append;
+    if (kappend && h->M + N > h->cfg.Mcap) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_end_generation: Z capacity exceeded");
+    hipLaunchKernelGGL(end_generation_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, h->stream, N, h->cfg.d, h->dX, h->dlp,
+                       h->dlp_before, hist ? h->dchain : nullptr, hist ? h->dlogobj : nullptr, h->dchanged,
+                       hist ? (g - h->g0 - 1) : 0, h->dZ, h->cfg.Mcap, h->M, kappend ? 1 : 0);
+    HIPCHK(h, hipGetLastError());
+    if (kappend) h->M += N;
+    else if (boundary && sharded) { int32_t rc = append_after_window(h); if (rc) return rc; }
+    h->gen_open = false;
+    h->g_done = g;
+    return DEMCZ_OK;
+}
+
+// ---- multi-GPU -------------------------------------------------------------------------------------
+extern "C" int32_t demcz_comm_unique_id(void* unique_id_128B)
+{
+    if (!unique_id_128B) return DEMCZ_ERR_INVALID_ARGUMENT;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return fail(nullptr, DEMCZ_ERR_HIP, "ncclGetUniqueId failed");
+    std::memcpy(unique_id_128B, &id, sizeof(id));
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_comm_init(demcz_handle* h, const void* unique_id_128B, int32_t nranks, int32_t rank)
+{
+    if (!h || !unique_id_128B || nranks < 1 || rank < 0 || rank >= nranks) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (h->comm) return fail(h, DEMCZ_ERR_STATE, "demcz_comm_init: communicator already initialised");
+    if (h->cfg.chain_id0 != (int64_t)rank * h->cfg.N)
+        return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_comm_init: chain_id0 must be rank * N (equal shards in rank order)");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id_128B, sizeof(id));
+    NCCLCHK(h, ncclCommInitRank(&h->comm, nranks, id, rank));
+    h->nranks = nranks;
+    h->rank = rank;
+    if (nranks > 1) HIPCHK(h, hipMalloc((void**)&h->d_gather, (size_t)h->cfg.N * h->cfg.d * nranks * sizeof(double)));
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_export_current_device(demcz_handle* h, double* X_device)
+{
+    if (!h || !X_device) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (!h->has_state) return fail(h, DEMCZ_ERR_STATE, "demcz_export_current_device: no state");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    HIPCHK(h, hipMemcpyAsync(X_device, h->dX, (size_t)h->cfg.N * h->cfg.d * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_append_rows_device(demcz_handle* h, const double* rows_device, int64_t nrows, int64_t ldrows)
+{
+    if (!h || !rows_device || nrows < 1 || ldrows < nrows) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (!h->has_state) return fail(h, DEMCZ_ERR_STATE, "demcz_append_rows_device: no state");
+    if (h->M + nrows > h->cfg.Mcap) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_append_rows_device: Z capacity exceeded");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const int64_t tot = nrows * h->cfg.d;
+    hipLaunchKernelGGL(append_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->dZ, h->cfg.Mcap, h->M,
+                       rows_device, nrows, ldrows, h->cfg.d);
+    HIPCHK(h, hipGetLastError());
+    h->M += nrows;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_append_rows(demcz_handle* h, const double* rows, int64_t nrows, int64_t ldrows)
+{
+    if (!h || !rows || nrows < 1 || ldrows < nrows) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (!h->has_state) return fail(h, DEMCZ_ERR_STATE, "demcz_append_rows: no state");
+    if (h->M + nrows > h->cfg.Mcap) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_append_rows: Z capacity exceeded");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    HIPCHK(h, hipMemcpy2DAsync(h->dZ + h->M, (size_t)h->cfg.Mcap * sizeof(double), rows, (size_t)ldrows * sizeof(double),
+                               (size_t)nrows * sizeof(double), (size_t)h->cfg.d, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // the caller may reuse `rows` on return
+    h->M += nrows;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_set_external_append(demcz_handle* h, int32_t enabled)
+{
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    h->external_append = enabled != 0;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_get_info(const demcz_handle* h, int64_t* M, int64_t* launches_window, int32_t* lanes_per_chain)
+{
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (M) *M = h->M;
+    if (launches_window) *launches_window = h->launches;
+    if (lanes_per_chain) *lanes_per_chain = h->lanes;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_selftest_draws(int32_t device_id, uint64_t seed, uint64_t chain, uint64_t blk0, int32_t n,
+                                        uint64_t* words, double* normals, double* logu)
+{
+    if (n < 1 || !words || !normals || !logu) return DEMCZ_ERR_INVALID_ARGUMENT;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, DEMCZ_ERR_NO_DEVICE, "demcz_selftest_draws: no HIP device visible");
+    if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, DEMCZ_ERR_HIP, "hipSetDevice failed");
+    uint64_t* dw = nullptr; double* dn = nullptr; double* dl = nullptr;
+    int32_t rc = DEMCZ_OK;
+    if (hipMalloc((void**)&dw, (size_t)n * 16) != hipSuccess || hipMalloc((void**)&dn, (size_t)n * 16) != hipSuccess ||
+        hipMalloc((void**)&dl, (size_t)n * 8) != hipSuccess) {
+        rc = fail(nullptr, DEMCZ_ERR_HIP, "demcz_selftest_draws: hipMalloc failed");
+    } else {
+        hipLaunchKernelGGL(selftest_draws_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, seed, chain, blk0, (int)n, dw, dn, dl);
+        if (hipMemcpy(words, dw, (size_t)n * 16, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(normals, dn, (size_t)n * 16, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(logu, dl, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(nullptr, DEMCZ_ERR_HIP, "demcz_selftest_draws: kernel or copy failed");
+    }
+    if (dw) (void)hipFree(dw);
+    if (dn) (void)hipFree(dn);
+    if (dl) (void)hipFree(dl);
+    return rc;
+}

@@ -1,0 +1,474 @@
+// demcz_kernels.h -- HIP kernels of the DEMCz chain update (gfx950).
+//
+// K1  window_kernel      propose -> log-density -> Metropolis accept -> history/Z write for one
+//                        K-window of generations; one lane per chain ("throughput layout").
+//                        Restates runchain!/update_blocks/update_demcz_chain_block/accept of
+//                        src/demcz.jl:80-93,167-203 and the tempered overloads of
+//                        src/demcz_anneal.jl:67-80,142-178 for all N chains at once.
+// K4  append_rows_kernel scatter gathered rows into the parameter-major archive
+// K5  rhat_*             split-R-hat moments (src/utils.jl:2-20)
+// K6  logp_kernel        initial log-densities (src/demcz.jl:17)
+// K7  accept_ratio / mean_cov reductions (src/utils.jl:61, 96-111)
+#pragma once
+
+#include "demcz_device.h"
+
+#pragma clang fp contract(off)
+
+namespace demcz {
+
+enum { TARGET_MVNORMAL = 0, TARGET_ISO_QUAD = 1, TARGET_LINREG_SSE = 2, TARGET_HOST_CALLBACK = 3 };
+
+constexpr int MAX_D = 64;        // generic (runtime-d) path keeps x / xprop / normals in LDS
+constexpr int WINDOW_BS = 64;    // one wave per workgroup: small N spreads over as many CUs as waves
+
+struct TargetParams {
+    const double* mu;        // d
+    const double* Wp;        // MVNORMAL: packed row-major lower triangle, row i at i(i+1)/2
+    double c0;
+    const double* design;    // LINREG: row-major nobs x d (one observation's regressors contiguous)
+    const double* yobs;
+    int64_t nobs;
+};
+
+struct WindowParams {
+    // archive
+    const double* Z;         // Mcap x d, parameter-major (column-major, ld Mcap)
+    double* Zw;              // same buffer, for the append
+    int64_t Mcap;
+    int64_t M;               // rows visible to every proposal of this window
+    // chain state
+    double* Xcur;            // N x d (ld N)
+    double* lpcur;           // N
+    // history (slot s holds generation g0 + 1 + s)
+    double* chain;           // N x d x Gcap or nullptr
+    double* logobj;          // N x Gcap or nullptr
+    unsigned int* changed;   // Gcap counters
+    const double* temperature;  // per generation of this window, or nullptr
+    int64_t N;
+    int64_t chain_id0;
+    int32_t d;
+    int32_t ngen;            // generations in this window
+    int64_t g_first;         // 1-based generation index of the first one
+    int64_t slot_first;      // history slot of g_first
+    double gamma;
+    uint64_t seed;
+    int64_t S;               // Philox blocks per generation
+    int32_t Nblocks;
+    int32_t do_append;       // window ends on a K multiple and the kernel appends rows M + ic
+    const int32_t* block_offsets;
+    const int32_t* slot_of;  // Nblocks x d: position of parameter p inside block ib, or -1
+    const double* eps;
+    TargetParams tp;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Targets.  `X` is a callable j -> x_j; with a compile-time D every loop unrolls and x stays in
+// registers, W / mu / the design row come in through scalar loads (wave-uniform addresses).
+// Summation orders are part of the arithmetic spec.
+// ------------------------------------------------------------------------------------------------
+template <int TARGET, int D, class XF>
+__device__ __forceinline__ double target_logp(const TargetParams& tp, int d, XF X)
+{
+    const int dd = (D > 0) ? D : d;
+    if constexpr (TARGET == TARGET_MVNORMAL) {
+        double q = 0.0;
+#pragma unroll
+        for (int i = 0; i < dd; ++i) {
+            const double* wrow = tp.Wp + (i * (i + 1)) / 2;
+            double acc = wrow[0] * (X(0) - tp.mu[0]);
+#pragma unroll
+            for (int j = 1; j <= i; ++j) acc = fma(wrow[j], X(j) - tp.mu[j], acc);
+            q = (i == 0) ? acc * acc : fma(acc, acc, q);
+        }
+        return fma(-0.5, q, tp.c0);
+    } else if constexpr (TARGET == TARGET_ISO_QUAD) {
+        double q = 0.0;
+#pragma unroll
+        for (int i = 0; i < dd; ++i) {
+            double r = X(i) - tp.mu[i];
+            q = (i == 0) ? r * r : fma(r, r, q);
+        }
+        return -q;
+    } else {
+        double sse = 0.0;
+        for (int64_t o = 0; o < tp.nobs; ++o) {
+            const double* row = tp.design + o * dd;
+            double acc = row[0] * X(0);
+#pragma unroll
+            for (int j = 1; j < dd; ++j) acc = fma(row[j], X(j), acc);
+            double r = tp.yobs[o] - acc;
+            sse = (o == 0) ? r * r : fma(r, r, sse);
+        }
+        return -0.5 * sse;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1, compile-time D.  FULL: one block covering 0..D-1 in order (the default blockindex = [1:Npar],
+// DEMC.jl:41) -- no LDS, no branches.  Otherwise blocks come from the CSR tables and the normals
+// of a block-step are staged per lane in LDS (uniform runtime index).
+// ------------------------------------------------------------------------------------------------
+template <int TARGET, int D, bool FULL>
+__global__ void __launch_bounds__(WINDOW_BS) window_kernel(const WindowParams P)
+{
+    __shared__ double zlds[FULL ? 1 : (D + 1) * WINDOW_BS];
+    const int64_t c = (int64_t)blockIdx.x * WINDOW_BS + threadIdx.x;
+    if (c >= P.N) return;
+    const int tid = threadIdx.x;
+
+    double x[D];
+#pragma unroll
+    for (int p = 0; p < D; ++p) x[p] = P.Xcur[c + P.N * p];
+    double lp = P.lpcur[c];
+
+    rng_state st;
+    rng_seek(st, P.seed, (uint64_t)(P.chain_id0 + c), (uint64_t)(P.g_first - 1) * (uint64_t)P.S);
+
+    for (int gi = 0; gi < P.ngen; ++gi) {
+        const double lp_before = lp;
+        const int nblocks = FULL ? 1 : P.Nblocks;
+        for (int ib = 0; ib < nblocks; ++ib) {
+            uint64_t r1, r2, i1, i2;
+            rng_next(st, r1, r2);
+            draw_rows(r1, r2, (uint64_t)P.M, i1, i2);
+            double xp[D];
+            if constexpr (FULL) {
+                double zn[(D == 1) ? 2 : ((D + 1) / 2) * 2];
+                constexpr int NPAIRS = (D == 1) ? 1 : (D + 1) / 2;
+#pragma unroll
+                for (int pr = 0; pr < NPAIRS; ++pr) {
+                    rng_next(st, r1, r2);
+                    normal_pair(r1, r2, zn[2 * pr], zn[2 * pr + 1]);
+                }
+                const double scale = (D == 1) ? P.gamma : P.gamma / sqrt((double)(2 * D));
+#pragma unroll
+                for (int p = 0; p < D; ++p) {
+                    double diff = P.Z[(int64_t)i1 + P.Mcap * p] - P.Z[(int64_t)i2 + P.Mcap * p];
+                    double t1 = scale * diff;
+                    double t2 = P.eps[p] * zn[(D == 1) ? 0 : p];
+                    double delta = t1 + t2;
+                    xp[p] = x[p] + delta;
+                }
+            } else {
+                const int b = P.block_offsets[ib + 1] - P.block_offsets[ib];
+                const int nn = (b == 1) ? 1 : b;
+                const int npairs = (nn + 1) / 2;
+                for (int pr = 0; pr < npairs; ++pr) {
+                    rng_next(st, r1, r2);
+                    double z0, z1;
+                    normal_pair(r1, r2, z0, z1);
+                    zlds[(2 * pr) * WINDOW_BS + tid] = z0;
+                    zlds[(2 * pr + 1) * WINDOW_BS + tid] = z1;
+                }
+                const double scale = (b == 1) ? P.gamma : P.gamma / sqrt((double)(2 * b));
+                const int32_t* so = P.slot_of + ib * D;
+#pragma unroll
+                for (int p = 0; p < D; ++p) {
+                    const int t = so[p];
+                    if (t >= 0) {
+                        double diff = P.Z[(int64_t)i1 + P.Mcap * p] - P.Z[(int64_t)i2 + P.Mcap * p];
+                        double zt = zlds[((b == 1) ? 0 : t) * WINDOW_BS + tid];
+                        double t1 = scale * diff;
+                        double t2 = P.eps[p] * zt;
+                        double delta = t1 + t2;
+                        xp[p] = x[p] + delta;
+                    } else {
+                        xp[p] = x[p];
+                    }
+                }
+            }
+            rng_next(st, r1, r2);
+            const double logu = dm_log(u_open(r1));
+            const double lpp = target_logp<TARGET, D>(P.tp, D, [&](int j) { return xp[j]; });
+            double dlt = lpp - lp;
+            if (P.temperature) dlt = dlt / P.temperature[gi];
+            const bool acc = logu < dlt;
+#pragma unroll
+            for (int p = 0; p < D; ++p) x[p] = acc ? xp[p] : x[p];
+            lp = acc ? lpp : lp;
+        }
+        const int64_t slot = P.slot_first + gi;
+        if (P.chain) {
+#pragma unroll
+            for (int p = 0; p < D; ++p) P.chain[c + P.N * (p + (int64_t)D * slot)] = x[p];
+            P.logobj[c + P.N * slot] = lp;
+        }
+        const unsigned long long m = __ballot(lp != lp_before);
+        if (m != 0ull && (unsigned)__lane_id() == (unsigned)__ffsll((long long)m) - 1u)
+            atomicAdd(&P.changed[slot], (unsigned int)__popcll(m));
+    }
+#pragma unroll
+    for (int p = 0; p < D; ++p) P.Xcur[c + P.N * p] = x[p];
+    P.lpcur[c] = lp;
+    if (P.do_append) {
+#pragma unroll
+        for (int p = 0; p < D; ++p) P.Zw[P.M + c + P.Mcap * p] = x[p];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1, runtime d (any d <= MAX_D, any block structure): x, xprop and the normals live in LDS,
+// one column per lane (conflict-free: address = index * WINDOW_BS + lane).
+// ------------------------------------------------------------------------------------------------
+template <int TARGET>
+__global__ void __launch_bounds__(WINDOW_BS) window_kernel_generic(const WindowParams P)
+{
+    extern __shared__ double lds[];
+    const int d = P.d;
+    double* xs = lds;                         // d x BS
+    double* xps = lds + d * WINDOW_BS;        // d x BS
+    double* zs = lds + 2 * d * WINDOW_BS;     // (d+1) x BS
+    const int64_t c = (int64_t)blockIdx.x * WINDOW_BS + threadIdx.x;
+    if (c >= P.N) return;
+    const int tid = threadIdx.x;
+
+    for (int p = 0; p < d; ++p) xs[p * WINDOW_BS + tid] = P.Xcur[c + P.N * p];
+    double lp = P.lpcur[c];
+    rng_state st;
+    rng_seek(st, P.seed, (uint64_t)(P.chain_id0 + c), (uint64_t)(P.g_first - 1) * (uint64_t)P.S);
+
+    for (int gi = 0; gi < P.ngen; ++gi) {
+        const double lp_before = lp;
+        for (int ib = 0; ib < P.Nblocks; ++ib) {
+            uint64_t r1, r2, i1, i2;
+            rng_next(st, r1, r2);
+            draw_rows(r1, r2, (uint64_t)P.M, i1, i2);
+            const int b = P.block_offsets[ib + 1] - P.block_offsets[ib];
+            const int nn = (b == 1) ? 1 : b;
+            const int npairs = (nn + 1) / 2;
+            for (int pr = 0; pr < npairs; ++pr) {
+                rng_next(st, r1, r2);
+                double z0, z1;
+                normal_pair(r1, r2, z0, z1);
+                zs[(2 * pr) * WINDOW_BS + tid] = z0;
+                zs[(2 * pr + 1) * WINDOW_BS + tid] = z1;
+            }
+            const double scale = (b == 1) ? P.gamma : P.gamma / sqrt((double)(2 * b));
+            const int32_t* so = P.slot_of + ib * d;
+            for (int p = 0; p < d; ++p) {
+                const int t = so[p];
+                double xv = xs[p * WINDOW_BS + tid];
+                if (t >= 0) {
+                    double diff = P.Z[(int64_t)i1 + P.Mcap * p] - P.Z[(int64_t)i2 + P.Mcap * p];
+                    double zt = zs[((b == 1) ? 0 : t) * WINDOW_BS + tid];
+                    double t1 = scale * diff;
+                    double t2 = P.eps[p] * zt;
+                    double delta = t1 + t2;
+                    xv = xv + delta;
+                }
+                xps[p * WINDOW_BS + tid] = xv;
+            }
+            rng_next(st, r1, r2);
+            const double logu = dm_log(u_open(r1));
+            const double lpp = target_logp<TARGET, 0>(P.tp, d, [&](int j) { return xps[j * WINDOW_BS + tid]; });
+            double dlt = lpp - lp;
+            if (P.temperature) dlt = dlt / P.temperature[gi];
+            if (logu < dlt) {
+                for (int p = 0; p < d; ++p) xs[p * WINDOW_BS + tid] = xps[p * WINDOW_BS + tid];
+                lp = lpp;
+            }
+        }
+        const int64_t slot = P.slot_first + gi;
+        if (P.chain) {
+            for (int p = 0; p < d; ++p) P.chain[c + P.N * (p + (int64_t)d * slot)] = xs[p * WINDOW_BS + tid];
+            P.logobj[c + P.N * slot] = lp;
+        }
+        const unsigned long long m = __ballot(lp != lp_before);
+        if (m != 0ull && (unsigned)__lane_id() == (unsigned)__ffsll((long long)m) - 1u)
+            atomicAdd(&P.changed[slot], (unsigned int)__popcll(m));
+    }
+    for (int p = 0; p < d; ++p) {
+        double xv = xs[p * WINDOW_BS + tid];
+        P.Xcur[c + P.N * p] = xv;
+        if (P.do_append) P.Zw[P.M + c + P.Mcap * p] = xv;
+    }
+    P.lpcur[c] = lp;
+}
+
+// K6: log-density of n points X (n x d, ld ldX) -> out.  Used for the initial log_objcurrent.
+template <int TARGET>
+__global__ void logp_kernel(TargetParams tp, int d, const double* X, int64_t ldX, int64_t n, double* out)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    out[c] = target_logp<TARGET, 0>(tp, d, [&](int j) { return X[c + ldX * j]; });
+}
+
+// K4: rows (nrows x d, ld ldrows) -> Z[M .. M+nrows) (ld Mcap)
+__global__ void append_rows_kernel(double* Z, int64_t Mcap, int64_t M, const double* rows, int64_t nrows,
+                                   int64_t ldrows, int d)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * d) return;
+    const int64_t r = i % nrows, p = i / nrows;
+    Z[M + r + Mcap * p] = rows[r + ldrows * p];
+}
+
+// Staging slab of an all-gather over R shards, each shard an n_loc x d column-major matrix
+// stored contiguously ([R][d][n_loc]) -> rows M + r*n_loc + j of Z.
+__global__ void append_gathered_kernel(double* Z, int64_t Mcap, int64_t M, const double* slab, int64_t n_loc,
+                                       int R, int d)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per = n_loc * d;
+    if (i >= per * R) return;
+    const int64_t r = i / per, rem = i % per, p = rem / n_loc, j = rem % n_loc;
+    Z[M + r * n_loc + j + Mcap * p] = slab[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: split-R-hat (src/utils.jl:2-20).  Window of w generations starting at history slot s0,
+// n = floor(w/2); split-chain (h, c) covers slots s0 + h n .. s0 + h n + n - 1.
+//   rhat_moments_kernel: per (chain, parameter, half, time-chunk) shifted sums
+//       S1 = sum (x - x0), S2 = sum (x - x0)^2, x0 = first sample of the half (same shift for
+//       every chunk of a half, so chunk partials simply add).
+//   rhat_chainstats_kernel: mean_j = x0 + S1/n, s_j^2 = (S2 - S1^2/n)/(n-1) per split-chain.
+//   rhat_reduce_kernel stage 0: sum_j mean_j per parameter; stage 1 (given the grand mean):
+//       sum_j (mean_j - grand)^2 and sum_j s_j^2.  Fixed-order tree reductions: deterministic.
+// ------------------------------------------------------------------------------------------------
+__global__ void rhat_moments_kernel(const double* chain, int64_t N, int d, int64_t s0, int64_t n, int nchunk,
+                                    double* S1, double* S2)
+{
+    // grid: x over N*d (chain fastest), y = h * nchunk + chunk
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * d) return;
+    const int h = blockIdx.y / nchunk, ck = blockIdx.y % nchunk;
+    const int64_t per = (n + nchunk - 1) / nchunk;
+    const int64_t t0 = ck * per, t1 = (t0 + per < n) ? t0 + per : n;
+    const int64_t stride = N * d;
+    const double* base = chain + i + stride * (s0 + h * n);
+    const double x0 = base[0];
+    double a = 0.0, b = 0.0;
+    for (int64_t t = t0; t < t1; ++t) {
+        double v = base[stride * t] - x0;
+        a += v;
+        b = fma(v, v, b);
+    }
+    const int64_t o = i + stride * blockIdx.y;
+    S1[o] = a;
+    S2[o] = b;
+}
+
+__global__ void rhat_chainstats_kernel(const double* chain, int64_t N, int d, int64_t s0, int64_t n, int nchunk,
+                                       const double* S1, const double* S2, double* mean_j, double* s2_j)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * d) return;
+    const int h = blockIdx.y;
+    const int64_t stride = N * d;
+    const double x0 = chain[i + stride * (s0 + h * n)];
+    double a = 0.0, b = 0.0;
+    for (int ck = 0; ck < nchunk; ++ck) {
+        a += S1[i + stride * (h * nchunk + ck)];
+        b += S2[i + stride * (h * nchunk + ck)];
+    }
+    const double nn = (double)n;
+    mean_j[i + stride * h] = x0 + a / nn;
+    s2_j[i + stride * h] = (b - a * a / nn) / (nn - 1.0);
+}
+
+// one workgroup of 256 per parameter; out[p] (stage 0) or out[p], out[d + p] (stage 1)
+__global__ void __launch_bounds__(256) rhat_reduce_kernel(const double* mean_j, const double* s2_j, int64_t N, int d,
+                                                          int stage, const double* grand, double* out)
+{
+    __shared__ double ra[256], rb[256];
+    const int p = blockIdx.x;
+    const int64_t stride = N * d;
+    double a = 0.0, b = 0.0;
+    const double gm = stage ? grand[p] : 0.0;
+    for (int64_t k = threadIdx.x; k < 2 * N; k += 256) {
+        const int64_t h = k / N, c = k % N;
+        const double mj = mean_j[c + N * p + stride * h];
+        if (stage == 0) {
+            a += mj;
+        } else {
+            const double dv = mj - gm;
+            a = fma(dv, dv, a);
+            b += s2_j[c + N * p + stride * h];
+        }
+    }
+    ra[threadIdx.x] = a;
+    rb[threadIdx.x] = b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            ra[threadIdx.x] += ra[threadIdx.x + s];
+            rb[threadIdx.x] += rb[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[p] = ra[0];
+        if (stage) out[d + p] = rb[0];
+    }
+}
+
+// K7a: per-chain count of generations in slots s0+1 .. s0+w-1 whose log_obj differs from the
+// previous slot (src/utils.jl:61).
+__global__ void changed_per_chain_kernel(const double* logobj, int64_t N, int64_t s0, int64_t w, double* ratio)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    int64_t k = 0;
+    double prev = logobj[c + N * s0];
+    for (int64_t t = 1; t < w; ++t) {
+        double cur = logobj[c + N * (s0 + t)];
+        k += (cur != prev) ? 1 : 0;
+        prev = cur;
+    }
+    ratio[c] = (double)k / (double)(w - 1);
+}
+
+// K7b: sums for mean_cov_chain (src/utils.jl:96-111).  One workgroup per (p, q) pair (q = d means
+// "mean of p"), shifted by ref[p] = first element so the one-pass covariance keeps its digits.
+__global__ void __launch_bounds__(256) meancov_kernel(const double* chain, int64_t N, int d, int64_t s0, int64_t w,
+                                                      double* out /* d*(d+1) */)
+{
+    __shared__ double ra[256];
+    const int p = blockIdx.x, q = blockIdx.y;
+    const int64_t stride = N * d;
+    const double rp = chain[N * p + stride * s0];
+    const double rq = (q < d) ? chain[N * q + stride * s0] : 0.0;
+    double a = 0.0;
+    const int64_t total = N * w;
+    for (int64_t k = threadIdx.x; k < total; k += 256) {
+        const int64_t c = k % N, t = k / N;
+        const double vp = chain[c + N * p + stride * (s0 + t)] - rp;
+        if (q < d) {
+            const double vq = chain[c + N * q + stride * (s0 + t)] - rq;
+            a = fma(vp, vq, a);
+        } else {
+            a += vp;
+        }
+    }
+    ra[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) ra[threadIdx.x] += ra[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[p + d * q] = ra[0];
+}
+
+// Self-test of the draw pipeline: for block index blk0 + i of chain `chain`, the two raw words,
+// the Box-Muller pair and log(u_open(r1)).
+__global__ void selftest_draws_kernel(uint64_t seed, uint64_t chain, uint64_t blk0, int n, uint64_t* words,
+                                      double* normals, double* logu)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    rng_state st;
+    rng_seek(st, seed, chain, blk0 + (uint64_t)i);
+    uint64_t r1, r2;
+    rng_next(st, r1, r2);
+    words[2 * i] = r1;
+    words[2 * i + 1] = r2;
+    double z0, z1;
+    normal_pair(r1, r2, z0, z1);
+    normals[2 * i] = z0;
+    normals[2 * i + 1] = z1;
+    logu[i] = dm_log(u_open(r1));
+}
+
+}  // namespace demcz

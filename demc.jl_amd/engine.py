@@ -1,0 +1,219 @@
+"""``HipEngine``: one ``demcz_handle`` (one GPU, one shard of chains) behind a small Python face.
+
+The drivers in ``sampler.py`` talk to an engine through the methods below and nothing else;
+the product only ever constructs ``HipEngine``.  (tests/ inject an oracle-backed engine with
+the same methods to exercise the host logic, e.g. the world_size-2 gloo tests, on machines
+without a GPU.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import DemczError
+from .targets import is_device_target
+
+
+def blocks_to_csr(blockindex, d):
+    """DEMCopt.blockindex (1-based ranges / index vectors, DEMC.jl:29) is given here as a list
+    of 0-based index sequences; returns CSR (offsets, indices) as int32 arrays."""
+    blocks = [np.asarray(list(b), dtype=np.int64) for b in blockindex]
+    for b in blocks:
+        if b.size == 0 or b.min() < 0 or b.max() >= d:
+            raise ValueError("block indices must be 0-based and within [0, d)")
+    offs = np.zeros(len(blocks) + 1, dtype=np.int32)
+    offs[1:] = np.cumsum([b.size for b in blocks])
+    idx = np.concatenate(blocks).astype(np.int32)
+    return offs, idx
+
+
+class HipEngine:
+    """Device state of one shard: Z replica, current states, history, RNG position."""
+
+    def __init__(self, *, N, d, K, Mcap, Gcap, blockindex, eps_scale, seed, target, chain_id0=0,
+                 device_id=0, stream=None, lanes_per_chain=0):
+        self._L = _lib.load()
+        self.N, self.d, self.K, self.Mcap, self.Gcap = int(N), int(d), int(K), int(Mcap), int(Gcap)
+        self.chain_id0 = int(chain_id0)
+        self._keep = []
+        offs, idx = blocks_to_csr(blockindex, d)
+        eps = _lib.f64(eps_scale)
+        if eps.shape != (d,):
+            raise ValueError("eps_scale must have d entries")
+        self._keep += [offs, idx, eps]
+        cfg = _lib.Config()
+        cfg.N, cfg.chain_id0, cfg.d, cfg.K = self.N, self.chain_id0, self.d, self.K
+        cfg.Mcap, cfg.Gcap, cfg.Nblocks = self.Mcap, self.Gcap, len(offs) - 1
+        cfg.block_offsets, cfg.block_indices = _lib.ptr(offs, _lib._ip), _lib.ptr(idx, _lib._ip)
+        cfg.eps_scale, cfg.seed, cfg.device_id = _lib.ptr(eps), int(seed) & (2**64 - 1), int(device_id)
+        cfg.stream = stream
+        cfg.lanes_per_chain = int(lanes_per_chain)
+        if is_device_target(target):
+            if target.d != d:
+                raise ValueError("target dimension != d")
+            cfg.target_kind = target.kind
+            target.fill(cfg, self._keep)
+        elif callable(target):
+            cfg.target_kind = _lib.TARGET_HOST_CALLBACK
+        else:
+            raise TypeError("target must be a device target or a callable")
+        self.host_callback = cfg.target_kind == _lib.TARGET_HOST_CALLBACK
+        self._h = C.c_void_p()
+        rc = self._L.demcz_create(C.byref(self._h), C.byref(cfg))
+        if rc != 0:
+            raise DemczError(rc, (self._L.demcz_last_error(None) or b"").decode())
+
+    # -- plumbing -----------------------------------------------------------------------------
+    def _chk(self, rc):
+        if rc != 0:
+            raise DemczError(rc, (self._L.demcz_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.demcz_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- state --------------------------------------------------------------------------------
+    def set_state(self, X, logp, Z):
+        X = _lib.f64(X, "F")
+        Z = _lib.f64(Z, "F")
+        if X.shape != (self.N, self.d) or Z.ndim != 2 or Z.shape[1] != self.d:
+            raise ValueError("X must be N x d and Z must be M0 x d")
+        lp = _lib.f64(logp) if logp is not None else None
+        if lp is not None and lp.shape != (self.N,):
+            raise ValueError("logp must have N entries")
+        self._chk(self._L.demcz_set_state(self._h, _lib.ptr(X), _lib.ptr(lp), _lib.ptr(Z), Z.shape[0], Z.shape[0]))
+
+    def get_state(self, with_Z=True):
+        X = np.empty((self.N, self.d), order="F")
+        lp = np.empty(self.N)
+        M = C.c_int64()
+        self._chk(self._L.demcz_get_state(self._h, _lib.ptr(X), _lib.ptr(lp), None, 0, C.byref(M)))
+        Z = None
+        if with_Z:
+            Z = np.empty((M.value, self.d), order="F")
+            self._chk(self._L.demcz_get_state(self._h, None, None, _lib.ptr(Z), M.value, None))
+        return X, lp, Z, int(M.value)
+
+    @property
+    def M(self):
+        M = C.c_int64()
+        self._chk(self._L.demcz_get_info(self._h, C.byref(M), None, None))
+        return int(M.value)
+
+    def info(self):
+        M, nl, lanes = C.c_int64(), C.c_int64(), C.c_int32()
+        self._chk(self._L.demcz_get_info(self._h, C.byref(M), C.byref(nl), C.byref(lanes)))
+        return dict(M=int(M.value), window_launches=int(nl.value), lanes_per_chain=int(lanes.value))
+
+    def set_history_origin(self, g0):
+        self._chk(self._L.demcz_set_history_origin(self._h, int(g0)))
+
+    # -- the hot path -------------------------------------------------------------------------
+    def run(self, g_from, g_to, gamma, temperature=None):
+        t = None
+        if temperature is not None:
+            t = _lib.f64(temperature)
+            if t.shape != (g_to - g_from + 1,):
+                raise ValueError("one temperature per generation")
+        self._chk(self._L.demcz_run(self._h, int(g_from), int(g_to), float(gamma), _lib.ptr(t)))
+
+    def synchronize(self):
+        self._chk(self._L.demcz_synchronize(self._h))
+
+    # -- results ------------------------------------------------------------------------------
+    def get_history(self, g_from, g_to, chain=True, log_obj=True):
+        G = g_to - g_from + 1
+        ch = np.empty((self.N, self.d, G), order="F") if chain else None
+        lo = np.empty((self.N, G), order="F") if log_obj else None
+        self._chk(self._L.demcz_get_history(self._h, int(g_from), int(g_to), _lib.ptr(ch), _lib.ptr(lo)))
+        return ch, lo
+
+    def get_changed(self, g_from, g_to):
+        out = np.zeros(g_to - g_from + 1, dtype=np.int64)
+        self._chk(self._L.demcz_get_changed(self._h, int(g_from), int(g_to), _lib.ptr(out, _lib._lp)))
+        return out
+
+    def rhat(self, g_from, g_to):
+        out = np.empty(self.d)
+        self._chk(self._L.demcz_rhat(self._h, int(g_from), int(g_to), _lib.ptr(out)))
+        return out
+
+    def rhat_partial(self, g_from, g_to, stage, grand):
+        out = np.empty(self.d if stage == 0 else 2 * self.d)
+        g = _lib.f64(grand) if grand is not None else None
+        self._chk(self._L.demcz_rhat_partial(self._h, int(g_from), int(g_to), int(stage), _lib.ptr(g), _lib.ptr(out)))
+        return out
+
+    def accept_ratio(self, g_from, g_to):
+        out = np.empty(self.N)
+        self._chk(self._L.demcz_accept_ratio(self._h, int(g_from), int(g_to), _lib.ptr(out)))
+        return out
+
+    def mean_cov(self, g_from, g_to):
+        mean = np.empty(self.d)
+        cov = np.empty((self.d, self.d), order="F")
+        self._chk(self._L.demcz_mean_cov(self._h, int(g_from), int(g_to), _lib.ptr(mean), _lib.ptr(cov)))
+        return mean, cov
+
+    # -- host-closure mode ----------------------------------------------------------------------
+    def propose(self, g, ib, gamma):
+        Xp = np.empty((self.N, self.d), order="F")
+        self._chk(self._L.demcz_propose(self._h, int(g), int(ib), float(gamma), _lib.ptr(Xp)))
+        return Xp
+
+    def accept_commit(self, logp_prop, temperature=None):
+        lp = _lib.f64(logp_prop)
+        t = C.byref(C.c_double(float(temperature))) if temperature is not None else None
+        self._chk(self._L.demcz_accept_commit(self._h, _lib.ptr(lp), C.cast(t, _lib._dp) if t is not None else None))
+
+    def end_generation(self, g):
+        self._chk(self._L.demcz_end_generation(self._h, int(g)))
+
+    # -- multi-GPU ------------------------------------------------------------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = self._L.demcz_comm_unique_id(buf)
+        if rc != 0:
+            raise DemczError(rc, (self._L.demcz_last_error(None) or b"").decode())
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, nranks: int, rank: int):
+        buf = C.create_string_buffer(unique_id, 128)
+        self._chk(self._L.demcz_comm_init(self._h, buf, int(nranks), int(rank)))
+
+    def set_external_append(self, enabled: bool):
+        self._chk(self._L.demcz_set_external_append(self._h, 1 if enabled else 0))
+
+    def append_rows(self, rows):
+        rows = _lib.f64(rows, "F")
+        if rows.ndim != 2 or rows.shape[1] != self.d:
+            raise ValueError("rows must be nrows x d")
+        self._chk(self._L.demcz_append_rows(self._h, _lib.ptr(rows), rows.shape[0], rows.shape[0]))
+
+    def export_current_device(self, device_ptr: int):
+        self._chk(self._L.demcz_export_current_device(self._h, C.c_void_p(device_ptr)))
+
+    def append_rows_device(self, device_ptr: int, nrows: int, ldrows: int):
+        self._chk(self._L.demcz_append_rows_device(self._h, C.c_void_p(device_ptr), int(nrows), int(ldrows)))
+
+
+def selftest_draws(seed, chain, blk0, n, device_id=0):
+    """Device draw pipeline for blocks blk0..blk0+n-1 of chain's stream (see demcz.h)."""
+    L = _lib.load()
+    words = np.zeros(2 * n, dtype=np.uint64)
+    normals = np.zeros(2 * n)
+    logu = np.zeros(n)
+    rc = L.demcz_selftest_draws(int(device_id), int(seed), int(chain), int(blk0), int(n),
+                                words.ctypes.data_as(C.POINTER(C.c_uint64)), _lib.ptr(normals), _lib.ptr(logu))
+    if rc != 0:
+        raise DemczError(rc, (L.demcz_last_error(None) or b"").decode())
+    return words.reshape(n, 2), normals.reshape(n, 2), logu

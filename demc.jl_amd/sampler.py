@@ -1,0 +1,446 @@
+"""Host drivers with the reference's call surface.
+
+Mirrors (same names, argument meaning, defaults and return shapes):
+
+* ``DEMCopt`` / ``demcopt(Npar; ...)``          src/DEMC.jl:24-43
+* ``MC``                                        src/DEMC.jl:10-15
+* ``demcz_sample(logobj, Zmat, opts; prevrun)`` src/demcz.jl:1-3 and the positional driver :9-63
+* ``demcz_anneal(logobj, Zmat, opts; ...)``     src/demcz_anneal.jl:14-65
+* ``tempbaseline``                              src/demcz_anneal.jl:1-3
+
+Everything from ``runchain!`` down runs on the GPU through ``include/demcz.h``; this file only
+does what the reference's drivers do around that call: set-up, the slab loop, the autostop
+test, gamma adaptation, truncation / prevrun concatenation of the results.
+
+Differences from the reference that a caller can see:
+
+* indices are 0-based (``blockindex=[range(0, Npar)]``), symbols are strings
+  (``autostop="Rhat"`` / ``"no"``);
+* chains start at the last N rows of ``Zmat`` as the reference documents (``init="last_rows"``);
+  ``init="reference_zeros"`` reproduces what the serial driver actually does (Q1);
+* all N chains of a generation see the same archive (Q2); the reference's serial driver lets
+  chain ic+1 see chain ic's fresh row inside generations divisible by K;
+* ``Z[:M]`` is returned (Q7); ``padded_Z=True`` returns the zero-padded matrix instead;
+* randomness comes from ``seed`` (Philox4x32-10 streams per chain), not a global RNG.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from dataclasses import dataclass, field
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+
+from .engine import HipEngine
+from .targets import is_device_target
+
+
+# --------------------------------------------------------------------------------------------
+# types (DEMC.jl:10-43)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class MC:
+    """Result container, src/DEMC.jl:10-15.  Arrays are column-major like the Julia ones."""
+    chain: np.ndarray            # N x d x G   parameter population for all generations
+    log_obj: np.ndarray          # N x G       log obj along the chain
+    Xcurrent: np.ndarray         # N x d       population
+    log_objcurrent: np.ndarray   # N           log obj values
+
+
+@dataclass
+class DEMCopt:
+    """Mutable options struct, src/DEMC.jl:24-39 (fields in the same order)."""
+    N: int
+    K: int
+    Ngeneration: int
+    Nblocks: int
+    blockindex: list
+    eps_scale: np.ndarray
+    γ: float
+    verbose: bool
+    print_step: int
+    T0: float
+    TN: float
+    autostop: str
+    autostop_every: int
+    autostop_Rhat: float
+
+    @property
+    def gamma(self):
+        return self.γ
+
+    @gamma.setter
+    def gamma(self, v):
+        self.γ = v
+
+
+def demcopt(Npar, *, N=4, K=10, Ngeneration=5000, Nblocks=1, blockindex=None, eps_scale=None, γ=2.38,
+            gamma=None, verbose=True, print_step=100, T0=3, TN=1e-3, autostop="Rhat", autostop_every=1000,
+            autostop_Rhat=1.05) -> DEMCopt:
+    """Keyword constructor with the defaults of src/DEMC.jl:41."""
+    if blockindex is None:
+        blockindex = [range(0, Npar)]
+    if eps_scale is None:
+        eps_scale = 1e-4 * np.ones(Npar)
+    if gamma is not None:
+        γ = gamma
+    return DEMCopt(N, K, Ngeneration, Nblocks, list(blockindex), np.asarray(eps_scale, dtype=np.float64), float(γ),
+                   verbose, print_step, float(T0), float(TN), _sym(autostop), autostop_every, autostop_Rhat)
+
+
+def _sym(s):
+    s = str(s).lstrip(":")
+    if s not in ("Rhat", "no"):
+        raise ValueError("autostop must be 'Rhat' or 'no'")
+    return s
+
+
+def tempbaseline(ig, Ng, T0, TN):
+    """``T0*(TN/T0)^(ig/Ng)``, src/demcz_anneal.jl:1-3."""
+    return T0 * (TN / T0) ** (ig / Ng)
+
+
+DEFAULT_ADAPT = {"adapt": True, "minγ": 0.1, "maxγ": 4.0, "adapt_every": 500}   # demcz_anneal.jl:14
+
+
+# --------------------------------------------------------------------------------------------
+# sharding: one process per GPU, chains split in rank order, Z replicated
+# --------------------------------------------------------------------------------------------
+@dataclass
+class Sharding:
+    """How the N chains are spread.
+
+    ``mode="rccl"``: one engine per process; the library all-gathers the K-boundary rows and
+    all-reduces the R-hat moments itself (``demcz_comm_init``).  ``mode="host"``: the driver does
+    the exchange through ``all_gather`` / ``all_reduce_sum`` callables on host arrays (any
+    backend: torch.distributed gloo/nccl, MPI ...), optionally with several in-process shards
+    (``local_shards`` > 1) -- used to prove that results do not depend on the sharding.
+    """
+    rank: int = 0
+    world_size: int = 1
+    mode: str = "host"
+    local_shards: int = 1
+    all_gather: Optional[Callable] = None       # np.ndarray -> list of np.ndarray, one per rank
+    all_reduce_sum: Optional[Callable] = None   # np.ndarray -> np.ndarray
+    broadcast_bytes: Optional[Callable] = None  # (bytes or None, src=0) -> bytes
+
+    @property
+    def total_shards(self):
+        return self.world_size * self.local_shards
+
+
+class _Runner:
+    """The engines of this process plus the exchange between shards."""
+
+    def __init__(self, engines, sharding: Optional[Sharding], K, N_total, d):
+        self.engines = engines
+        self.sh = sharding
+        self.K, self.N_total, self.d = K, N_total, d
+        self.lib_exchange = sharding is not None and sharding.mode == "rccl" and sharding.world_size > 1
+        self.host_exchange = sharding is not None and not self.lib_exchange and sharding.total_shards > 1
+        if self.host_exchange:
+            for e in engines:
+                e.set_external_append(True)
+
+    # generation loop --------------------------------------------------------------------------
+    def run(self, g_from, g_to, gamma, temperature=None):
+        if not self.host_exchange:
+            for e in self.engines:
+                e.run(g_from, g_to, gamma, temperature)
+            return
+        g = g_from
+        while g <= g_to:
+            w_end = min(((g - 1) // self.K + 1) * self.K, g_to)
+            t = None if temperature is None else temperature[g - g_from:w_end - g_from + 1]
+            for e in self.engines:
+                e.run(g, w_end, gamma, t)
+            if w_end % self.K == 0:
+                rows = np.concatenate([e.get_state(with_Z=False)[0] for e in self.engines], axis=0)
+                if self.sh.world_size > 1:
+                    rows = np.concatenate(self.sh.all_gather(np.ascontiguousarray(rows)), axis=0)
+                rows = np.asfortranarray(rows)
+                for e in self.engines:
+                    e.append_rows(rows)
+            g = w_end + 1
+
+    # statistics -------------------------------------------------------------------------------
+    def _allsum(self, a):
+        if self.sh is not None and self.sh.world_size > 1 and not self.lib_exchange:
+            return self.sh.all_reduce_sum(np.ascontiguousarray(a))
+        return a
+
+    def rhat(self, g_from, g_to):
+        """Rhat_gelman over all N_total chains, src/utils.jl:2-20."""
+        if not self.host_exchange:
+            return self.engines[0].rhat(g_from, g_to)
+        d = self.d
+        n = (g_to - g_from + 1) // 2
+        m = 2 * self.N_total
+        s0 = self._allsum(sum(e.rhat_partial(g_from, g_to, 0, None) for e in self.engines))
+        grand = s0 / m
+        s1 = self._allsum(sum(e.rhat_partial(g_from, g_to, 1, grand) for e in self.engines))
+        B = n / (m - 1) * s1[:d]
+        W = s1[d:] / m
+        varhat = (n - 1) / n * W + B / n
+        return np.sqrt(varhat / W)
+
+    def changed(self, g_from, g_to):
+        c = sum(e.get_changed(g_from, g_to) for e in self.engines)
+        if self.sh is not None and self.sh.world_size > 1:
+            c = self.sh.all_reduce_sum(np.ascontiguousarray(c.astype(np.float64))).astype(np.int64)
+        return c
+
+    def accept_ratio_mean(self, g_from, g_to):
+        r = np.concatenate([e.accept_ratio(g_from, g_to) for e in self.engines])
+        s = np.array([r.sum(), float(r.size)])
+        if self.sh is not None and self.sh.world_size > 1:
+            s = self.sh.all_reduce_sum(s)
+        return s[0] / s[1]
+
+    # results ----------------------------------------------------------------------------------
+    def history(self, g_from, g_to):
+        parts = [e.get_history(g_from, g_to) for e in self.engines]
+        chain = np.asfortranarray(np.concatenate([p[0] for p in parts], axis=0))
+        lobj = np.asfortranarray(np.concatenate([p[1] for p in parts], axis=0))
+        return chain, lobj
+
+    def state(self):
+        sts = [e.get_state(with_Z=(i == 0)) for i, e in enumerate(self.engines)]
+        X = np.asfortranarray(np.concatenate([s[0] for s in sts], axis=0))
+        lp = np.concatenate([s[1] for s in sts])
+        return X, lp, sts[0][2], sts[0][3]
+
+    def synchronize(self):
+        for e in self.engines:
+            e.synchronize()
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+
+
+def _make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp, *, seed, sharding, device_id,
+                 engine_factory, lanes_per_chain, stream):
+    M0, d = Zmat.shape
+    if M0 < 2:
+        raise ValueError("Zmat needs at least 2 rows (two distinct archive rows per proposal, demcz.jl:176-179)")
+    sh = sharding
+    shards = sh.total_shards if sh else 1
+    if N % shards:
+        raise ValueError("N must be divisible by the number of shards")
+    n_loc = N // shards
+    Mcap = M0 + int(math.ceil(N * Ngeneration / K))                     # demcz.jl:11
+    nloc_shards = sh.local_shards if sh else 1
+    first = (sh.rank * nloc_shards) if sh else 0
+    factory = engine_factory or HipEngine
+    engines = []
+    for s in range(nloc_shards):
+        c0 = (first + s) * n_loc
+        e = factory(N=n_loc, d=d, K=K, Mcap=Mcap, Gcap=Ngeneration, blockindex=blockindex, eps_scale=eps_scale,
+                    seed=seed, target=logobj, chain_id0=c0, device_id=device_id, stream=stream,
+                    lanes_per_chain=lanes_per_chain)
+        e.set_state(X[c0:c0 + n_loc], None if logp is None else logp[c0:c0 + n_loc], Zmat)
+        engines.append(e)
+    if sh and sh.mode == "rccl" and sh.world_size > 1:
+        uid = engines[0].comm_unique_id() if sh.rank == 0 else None
+        uid = sh.broadcast_bytes(uid)
+        engines[0].comm_init(uid, sh.world_size, sh.rank)
+    return _Runner(engines, sh, K, N, d)
+
+
+def _initial_state(logobj, Zmat, N, Ngeneration, K, prevrun, init):
+    """demcz.jl:13-22.  Returns (X, logp or None)."""
+    M0, d = Zmat.shape
+    if prevrun is None:
+        if init == "last_rows":
+            if M0 < N:
+                raise ValueError("init='last_rows' needs at least N rows in Zmat")
+            X = np.array(Zmat[M0 - N:M0, :], dtype=np.float64, order="F")
+        elif init == "reference_zeros":
+            # demcz.jl:11,15: the slice is taken from the zero-padded matrix
+            pad = int(math.ceil(N * Ngeneration / K))
+            padded = np.vstack([Zmat, np.zeros((pad, d))])
+            X = np.array(padded[padded.shape[0] - N:, :], dtype=np.float64, order="F")
+        else:
+            raise ValueError("init must be 'last_rows' or 'reference_zeros'")
+        logp = None
+        if not is_device_target(logobj):
+            logp = np.array([float(logobj(X[i, :].copy())) for i in range(N)])      # demcz.jl:17
+        return X, logp
+    X = np.array(prevrun.chain[:, :, -1], dtype=np.float64, order="F")             # demcz.jl:20
+    logp = np.array(prevrun.log_objcurrent, dtype=np.float64).reshape(-1)          # demcz.jl:21
+    return X, logp
+
+
+def _run_generations(runner, logobj, g_from, g_to, gamma, Nblocks, temperature=None):
+    """Device targets: one call.  Python closures: the split propose / evaluate / commit loop."""
+    if is_device_target(logobj):
+        runner.run(g_from, g_to, gamma, temperature)
+        return
+    eng = runner.engines[0]
+    for g in range(g_from, g_to + 1):
+        T = None if temperature is None else float(temperature[g - g_from])
+        for ib in range(Nblocks):
+            Xp = eng.propose(g, ib, gamma)
+            lp = np.array([float(logobj(Xp[i, :].copy())) for i in range(Xp.shape[0])])   # demcz.jl:189
+            eng.accept_commit(lp, T)
+        eng.end_generation(g)
+
+
+def _finish(runner, prevrun, G, padded_Z, Mcap):
+    chain, lobj = runner.history(1, G)
+    X, lp, Z, M = runner.state()
+    if padded_Z:
+        Zp = np.zeros((Mcap, Z.shape[1]), order="F")
+        Zp[:M] = Z
+        Z = Zp
+    if prevrun is not None:                                                          # demcz.jl:58-59
+        chain = np.asfortranarray(np.concatenate([prevrun.chain, chain], axis=2))
+        lobj = np.asfortranarray(np.concatenate([prevrun.log_obj, lobj], axis=1))
+    return MC(chain, lobj, X, lp), Z
+
+
+def print_status(runner, ig, printlast=500):
+    """src/demcz.jl:65-78"""
+    lo, hi = max(1, ig - printlast), max(1, ig)
+    chain, lobj = runner.history(lo, hi)
+    print("-----------------------")
+    print(f"iteration {ig}")
+    print(f"average par = {chain.mean(axis=(0, 2))}")
+    print(f"average val = {lobj.mean()}")
+    print("-----------------------")
+
+
+def print_status_anneal(runner, ig):
+    """src/demcz_anneal.jl:5-12"""
+    _, lobj = runner.history(1, ig)
+    print("-----------------------")
+    print(f"iteration {ig}")
+    print(f"bestval = {lobj.max()}")
+    print("-----------------------")
+
+
+# --------------------------------------------------------------------------------------------
+# demcz_sample (demcz.jl:1-63)
+# --------------------------------------------------------------------------------------------
+def demcz_sample(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockindex=None, eps_scale=None, γ=2.38, *,
+                 prevrun=None, verbose=True, print_step=100, autostop="no", autostop_Rhat=1.01,
+                 autostop_every=1000, seed=0, init="last_rows", padded_Z=False, sharding=None, device_id=0,
+                 lanes_per_chain=0, stream=None, engine_factory=None, return_runner=False):
+    """Serial-driver surface of src/demcz.jl: pass a ``DEMCopt`` as the third argument
+    (``demcz_sample(logobj, Zmat, opts; prevrun)``, :1-3) or the positional arguments with
+    the positional method's defaults (:9).  Returns ``(mc, Z)``."""
+    if isinstance(N, DEMCopt):
+        o = N
+        N, K, Ngeneration, Nblocks, blockindex, eps_scale, γ = o.N, o.K, o.Ngeneration, o.Nblocks, o.blockindex, o.eps_scale, o.γ
+        verbose, print_step = o.verbose, o.print_step
+        autostop, autostop_Rhat, autostop_every = o.autostop, o.autostop_Rhat, o.autostop_every
+    Zmat = np.asarray(Zmat, dtype=np.float64)
+    M0, d = Zmat.shape
+    if blockindex is None:
+        blockindex = [range(0, d)]
+    if eps_scale is None:
+        eps_scale = 1e-4 * np.ones(d)
+    if len(blockindex) != Nblocks:
+        raise ValueError("Nblocks != length(blockindex)")
+    autostop = _sym(autostop)
+    X, logp = _initial_state(logobj, Zmat, N, Ngeneration, K, prevrun, init)
+    runner = _make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp, seed=seed,
+                          sharding=sharding, device_id=device_id, engine_factory=engine_factory,
+                          lanes_per_chain=lanes_per_chain, stream=stream)
+    Mcap = M0 + int(math.ceil(N * Ngeneration / K))
+    try:
+        if verbose:
+            print("-----------------------\niteration 0\n-----------------------")
+        ig = 0
+        while ig < Ngeneration:                                                     # demcz.jl:30
+            stops = [Ngeneration]
+            if verbose:
+                stops.append((ig // print_step + 1) * print_step)
+            if autostop == "Rhat":
+                stops.append((ig // autostop_every + 1) * autostop_every)
+            nxt = min(stops)
+            _run_generations(runner, logobj, ig + 1, nxt, γ, Nblocks)
+            ig = nxt
+            if verbose and ig % print_step == 0:                                    # demcz.jl:34-38
+                print_status(runner, ig, printlast=autostop_every)
+            if autostop == "Rhat" and ig % autostop_every == 0:                     # demcz.jl:39-40
+                Rhat = runner.rhat(ig - autostop_every + 1, ig)                     # demcz.jl:41
+                if np.max(Rhat) < autostop_Rhat:                                    # demcz.jl:43
+                    # demcz.jl:42,44-46 (intent: per-chain ratio over log_obj[:, window])
+                    if runner.accept_ratio_mean(ig - autostop_every + 1, ig) < 0.1:
+                        print("Warning: accept ratio below 10% on average")
+                    res = _finish(runner, prevrun, ig, padded_Z, Mcap)              # demcz.jl:47-52
+                    return (res + (runner,)) if return_runner else res
+        res = _finish(runner, prevrun, Ngeneration, padded_Z, Mcap)                 # demcz.jl:58-62
+        return (res + (runner,)) if return_runner else res
+    finally:
+        if not return_runner:
+            runner.close()
+
+
+# --------------------------------------------------------------------------------------------
+# demcz_anneal (demcz_anneal.jl:14-65)
+# --------------------------------------------------------------------------------------------
+def demcz_anneal(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockindex=None, eps_scale=None, γ=2.38, *,
+                 prevrun=None, verbose=True, print_step=100, temperaturefun=tempbaseline, T0=3, TN=0.0,
+                 adaptγ=None, seed=0, init="last_rows", padded_Z=False, compat_serial_temp=False, sharding=None,
+                 device_id=0, lanes_per_chain=0, stream=None, engine_factory=None):
+    """Simulated-annealing variant, src/demcz_anneal.jl:14-65: tempered accept
+    ``log(u) < (lp' - lp)/T(ig)`` (:172-178), ``T(ig) = temperaturefun(ig, Ngeneration, T0, TN)``,
+    gamma adapted from the windowed acceptance ratio every ``adapt_every`` generations (:48-57).
+
+    ``compat_serial_temp=True`` reproduces the serial reference's actual schedule, which ignores
+    T0/TN/Ngeneration and uses ``tempbaseline(ig, 1000, 1, 1e-3)``."""
+    if isinstance(N, DEMCopt):
+        o = N
+        N, K, Ngeneration, Nblocks, blockindex, eps_scale, γ = o.N, o.K, o.Ngeneration, o.Nblocks, o.blockindex, o.eps_scale, o.γ
+        verbose, print_step, T0, TN = o.verbose, o.print_step, o.T0, o.TN
+    adapt = dict(DEFAULT_ADAPT)
+    if adaptγ:
+        adapt.update(adaptγ)
+    Zmat = np.asarray(Zmat, dtype=np.float64)
+    M0, d = Zmat.shape
+    if blockindex is None:
+        blockindex = [range(0, d)]
+    if eps_scale is None:
+        eps_scale = 1e-4 * np.ones(d)
+    X, logp = _initial_state(logobj, Zmat, N, Ngeneration, K, prevrun, init)
+    runner = _make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp, seed=seed,
+                          sharding=sharding, device_id=device_id, engine_factory=engine_factory,
+                          lanes_per_chain=lanes_per_chain, stream=stream)
+    Mcap = M0 + int(math.ceil(N * Ngeneration / K))
+
+    def temp(ig):
+        if compat_serial_temp:
+            return temperaturefun(ig, 1000, 1, 1e-3)                               # demcz_anneal.jl:67
+        return temperaturefun(ig, Ngeneration, T0, TN)
+
+    try:
+        ae = int(adapt["adapt_every"])
+        ig = 0
+        while ig < Ngeneration:                                                     # demcz_anneal.jl:39
+            stops = [Ngeneration]
+            if verbose:
+                stops.append((ig // print_step + 1) * print_step)
+            if adapt["adapt"]:
+                stops.append((ig // ae + 1) * ae)
+            nxt = min(stops)
+            temps = np.array([temp(g) for g in range(ig + 1, nxt + 1)], dtype=np.float64)
+            _run_generations(runner, logobj, ig + 1, nxt, γ, Nblocks, temps)
+            ig = nxt
+            if verbose and ig % print_step == 0:
+                print_status_anneal(runner, ig)                                     # demcz_anneal.jl:43-47
+            if adapt["adapt"] and ig % ae == 0:                                     # demcz_anneal.jl:48-57
+                # sum(diff(log_obj[:, ig-ae+1:ig], dims=2) .!= 0) / (N*ae): the first column of the
+                # window has no predecessor inside the window
+                ch = runner.changed(ig - ae + 2, ig) if ae > 1 else np.zeros(0)
+                accept_ratio = float(ch.sum()) / (N * ae)
+                if accept_ratio < 0.1:
+                    γ = max(adapt["minγ"], γ * 0.5)
+                elif accept_ratio > 0.5:
+                    γ = min(adapt["maxγ"], γ * 1.5)
+        return _finish(runner, prevrun, Ngeneration, padded_Z, Mcap)                # demcz_anneal.jl:60-64
+    finally:
+        runner.close()

@@ -1,0 +1,200 @@
+/*
+ * demcz.h -- C ABI of libdemcz_hip.so, the MI355X (gfx950) DEMCz chain-update engine.
+ *
+ * The reference (chrished/DEMC.jl) is a pure-Julia package with no FFI of its own; the seam this
+ * ABI occupies is the call the drivers make into runchain!:
+ *     src/demcz.jl:30-33         for ig = 1:Ngeneration, for ic = 1:N  runchain!(ic, ig, ig, ...)
+ *     src/demcz_anneal.jl:39-42  same loop, tempered
+ * Everything below that call (runchain! :80-93, update_blocks :167-172,
+ * update_demcz_chain_block :174-195, accept :197-203, and the annealer's overloads
+ * demcz_anneal.jl:67-80,142-178) runs on the device; the autostop statistic
+ * (Rhat_gelman, src/utils.jl:2-20, called at demcz.jl:41) and the acceptance counts
+ * (demcz.jl:42, demcz_anneal.jl:50) are device reductions over the on-device history.
+ * The Julia-side binding a maintainer would add is in INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; every function returns an int32 status (0 = OK);
+ *     no exceptions or longjmp cross the boundary; demcz_last_error() gives the message.
+ *   - All matrices are COLUMN-MAJOR exactly as Julia lays them out (DEMC.jl:10-15), so a
+ *     Matrix{Float64} / Array{Float64,3} is passed by pointer without transposition:
+ *       X, Xcurrent   N x d        element (ic, ip)      at ic + N*ip
+ *       Z             M x d        element (row, ip)     at row + ldZ*ip   ("parameter-major")
+ *       chain         N x d x G    element (ic, ip, ig)  at ic + N*(ip + d*ig)
+ *       log_obj       N x G        element (ic, ig)      at ic + N*ig
+ *   - Indices are 0-based on this side; generations are 1-based like the reference's `ig`
+ *     because `ig % K == 0` (demcz.jl:88) and the temperature schedule depend on the value.
+ *   - Host pointers unless a name ends in `_device`.  The caller owns every host buffer; the
+ *     library owns device memory.
+ *   - A handle is bound to one device and one stream and is not thread-safe.
+ *   - Work is enqueued asynchronously on the handle's stream; functions that return data to
+ *     host memory synchronise that stream first.
+ */
+#ifndef DEMCZ_H
+#define DEMCZ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct demcz_handle demcz_handle;
+
+enum demcz_status {
+    DEMCZ_OK = 0,
+    DEMCZ_ERR_INVALID_ARGUMENT = 1,
+    DEMCZ_ERR_HIP = 2,            /* a HIP runtime call failed (message has hipGetErrorString) */
+    DEMCZ_ERR_CAPACITY = 3,       /* Z row capacity or history capacity exceeded               */
+    DEMCZ_ERR_STATE = 4,          /* call order: e.g. run before set_state                      */
+    DEMCZ_ERR_NO_DEVICE = 5       /* no gfx950 device visible: there is NO CPU fallback         */
+};
+
+/* User log-densities the device can evaluate (the reference takes an arbitrary Julia closure,
+ * demcz.jl:189; the BASELINE configs use these three -- SURVEY.md 8(a) a11). */
+enum demcz_target_kind {
+    DEMCZ_TARGET_MVNORMAL = 0,    /* logpdf(MvNormal(mu, Sigma), x)   test/example_normpdf.jl:13-16 */
+    DEMCZ_TARGET_ISO_QUAD = 1,    /* -sum((x - mu).^2)                test/test_anneal.jl:10        */
+    DEMCZ_TARGET_LINREG_SSE = 2,  /* -0.5*sum((y - X*b).^2)           test/example_linreg.jl:32     */
+    DEMCZ_TARGET_HOST_CALLBACK = 3 /* arbitrary closure on the host: demcz_propose/accept_commit    */
+};
+
+/* Mirrors the fields of DEMCopt the hot path reads (src/DEMC.jl:24-39: N, K, Nblocks,
+ * blockindex, eps_scale) plus what a device engine needs.  POD; copied by demcz_create. */
+typedef struct demcz_config {
+    int64_t N;                    /* chains on THIS handle (DEMCopt.N, or the local shard of it)   */
+    int64_t chain_id0;            /* global id of local chain 0 (0 when not sharded): the chain's
+                                     RNG stream is Philox subsequence chain_id0 + ic, so results do
+                                     not depend on how chains are sharded over GPUs                */
+    int32_t d;                    /* Npar                                                           */
+    int32_t K;                    /* DEMCopt.K: every K-th generation the current states join Z     */
+    int64_t Mcap;                 /* row capacity of Z: M0 + ceil(N_total*Ngeneration/K), demcz.jl:11 */
+    int64_t Gcap;                 /* generations of chain/log_obj history kept on the device        */
+    int32_t Nblocks;              /* DEMCopt.Nblocks                                                */
+    const int32_t* block_offsets; /* CSR over DEMCopt.blockindex: Nblocks+1 offsets ...             */
+    const int32_t* block_indices; /* ... into 0-based parameter indices                             */
+    const double* eps_scale;      /* DEMCopt.eps_scale, d values                                    */
+    uint64_t seed;                /* Philox4x32-10 key (rocRAND-compatible stream layout)           */
+    int32_t device_id;            /* HIP device ordinal                                             */
+    int32_t target_kind;          /* enum demcz_target_kind                                         */
+    const double* mu;             /* MVNORMAL / ISO_QUAD: d                                         */
+    const double* W;              /* MVNORMAL: d x d column-major lower-triangular inv(chol(Sigma)) */
+    double c0;                    /* MVNORMAL: -0.5*(d*log(2pi) + logdet(Sigma))                    */
+    const double* design;         /* LINREG_SSE: nobs x d column-major                              */
+    const double* yobs;           /* LINREG_SSE: nobs                                               */
+    int64_t nobs;
+    void* stream;                 /* hipStream_t to enqueue on, or NULL: the library makes its own  */
+    int32_t lanes_per_chain;      /* 0 = let the library choose; 1 = one lane per chain
+                                     (throughput layout); 8 = eight lanes per chain (latency layout
+                                     for small N).  Results are bit-identical either way.          */
+    int32_t reserved0;
+} demcz_config;
+
+/* Version of this header's ABI; demcz_abi_version() must return the same number. */
+#define DEMCZ_ABI_VERSION 1
+int32_t demcz_abi_version(void);
+
+/* Create / destroy.  Replaces the driver's setup, demcz.jl:10-12 and :24 (allocation of the
+ * padded Z, M, and the MC history arrays) -- here as device buffers sized from cfg. */
+int32_t demcz_create(demcz_handle** out, const demcz_config* cfg);
+int32_t demcz_destroy(demcz_handle* h);
+const char* demcz_last_error(const demcz_handle* h);   /* h may be NULL: last create error */
+
+/* Upload the start state: demcz.jl:13-22.  X is N x d (ld N); logp is N values or NULL to have
+ * the device evaluate the target at X (demcz.jl:17); Z is M0 x d with leading dimension ldZ;
+ * 2 <= M0 <= Mcap (two distinct archive rows are needed, demcz.jl:176-179). */
+int32_t demcz_set_state(demcz_handle* h, const double* X, const double* logp,
+                        const double* Z, int64_t ldZ, int64_t M0);
+
+/* Download the current state: mc.Xcurrent, mc.log_objcurrent (DEMC.jl:13-14), Z[1:M,:] and M
+ * (demcz.jl:51).  Any pointer may be NULL.  Z is written with leading dimension ldZ >= M. */
+int32_t demcz_get_state(demcz_handle* h, double* X, double* logp, double* Z, int64_t ldZ, int64_t* M);
+
+/* Map generation index -> history slot: generation g is stored at slot g - g0 - 1, so the
+ * device keeps generations g0+1 .. g0+Gcap.  Default g0 = 0. */
+int32_t demcz_set_history_origin(demcz_handle* h, int64_t g0);
+
+/* Run generations g_from..g_to (inclusive, 1-based) for all N chains: the loop demcz.jl:30-33 /
+ * demcz_anneal.jl:39-42 with runchain! and everything below it.  gamma is DEMCopt.gamma (a
+ * per-call scalar so the annealer's adaptation, demcz_anneal.jl:48-57, can change it between
+ * calls).  temperature is NULL for the sampler or g_to-g_from+1 host values (one per
+ * generation, temperaturefun(ig, ...) of demcz_anneal.jl:69) for the tempered accept.
+ * Asynchronous.  Chains are updated synchronously within a generation (all proposals of a
+ * generation see the same M; the N rows are appended after it -- SURVEY.md Q2).
+ * When the handle is one shard of a multi-GPU run (demcz_comm_init was called) the K-boundary
+ * append all-gathers the shards' rows over RCCL so every replica of Z stays identical. */
+int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, double gamma, const double* temperature);
+
+int32_t demcz_synchronize(demcz_handle* h);
+
+/* Copy history out: mc.chain[:, :, g_from:g_to] and mc.log_obj[:, g_from:g_to] (DEMC.jl:11-12).
+ * Either pointer may be NULL. */
+int32_t demcz_get_history(demcz_handle* h, int64_t g_from, int64_t g_to, double* chain, double* log_obj);
+
+/* changed[g - g_from] = number of local chains whose log_obj at generation g differs from the
+ * one before it -- the event counted by sum(diff(log_obj, dims=2) .!= 0) at demcz.jl:42 and
+ * demcz_anneal.jl:50. */
+int32_t demcz_get_changed(demcz_handle* h, int64_t g_from, int64_t g_to, int64_t* changed);
+
+/* Split-chain Gelman-Rubin statistic over generations g_from..g_to of the on-device history:
+ * Rhat_gelman(chain[:, :, g_from:g_to], N, g_to-g_from+1, d), src/utils.jl:2-20, as called by
+ * the autostop at demcz.jl:41.  rhat receives d values.  On a sharded handle the partial
+ * moments are all-reduced so every rank gets the statistic over all N_total chains. */
+int32_t demcz_rhat(demcz_handle* h, int64_t g_from, int64_t g_to, double* rhat);
+
+/* The two reduction stages of demcz_rhat over the LOCAL chains only, for hosts that reduce
+ * across shards themselves: stage 0 -> out[0..d) = sum_j mean_j over the 2N local split-chains;
+ * stage 1 (grand = the global mean per parameter, d values) -> out[0..d) = sum_j (mean_j -
+ * grand)^2, out[d..2d) = sum_j s_j^2.  The caller sums `out` over shards between the stages
+ * and finishes with utils.jl:13-18. */
+int32_t demcz_rhat_partial(demcz_handle* h, int64_t g_from, int64_t g_to, int32_t stage,
+                           const double* grand, double* out);
+
+/* Per-chain acceptance ratio over generations g_from..g_to:
+ * sum(diff(log_obj, dims=2) .!= 0, dims=2) ./ (G-1), src/utils.jl:61.  ratio: N values. */
+int32_t demcz_accept_ratio(demcz_handle* h, int64_t g_from, int64_t g_to, double* ratio);
+
+/* mean_cov_chain over generations g_from..g_to, src/utils.jl:96-111 (1/(N*G) normalisation).
+ * mean: d values, cov: d x d column-major. */
+int32_t demcz_mean_cov(demcz_handle* h, int64_t g_from, int64_t g_to, double* mean, double* cov);
+
+/* Host-closure mode (DEMCZ_TARGET_HOST_CALLBACK): one block-step of update_demcz_chain_block
+ * split at the closure call demcz.jl:189.  demcz_propose draws (i1, i2, normals, log u) for
+ * block ib of generation g and returns the N proposals (N x d, ld N); the caller evaluates its
+ * closure; demcz_accept_commit applies demcz.jl:190-194 (tempered if temperature != NULL).
+ * demcz_end_generation performs runchain!'s bookkeeping demcz.jl:84-91. */
+int32_t demcz_propose(demcz_handle* h, int64_t g, int32_t ib, double gamma, double* Xprop);
+int32_t demcz_accept_commit(demcz_handle* h, const double* logp_prop, const double* temperature);
+int32_t demcz_end_generation(demcz_handle* h, int64_t g);
+
+/* Multi-GPU: one handle per rank (one process per GPU).  `unique_id` is the 128-byte
+ * ncclUniqueId obtained from demcz_comm_unique_id on rank 0 and broadcast by the host
+ * (torch.distributed / MPI / Distributed.jl -- plumbing).  After this call demcz_run appends
+ * through ncclAllGather and demcz_rhat all-reduces its partial moments. */
+int32_t demcz_comm_unique_id(void* unique_id_128B);
+int32_t demcz_comm_init(demcz_handle* h, const void* unique_id_128B, int32_t nranks, int32_t rank);
+
+/* Device-pointer access for hosts that do the exchange themselves (e.g. torch.distributed):
+ * copy the current N x d states into caller device memory, and append `nrows` rows given as an
+ * nrows x d column-major device matrix (ld = ldrows) to Z, bumping M. */
+int32_t demcz_export_current_device(demcz_handle* h, double* X_device);
+int32_t demcz_append_rows_device(demcz_handle* h, const double* rows_device, int64_t nrows, int64_t ldrows);
+/* Host-pointer form of the append: rows is nrows x d column-major with leading dimension ldrows. */
+int32_t demcz_append_rows(demcz_handle* h, const double* rows, int64_t nrows, int64_t ldrows);
+/* When set (non-zero), demcz_run stops short of the K-boundary append and leaves it to the
+ * caller (demcz_export_current_device + host collective + demcz_append_rows_device). */
+int32_t demcz_set_external_append(demcz_handle* h, int32_t enabled);
+
+/* Introspection for benchmarks and tests. */
+int32_t demcz_get_info(const demcz_handle* h, int64_t* M, int64_t* launches_window, int32_t* lanes_per_chain);
+
+/* Device self-test of the draw pipeline: for Philox block blk0+i of the
+ * stream of global chain `chain`, words[2i..2i+1] = the two raw 64-bit words,
+ * normals[2i..2i+1] = the Box-Muller pair, logu[i] = log(u_open(word 0)).  Lets an integrator
+ * check the device arithmetic against any host implementation of the spec, bit for bit. */
+int32_t demcz_selftest_draws(int32_t device_id, uint64_t seed, uint64_t chain, uint64_t blk0, int32_t n,
+                             uint64_t* words, double* normals, double* logu);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEMCZ_H */

@@ -1,0 +1,19 @@
+"""Shared test helpers: run the oracle and the HIP path on the same seeded inputs."""
+import numpy as np
+
+
+def oracle_sample(O, target, Z0, N, K, G, blocks, eps, gamma, seed, temperature=None, schedule=0, init="last_rows",
+                  X0=None, lp0=None):
+    """Oracle twin of demcz_sample's generation loop.  Returns dict(chain, log_obj, X, logp, Z, M, changed)."""
+    M0, d = Z0.shape
+    Mcap = M0 + -(-N * G // K)
+    prob = O.Problem(N, d, K, Mcap, eps, seed, blocks=blocks, target=target.oracle_spec())
+    if X0 is None:
+        X = np.array(Z0[M0 - N:], order="F") if init == "last_rows" else np.zeros((N, d), order="F")
+    else:
+        X = np.array(X0, order="F")
+    lp = O.logp(prob, X) if lp0 is None else np.array(lp0, dtype=np.float64)
+    Z = np.zeros((Mcap, d), order="F")
+    Z[:M0] = Z0
+    M, chain, lobj, changed = O.run(prob, X, lp, Z, M0, 1, G, gamma, temperature=temperature, schedule=schedule)
+    return dict(chain=chain, log_obj=lobj, X=X, logp=lp, Z=Z[:M].copy(), M=M, changed=changed, prob=prob)
