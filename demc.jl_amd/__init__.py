@@ -13,5 +13,6 @@ from ._lib import DemczError, build, LIB_PATH, SYMBOLS          # noqa: F401
 from .engine import HipEngine, selftest_draws                   # noqa: F401
 from .targets import MvNormalTarget, IsoQuadTarget, LinRegSSETarget, is_device_target   # noqa: F401
 from .sampler import (MC, DEMCopt, demcopt, demcz_sample, demcz_anneal, tempbaseline,   # noqa: F401
+                      make_runner, initial_state,
                       Sharding, DEFAULT_ADAPT)
 from . import workloads                                         # noqa: F401

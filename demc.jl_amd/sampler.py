@@ -220,7 +220,7 @@ class _Runner:
             e.close()
 
 
-def _make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp, *, seed, sharding, device_id,
+def make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp, *, seed, sharding, device_id,
                  engine_factory, lanes_per_chain, stream):
     M0, d = Zmat.shape
     if M0 < 2:
@@ -249,7 +249,7 @@ def _make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp
     return _Runner(engines, sh, K, N, d)
 
 
-def _initial_state(logobj, Zmat, N, Ngeneration, K, prevrun, init):
+def initial_state(logobj, Zmat, N, Ngeneration, K, prevrun, init):
     """demcz.jl:13-22.  Returns (X, logp or None)."""
     M0, d = Zmat.shape
     if prevrun is None:
@@ -345,8 +345,8 @@ def demcz_sample(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
     if len(blockindex) != Nblocks:
         raise ValueError("Nblocks != length(blockindex)")
     autostop = _sym(autostop)
-    X, logp = _initial_state(logobj, Zmat, N, Ngeneration, K, prevrun, init)
-    runner = _make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp, seed=seed,
+    X, logp = initial_state(logobj, Zmat, N, Ngeneration, K, prevrun, init)
+    runner = make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp, seed=seed,
                           sharding=sharding, device_id=device_id, engine_factory=engine_factory,
                           lanes_per_chain=lanes_per_chain, stream=stream)
     Mcap = M0 + int(math.ceil(N * Ngeneration / K))
@@ -406,8 +406,8 @@ def demcz_anneal(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
         blockindex = [range(0, d)]
     if eps_scale is None:
         eps_scale = 1e-4 * np.ones(d)
-    X, logp = _initial_state(logobj, Zmat, N, Ngeneration, K, prevrun, init)
-    runner = _make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp, seed=seed,
+    X, logp = initial_state(logobj, Zmat, N, Ngeneration, K, prevrun, init)
+    runner = make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp, seed=seed,
                           sharding=sharding, device_id=device_id, engine_factory=engine_factory,
                           lanes_per_chain=lanes_per_chain, stream=stream)
     Mcap = M0 + int(math.ceil(N * Ngeneration / K))

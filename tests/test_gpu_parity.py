@@ -39,3 +39,186 @@ def test_mvnormal_full_block_bit_exact(demc, oracle, N, d, G):
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+BLOCKS_D6 = [[0], [1, 2], [5, 3, 4]]
+BLOCKS_D20 = [range(0, 5), range(5, 10), range(10, 15), range(15, 20)]
+
+
+@pytest.mark.parametrize("N,d,G,blocks", [(70, 6, 35, BLOCKS_D6), (256, 20, 23, BLOCKS_D20), (64, 20, 21, None),
+                                          (33, 10, 30, [range(0, 10)]), (40, 5, 30, [[4, 3, 2, 1, 0]]),
+                                          (16, 13, 25, [range(0, 7), range(7, 13)]), (8, 64, 12, None)])
+def test_mvnormal_blocks_and_generic_d_bit_exact(demc, oracle, N, d, G, blocks):
+    """Block updates (C3 layout), permuted single block (not the FULL fast path), runtime-d kernel."""
+    w = demc.workloads.mvnormal_problem(d, N)
+    bl = blocks or [range(d)]
+    mc, Z = demc.demcz_sample(w["target"], w["Zinit"], N, w["K"], G, len(bl), bl, w["eps_scale"], w["gamma"],
+                              verbose=False, seed=5)
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, w["K"], G, [list(b) for b in bl], w["eps_scale"], w["gamma"], 5)
+    assert np.array_equal(mc.chain, ref["chain"]) and np.array_equal(mc.log_obj, ref["log_obj"]) and np.array_equal(Z, ref["Z"])
+
+
+@pytest.mark.parametrize("kind,d,N,G", [("iso", 10, 50, 60), ("iso", 7, 20, 30), ("linreg", 10, 64, 40), ("linreg", 26, 10, 20),
+                                        ("linreg", 4, 10, 20)])
+def test_anneal_targets_bit_exact(demc, oracle, kind, d, N, G):
+    """Tempered accept (demcz_anneal.jl:172-178) on the isotropic quadratic and the regression SSE."""
+    w = demc.workloads.iso_quad_problem(d, N) if kind == "iso" else demc.workloads.linreg_problem(d, N, nobs=120)
+    mc, Z = demc.demcz_anneal(w["target"], w["Zinit"], N, 10, G, 1, [range(d)], w["eps_scale"], w["gamma"], verbose=False,
+                              T0=3, TN=1e-3, seed=17, adaptγ={"adapt": False})
+    temps = np.array([demc.tempbaseline(g, G, 3, 1e-3) for g in range(1, G + 1)])
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, 10, G, None, w["eps_scale"], w["gamma"], 17, temperature=temps)
+    assert np.array_equal(mc.chain, ref["chain"]) and np.array_equal(mc.log_obj, ref["log_obj"]) and np.array_equal(Z, ref["Z"])
+
+
+def test_anneal_gamma_adaptation_matches_host_logic_on_oracle(demc):
+    """Same driver, HIP engine vs the oracle-backed test engine: identical, incl. adapted gamma."""
+    from oracle_engine import OracleEngine
+    d, N, G = 10, 32, 400
+    w = demc.workloads.iso_quad_problem(d, N)
+    args = (w["target"], w["Zinit"], N, 10, G, 1, [range(d)], w["eps_scale"], 2.38)
+    kw = dict(verbose=False, T0=2, TN=1e-4, seed=6, adaptγ={"adapt_every": 100})
+    a, Za = demc.demcz_anneal(*args, **kw)
+    b, Zb = demc.demcz_anneal(*args, engine_factory=OracleEngine, **kw)
+    assert np.array_equal(a.chain, b.chain) and np.array_equal(Za, Zb)
+
+
+def test_device_statistics_vs_oracle(demc, oracle):
+    """R-hat (utils.jl:2-20), per-chain accept ratio (utils.jl:61), mean/cov (utils.jl:96-111) and the
+    per-generation changed counts, computed on the device history."""
+    d, N, G = 5, 200, 301
+    w = demc.workloads.mvnormal_problem(d, N)
+    mc, Z, runner = demc.demcz_sample(w["target"], w["Zinit"], N, 10, G, 1, [range(d)], w["eps_scale"], 2.38, verbose=False,
+                                      seed=2, return_runner=True)
+    e = runner.engines[0]
+    for a, b in [(1, G), (2, 300), (100, 299), (290, 301)]:
+        tol = dict(rtol=1e-9, atol=0)                               # floating-point reductions: order differs
+        assert np.allclose(e.rhat(a, b), oracle.rhat_gelman(mc.chain[:, :, a - 1:b]), **tol)
+        assert np.allclose(e.accept_ratio(a, b), oracle.changed_per_chain(mc.log_obj[:, a - 1:b]) / (b - a), rtol=1e-15)
+        mean, cov = e.mean_cov(a, b)
+        om, oc = oracle.mean_cov_chain(mc.chain[:, :, a - 1:b])
+        assert np.allclose(mean, om, rtol=1e-12) and np.allclose(cov, oc, rtol=1e-9, atol=1e-18)
+    lp0 = oracle.logp(oracle.Problem(N, d, 10, 10, w["eps_scale"], 2, target=w["target"].oracle_spec()), w["Zinit"][-N:])
+    prev = np.concatenate([lp0[:, None], mc.log_obj[:, :-1]], axis=1)
+    assert np.array_equal(e.get_changed(1, G), (mc.log_obj != prev).sum(axis=0))
+    runner.close()
+
+
+def test_split_calls_and_history_origin(demc, oracle):
+    """demcz_run in arbitrary pieces == one call; history origin shifting keeps a sliding window."""
+    d, N, G = 5, 96, 83
+    w = demc.workloads.mvnormal_problem(d, N)
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, 10, G, None, w["eps_scale"], 2.38, 12)
+    M0 = w["Zinit"].shape[0]
+    e = demc.HipEngine(N=N, d=d, K=10, Mcap=M0 + N * 9, Gcap=30, blockindex=[range(d)], eps_scale=w["eps_scale"], seed=12,
+                       target=w["target"])
+    e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+    g = 1
+    for step in (3, 7, 10, 1, 9, 30, 23):
+        if (g - 1) % 30 + step > 30 or (g - 1) % 30 == 0:
+            e.synchronize()
+            e.set_history_origin(g - 1)
+        e.run(g, g + step - 1, 2.38)
+        ch, lo = e.get_history(g, g + step - 1)
+        assert np.array_equal(ch, ref["chain"][:, :, g - 1:g + step - 1])
+        g += step
+    X, lp, Z, M = e.get_state()
+    assert M == ref["M"] and np.array_equal(Z, ref["Z"]) and np.array_equal(X, ref["X"])
+    with pytest.raises(demc.DemczError) as ei:                       # Mcap exhausted: loud, not silent
+        e.run(g, g + 30, 2.38)
+    assert ei.value.code in (3,)
+    e.close()
+
+
+def test_host_closure_mode_equals_device_target(demc, oracle):
+    """Arbitrary Python closure through demcz_propose / demcz_accept_commit (the reference's
+    defining feature, demcz.jl:189): with the closure = the oracle's own log-density the
+    trajectory equals the device-target run bit for bit."""
+    d, N, G = 6, 24, 25
+    w = demc.workloads.mvnormal_problem(d, N)
+    prob = oracle.Problem(1, d, 10, 10, w["eps_scale"], 0, target=w["target"].oracle_spec())
+    closure = lambda x: float(oracle.logp(prob, x[None, :])[0])      # noqa: E731
+    a, Za = demc.demcz_sample(closure, w["Zinit"], N, 10, G, 3, BLOCKS_D6, w["eps_scale"], 2.38, verbose=False, seed=3)
+    b, Zb = demc.demcz_sample(w["target"], w["Zinit"], N, 10, G, 3, BLOCKS_D6, w["eps_scale"], 2.38, verbose=False, seed=3)
+    assert np.array_equal(a.chain, b.chain) and np.array_equal(a.log_obj, b.log_obj) and np.array_equal(Za, Zb)
+
+
+@pytest.mark.parametrize("shards", [2, 4])
+def test_in_process_shards_on_gpu_are_invariant(demc, shards):
+    """S handles on one GPU, host-driven K-boundary exchange: same bits as one handle."""
+    d, N, G = 5, 256, 45
+    w = demc.workloads.mvnormal_problem(d, N)
+    opts = demc.demcopt(d, N=N, K=10, Ngeneration=G, eps_scale=w["eps_scale"], verbose=False, autostop="Rhat",
+                        autostop_every=20, autostop_Rhat=1.0)
+    a, Za, ra = demc.demcz_sample(w["target"], w["Zinit"], opts, seed=8, return_runner=True)
+    sh = demc.Sharding(rank=0, world_size=1, mode="host", local_shards=shards)
+    b, Zb, rb = demc.demcz_sample(w["target"], w["Zinit"], opts, seed=8, sharding=sh, return_runner=True)
+    assert np.array_equal(a.chain, b.chain) and np.array_equal(Za, Zb)
+    assert np.allclose(ra.rhat(1, 40), rb.rhat(1, 40), rtol=1e-12)
+    assert np.array_equal(ra.changed(1, G), rb.changed(1, G))
+    ra.close(); rb.close()
+
+
+def test_rccl_path_single_rank(demc):
+    """demcz_comm_init at nranks=1 (the one-GPU box cannot host two RCCL ranks): communicator
+    set-up works and the run is unchanged."""
+    d, N, G = 5, 128, 25
+    w = demc.workloads.mvnormal_problem(d, N)
+    M0 = w["Zinit"].shape[0]
+    outs = []
+    for use_comm in (False, True):
+        e = demc.HipEngine(N=N, d=d, K=10, Mcap=M0 + N * 3, Gcap=G, blockindex=[range(d)], eps_scale=w["eps_scale"], seed=1,
+                           target=w["target"])
+        if use_comm:
+            e.comm_init(e.comm_unique_id(), 1, 0)
+        e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+        e.run(1, G, 2.38)
+        outs.append((e.get_history(1, G)[0], e.rhat(1, G), e.get_state()[2]))
+        e.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+
+
+def test_argument_validation(demc):
+    """Error behaviour at the boundary: status codes + messages, never a crash."""
+    w = demc.workloads.mvnormal_problem(5, 8)
+    with pytest.raises(ValueError):                                  # demcz.jl:176-179 would throw at M=1
+        demc.demcz_sample(w["target"], w["Zinit"][:1], 1, 10, 5, verbose=False)
+    e = demc.HipEngine(N=8, d=5, K=10, Mcap=100, Gcap=10, blockindex=[range(5)], eps_scale=w["eps_scale"], seed=1, target=w["target"])
+    with pytest.raises(demc.DemczError) as ei:
+        e.run(1, 5, 2.38)                                            # no state yet
+    assert ei.value.code == 4
+    e.set_state(w["Zinit"][-8:], None, w["Zinit"])
+    with pytest.raises(demc.DemczError) as ei:
+        e.run(1, 11, 2.38)                                           # beyond the history window
+    assert ei.value.code == 3
+    with pytest.raises(demc.DemczError):
+        e.rhat(1, 3)                                                 # window too short for split-R-hat
+    e.close()
+    with pytest.raises(demc.DemczError) as ei:
+        demc.HipEngine(N=8, d=5, K=10, Mcap=100, Gcap=10, blockindex=[[0, 0]], eps_scale=w["eps_scale"], seed=1, target=w["target"])
+    assert ei.value.code == 1
+
+
+def test_full_size_c2_properties(demc, oracle):
+    """BASELINE C2 at full size (N=1024, d=5, 10000 generations): the reference's predicates
+    (Rhat, accept band: example_normpdf.jl:49-51) tightened to BASELINE's 1.05, moments of the
+    pooled draws against (mu, Sigma), archive bookkeeping, and run-splitting invariance."""
+    d, N, G = 5, 1024, 10000
+    w = demc.workloads.mvnormal_problem(d, N)
+    opts = demc.demcopt(d, N=N, K=10, Ngeneration=G, eps_scale=w["eps_scale"], verbose=False, autostop="no")
+    mc, Z, runner = demc.demcz_sample(w["target"], w["Zinit"], opts, seed=31953150, return_runner=True)
+    e = runner.engines[0]
+    assert Z.shape[0] == w["Zinit"].shape[0] + N * (G // 10)
+    assert np.array_equal(Z[w["Zinit"].shape[0]:][:N], mc.chain[:, :, 9])      # rows appended after generation 10
+    assert np.array_equal(Z[-N:], mc.chain[:, :, G - 1])
+    rh = e.rhat(G - 999, G)
+    assert np.max(rh) < 1.05, rh
+    acc = e.accept_ratio(G - 2499, G)
+    assert np.all(acc > 0.1) and np.all(acc < 0.45), (acc.min(), acc.max())
+    mean, cov = e.mean_cov(G // 2 + 1, G)
+    sd = np.sqrt(np.diag(w["Sigma"]))
+    assert np.all(np.abs(mean - w["mu"]) < 0.01 * sd), (mean - w["mu"]) / sd
+    assert np.allclose(cov, w["Sigma"], rtol=0.02, atol=0.01 * w["Sigma"].max())
+    # first 300 generations against the oracle, bit for bit (the oracle finishes this in a second)
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, 10, 300, None, w["eps_scale"], 2.38, 31953150)
+    assert np.array_equal(mc.chain[:, :, :300], ref["chain"])
+    runner.close()
