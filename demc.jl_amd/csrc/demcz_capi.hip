@@ -28,6 +28,7 @@ struct demcz_handle {
     std::vector<int32_t> block_offsets, block_indices, slot_of;
     std::vector<double> eps;
     int64_t S = 0;            // Philox blocks per generation
+    int64_t ZS = 0;           // archive row stride in doubles (row-major on the device)
     bool full_block = false;
     // device buffers
     double* dZ = nullptr;
@@ -213,8 +214,9 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
     h->cfg.mu = nullptr; h->cfg.W = nullptr; h->cfg.design = nullptr; h->cfg.yobs = nullptr; h->cfg.stream = nullptr;
 
     const int64_t N = cfg->N;
-    CRCHK(hipMalloc((void**)&h->dZ, (size_t)cfg->Mcap * d * sizeof(double)));
-    CRCHK(hipMemsetAsync(h->dZ, 0, (size_t)cfg->Mcap * d * sizeof(double), h->stream));   // zeros(...) demcz.jl:11
+    h->ZS = (d <= 1) ? 2 : (d <= 2) ? 2 : (d <= 4) ? 4 : ((d + 7) / 8) * 8;     // 16-byte aligned rows; d=5 -> one 64-byte line
+    CRCHK(hipMalloc((void**)&h->dZ, (size_t)cfg->Mcap * h->ZS * sizeof(double)));
+    CRCHK(hipMemsetAsync(h->dZ, 0, (size_t)cfg->Mcap * h->ZS * sizeof(double), h->stream));   // zeros(...) demcz.jl:11
     CRCHK(hipMalloc((void**)&h->dX, (size_t)N * d * sizeof(double)));
     CRCHK(hipMalloc((void**)&h->dlp, (size_t)N * sizeof(double)));
     if (cfg->Gcap > 0) {
@@ -318,8 +320,16 @@ extern "C" int32_t demcz_set_state(demcz_handle* h, const double* X, const doubl
     const int d = h->cfg.d;
     const int64_t N = h->cfg.N;
     HIPCHK(h, hipMemcpyAsync(h->dX, X, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpy2DAsync(h->dZ, (size_t)h->cfg.Mcap * sizeof(double), Z, (size_t)ldZ * sizeof(double),
-                               (size_t)M0 * sizeof(double), (size_t)d, hipMemcpyHostToDevice, h->stream));
+    {   // parameter-major host matrix -> staging -> row-major archive
+        int32_t rcz = ensure_scratch(h, M0 * d);
+        if (rcz) return rcz;
+        HIPCHK(h, hipMemcpy2DAsync(h->d_scratch, (size_t)M0 * sizeof(double), Z, (size_t)ldZ * sizeof(double),
+                                   (size_t)M0 * sizeof(double), (size_t)d, hipMemcpyHostToDevice, h->stream));
+        const int64_t tot = M0 * d;
+        hipLaunchKernelGGL(append_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->dZ, h->ZS,
+                           (int64_t)0, (const double*)h->d_scratch, M0, M0, d);
+        HIPCHK(h, hipGetLastError());
+    }
     if (logp) {
         HIPCHK(h, hipMemcpyAsync(h->dlp, logp, (size_t)N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     } else {
@@ -345,7 +355,13 @@ extern "C" int32_t demcz_get_state(demcz_handle* h, double* X, double* logp, dou
     if (logp) HIPCHK(h, hipMemcpyAsync(logp, h->dlp, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (Z) {
         if (ldZ < h->M) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_get_state: ldZ < M");
-        HIPCHK(h, hipMemcpy2DAsync(Z, (size_t)ldZ * sizeof(double), h->dZ, (size_t)h->cfg.Mcap * sizeof(double),
+        int32_t rcz = ensure_scratch(h, h->M * d);
+        if (rcz) return rcz;
+        const int64_t tot = h->M * d;
+        hipLaunchKernelGGL(export_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->dZ,
+                           h->ZS, (int64_t)0, h->d_scratch, h->M, h->M, d);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpy2DAsync(Z, (size_t)ldZ * sizeof(double), h->d_scratch, (size_t)h->M * sizeof(double),
                                    (size_t)h->M * sizeof(double), (size_t)d, hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -429,7 +445,7 @@ static int32_t append_after_window(demcz_handle* h)
         NCCLCHK(h, ncclAllGather(h->dX, h->d_gather, (size_t)N * d, ncclDouble, h->comm, h->stream));
         const int64_t tot = total * d;
         hipLaunchKernelGGL(append_gathered_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->dZ,
-                           h->cfg.Mcap, h->M, h->d_gather, N, h->nranks, d);
+                           h->ZS, h->M, h->d_gather, N, h->nranks, d);
         HIPCHK(h, hipGetLastError());
         h->M += total;
     }
@@ -475,7 +491,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         HIPCHK(h, hipStreamSynchronize(h->stream));   // the caller may reuse its buffer on return
     }
     WindowParams P;
-    P.Z = h->dZ; P.Zw = h->dZ; P.Mcap = h->cfg.Mcap;
+    P.Z = h->dZ; P.Zw = h->dZ; P.ZS = h->ZS;
     P.Xcur = h->dX; P.lpcur = h->dlp;
     P.chain = hist ? h->dchain : nullptr; P.logobj = hist ? h->dlogobj : nullptr;
     P.changed = h->dchanged;
@@ -708,11 +724,13 @@ __global__ void propose_kernel(const WindowParams P, int ib, uint64_t blk0, doub
     }
     const double scale = (b == 1) ? P.gamma : P.gamma / sqrt((double)(2 * b));
     const int32_t* so = P.slot_of + ib * d;
+    const double* za = P.Z + (int64_t)i1 * P.ZS;
+    const double* zb = P.Z + (int64_t)i2 * P.ZS;
     for (int p = 0; p < d; ++p) {
         const int t = so[p];
         double xv = P.Xcur[c + P.N * p];
         if (t >= 0) {
-            double diff = P.Z[(int64_t)i1 + P.Mcap * p] - P.Z[(int64_t)i2 + P.Mcap * p];
+            double diff = za[p] - zb[p];
             double zt = lds[((b == 1) ? 0 : t) * WINDOW_BS + tid];
             double t1 = scale * diff;
             double t2 = P.eps[p] * zt;
@@ -741,7 +759,7 @@ __global__ void accept_commit_kernel(int64_t N, int d, double* Xcur, double* lpc
 
 __global__ void end_generation_kernel(int64_t N, int d, const double* Xcur, const double* lpcur, const double* lp_before,
                                       double* chain, double* logobj, unsigned int* changed, int64_t slot,
-                                      double* Z, int64_t Mcap, int64_t M, int do_append)
+                                      double* Z, int64_t ZS, int64_t M, int do_append)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool ch = false;
@@ -750,7 +768,7 @@ __global__ void end_generation_kernel(int64_t N, int d, const double* Xcur, cons
         for (int p = 0; p < d; ++p) {
             const double xv = Xcur[c + N * p];
             if (chain) chain[c + N * (p + (int64_t)d * slot)] = xv;
-            if (do_append) Z[M + c + Mcap * p] = xv;
+            if (do_append) Z[(M + c) * ZS + p] = xv;
         }
         if (logobj) logobj[c + N * slot] = lp;
         ch = lp != lp_before[c];
@@ -778,7 +796,7 @@ extern "C" int32_t demcz_propose(demcz_handle* h, int64_t g, int32_t ib, double 
     int64_t off = 0;
     for (int t = 0; t < ib; ++t) off += blockstep_nblk(h->block_offsets[t + 1] - h->block_offsets[t]);
     WindowParams P{};
-    P.Z = h->dZ; P.Mcap = h->cfg.Mcap; P.M = h->M; P.Xcur = h->dX; P.N = N; P.chain_id0 = h->cfg.chain_id0; P.d = d;
+    P.Z = h->dZ; P.ZS = h->ZS; P.M = h->M; P.Xcur = h->dX; P.N = N; P.chain_id0 = h->cfg.chain_id0; P.d = d;
     P.gamma = gamma; P.seed = h->cfg.seed; P.block_offsets = h->d_block_offsets; P.slot_of = h->d_slot_of; P.eps = h->d_eps;
     const uint64_t blk0 = (uint64_t)(g - 1) * (uint64_t)h->S + (uint64_t)off;
     hipLaunchKernelGGL(propose_kernel, dim3((unsigned)((N + WINDOW_BS - 1) / WINDOW_BS)), dim3(WINDOW_BS),
@@ -822,7 +840,7 @@ extern "C" int32_t demcz_end_generation(demcz_handle* h, int64_t g)
     if (kappend && h->M + N > h->cfg.Mcap) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_end_generation: Z capacity exceeded");
     hipLaunchKernelGGL(end_generation_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, h->stream, N, h->cfg.d, h->dX, h->dlp,
                        h->dlp_before, hist ? h->dchain : nullptr, hist ? h->dlogobj : nullptr, h->dchanged,
-                       hist ? (g - h->g0 - 1) : 0, h->dZ, h->cfg.Mcap, h->M, kappend ? 1 : 0);
+                       hist ? (g - h->g0 - 1) : 0, h->dZ, h->ZS, h->M, kappend ? 1 : 0);
     HIPCHK(h, hipGetLastError());
     if (kappend) h->M += N;
     else if (boundary && sharded) { int32_t rc = append_after_window(h); if (rc) return rc; }
@@ -874,7 +892,7 @@ extern "C" int32_t demcz_append_rows_device(demcz_handle* h, const double* rows_
     if (h->M + nrows > h->cfg.Mcap) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_append_rows_device: Z capacity exceeded");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     const int64_t tot = nrows * h->cfg.d;
-    hipLaunchKernelGGL(append_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->dZ, h->cfg.Mcap, h->M,
+    hipLaunchKernelGGL(append_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->dZ, h->ZS, h->M,
                        rows_device, nrows, ldrows, h->cfg.d);
     HIPCHK(h, hipGetLastError());
     h->M += nrows;
@@ -887,8 +905,14 @@ extern "C" int32_t demcz_append_rows(demcz_handle* h, const double* rows, int64_
     if (!h->has_state) return fail(h, DEMCZ_ERR_STATE, "demcz_append_rows: no state");
     if (h->M + nrows > h->cfg.Mcap) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_append_rows: Z capacity exceeded");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
-    HIPCHK(h, hipMemcpy2DAsync(h->dZ + h->M, (size_t)h->cfg.Mcap * sizeof(double), rows, (size_t)ldrows * sizeof(double),
+    int32_t rcz = ensure_scratch(h, nrows * h->cfg.d);
+    if (rcz) return rcz;
+    HIPCHK(h, hipMemcpy2DAsync(h->d_scratch, (size_t)nrows * sizeof(double), rows, (size_t)ldrows * sizeof(double),
                                (size_t)nrows * sizeof(double), (size_t)h->cfg.d, hipMemcpyHostToDevice, h->stream));
+    const int64_t tot = nrows * h->cfg.d;
+    hipLaunchKernelGGL(append_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->dZ, h->ZS, h->M,
+                       (const double*)h->d_scratch, nrows, nrows, h->cfg.d);
+    HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));   // the caller may reuse `rows` on return
     h->M += nrows;
     return DEMCZ_OK;

@@ -32,10 +32,13 @@ struct TargetParams {
 };
 
 struct WindowParams {
-    // archive
-    const double* Z;         // Mcap x d, parameter-major (column-major, ld Mcap)
+    // archive: row-major on the device, row r at Z + r*ZS (ZS = padded row stride in doubles,
+    // a multiple of 2 so rows are 16-byte aligned; d=5 -> 8 = one 64-byte line per row).  The
+    // boundary keeps Julia's parameter-major layout; set_state/get_state transpose.  A random row
+    // then costs one or two cache lines instead of d of them (measured: profiles/r01_*pmc*).
+    const double* Z;
     double* Zw;              // same buffer, for the append
-    int64_t Mcap;
+    int64_t ZS;
     int64_t M;               // rows visible to every proposal of this window
     // chain state
     double* Xcur;            // N x d (ld N)
@@ -61,6 +64,29 @@ struct WindowParams {
     const double* eps;
     TargetParams tp;
 };
+
+// One archive row (16-byte aligned) <-> registers, as 16-byte accesses.
+template <int D>
+__device__ __forceinline__ void load_row(const double* __restrict__ row, double (&v)[D])
+{
+    const double2* r2 = reinterpret_cast<const double2*>(row);
+#pragma unroll
+    for (int k = 0; k < D / 2; ++k) {
+        double2 t = r2[k];
+        v[2 * k] = t.x;
+        v[2 * k + 1] = t.y;
+    }
+    if constexpr (D & 1) v[D - 1] = row[D - 1];
+}
+
+template <int D>
+__device__ __forceinline__ void store_row(double* __restrict__ row, const double (&v)[D])
+{
+    double2* r2 = reinterpret_cast<double2*>(row);
+#pragma unroll
+    for (int k = 0; k < D / 2; ++k) r2[k] = make_double2(v[2 * k], v[2 * k + 1]);
+    if constexpr (D & 1) row[D - 1] = v[D - 1];
+}
 
 // ------------------------------------------------------------------------------------------------
 // Targets.  `X` is a callable j -> x_j; with a compile-time D every loop unrolls and x stays in
@@ -142,9 +168,12 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel(const WindowParams P)
                     normal_pair(r1, r2, zn[2 * pr], zn[2 * pr + 1]);
                 }
                 const double scale = (D == 1) ? P.gamma : P.gamma / sqrt((double)(2 * D));
+                double za[D], zb[D];
+                load_row<D>(P.Z + (int64_t)i1 * P.ZS, za);
+                load_row<D>(P.Z + (int64_t)i2 * P.ZS, zb);
 #pragma unroll
                 for (int p = 0; p < D; ++p) {
-                    double diff = P.Z[(int64_t)i1 + P.Mcap * p] - P.Z[(int64_t)i2 + P.Mcap * p];
+                    double diff = za[p] - zb[p];
                     double t1 = scale * diff;
                     double t2 = P.eps[p] * zn[(D == 1) ? 0 : p];
                     double delta = t1 + t2;
@@ -163,11 +192,13 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel(const WindowParams P)
                 }
                 const double scale = (b == 1) ? P.gamma : P.gamma / sqrt((double)(2 * b));
                 const int32_t* so = P.slot_of + ib * D;
+                const double* za = P.Z + (int64_t)i1 * P.ZS;
+                const double* zb = P.Z + (int64_t)i2 * P.ZS;
 #pragma unroll
                 for (int p = 0; p < D; ++p) {
                     const int t = so[p];
                     if (t >= 0) {
-                        double diff = P.Z[(int64_t)i1 + P.Mcap * p] - P.Z[(int64_t)i2 + P.Mcap * p];
+                        double diff = za[p] - zb[p];
                         double zt = zlds[((b == 1) ? 0 : t) * WINDOW_BS + tid];
                         double t1 = scale * diff;
                         double t2 = P.eps[p] * zt;
@@ -201,10 +232,7 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel(const WindowParams P)
 #pragma unroll
     for (int p = 0; p < D; ++p) P.Xcur[c + P.N * p] = x[p];
     P.lpcur[c] = lp;
-    if (P.do_append) {
-#pragma unroll
-        for (int p = 0; p < D; ++p) P.Zw[P.M + c + P.Mcap * p] = x[p];
-    }
+    if (P.do_append) store_row<D>(P.Zw + (P.M + c) * P.ZS, x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -246,11 +274,13 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel_generic(const WindowP
             }
             const double scale = (b == 1) ? P.gamma : P.gamma / sqrt((double)(2 * b));
             const int32_t* so = P.slot_of + ib * d;
+            const double* za = P.Z + (int64_t)i1 * P.ZS;
+            const double* zb = P.Z + (int64_t)i2 * P.ZS;
             for (int p = 0; p < d; ++p) {
                 const int t = so[p];
                 double xv = xs[p * WINDOW_BS + tid];
                 if (t >= 0) {
-                    double diff = P.Z[(int64_t)i1 + P.Mcap * p] - P.Z[(int64_t)i2 + P.Mcap * p];
+                    double diff = za[p] - zb[p];
                     double zt = zs[((b == 1) ? 0 : t) * WINDOW_BS + tid];
                     double t1 = scale * diff;
                     double t2 = P.eps[p] * zt;
@@ -281,7 +311,7 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel_generic(const WindowP
     for (int p = 0; p < d; ++p) {
         double xv = xs[p * WINDOW_BS + tid];
         P.Xcur[c + P.N * p] = xv;
-        if (P.do_append) P.Zw[P.M + c + P.Mcap * p] = xv;
+        if (P.do_append) P.Zw[(P.M + c) * P.ZS + p] = xv;
     }
     P.lpcur[c] = lp;
 }
@@ -295,26 +325,35 @@ __global__ void logp_kernel(TargetParams tp, int d, const double* X, int64_t ldX
     out[c] = target_logp<TARGET, 0>(tp, d, [&](int j) { return X[c + ldX * j]; });
 }
 
-// K4: rows (nrows x d, ld ldrows) -> Z[M .. M+nrows) (ld Mcap)
-__global__ void append_rows_kernel(double* Z, int64_t Mcap, int64_t M, const double* rows, int64_t nrows,
+// K4: rows (nrows x d column-major, ld ldrows) -> archive rows M .. M+nrows (row-major, stride ZS)
+__global__ void append_rows_kernel(double* Z, int64_t ZS, int64_t M, const double* rows, int64_t nrows,
                                    int64_t ldrows, int d)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nrows * d) return;
     const int64_t r = i % nrows, p = i / nrows;
-    Z[M + r + Mcap * p] = rows[r + ldrows * p];
+    Z[(M + r) * ZS + p] = rows[r + ldrows * p];
+}
+
+// archive rows r0 .. r0+nrows (row-major) -> out (nrows x d column-major, ld ldout)
+__global__ void export_rows_kernel(const double* Z, int64_t ZS, int64_t r0, double* out, int64_t nrows, int64_t ldout, int d)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * d) return;
+    const int64_t r = i % nrows, p = i / nrows;
+    out[r + ldout * p] = Z[(r0 + r) * ZS + p];
 }
 
 // Staging slab of an all-gather over R shards, each shard an n_loc x d column-major matrix
-// stored contiguously ([R][d][n_loc]) -> rows M + r*n_loc + j of Z.
-__global__ void append_gathered_kernel(double* Z, int64_t Mcap, int64_t M, const double* slab, int64_t n_loc,
+// stored contiguously ([R][d][n_loc]) -> archive rows M + r*n_loc + j.
+__global__ void append_gathered_kernel(double* Z, int64_t ZS, int64_t M, const double* slab, int64_t n_loc,
                                        int R, int d)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t per = n_loc * d;
     if (i >= per * R) return;
     const int64_t r = i / per, rem = i % per, p = rem / n_loc, j = rem % n_loc;
-    Z[M + r * n_loc + j + Mcap * p] = slab[i];
+    Z[(M + r * n_loc + j) * ZS + p] = slab[i];
 }
 
 // ------------------------------------------------------------------------------------------------
