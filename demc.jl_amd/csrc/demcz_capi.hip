@@ -4,6 +4,7 @@
 // DEMCZ_ERR_NO_DEVICE.
 #include "../../include/demcz.h"
 #include "demcz_kernels.h"
+#include "demcz_kernels_ml.h"
 
 #include <rccl/rccl.h>
 
@@ -100,6 +101,8 @@ static int64_t blockstep_nblk(int b)
     return 1 + (nn + 1) / 2 + 1;
 }
 
+static int ml_lanes_available(int target_kind, int d, bool full_block);
+
 extern "C" int32_t demcz_abi_version(void) { return DEMCZ_ABI_VERSION; }
 
 extern "C" const char* demcz_last_error(const demcz_handle* h)
@@ -136,8 +139,8 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         cfg->Nblocks < 1 || !cfg->block_offsets || !cfg->block_indices || !cfg->eps_scale || cfg->chain_id0 < 0)
         return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT,
                     "demcz_create: need N>=1, 1<=d<=64, K>=1, Mcap>=2, Gcap>=0, Nblocks>=1 and block/eps tables");
-    if (cfg->lanes_per_chain != 0 && cfg->lanes_per_chain != 1)
-        return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_create: lanes_per_chain must be 0 or 1 in this build");
+    if (cfg->lanes_per_chain != 0 && cfg->lanes_per_chain != 1 && cfg->lanes_per_chain != 8 && cfg->lanes_per_chain != 16)
+        return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_create: lanes_per_chain must be 0 (auto), 1, 8 or 16");
     const int d = cfg->d;
     // validate blocks: offsets ascending, indices within range and unique inside a block
     if (cfg->block_offsets[0] != 0) return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT, "block_offsets[0] must be 0");
@@ -209,6 +212,18 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
     h->full_block = (cfg->Nblocks == 1 && h->block_offsets[1] == d);
     if (h->full_block)
         for (int p = 0; p < d; ++p) h->full_block = h->full_block && (h->block_indices[p] == p);
+    {   // layout: L lanes per chain when the chip would otherwise sit idle (small N), else one lane
+        const int L = ml_lanes_available(cfg->target_kind, d, h->full_block);
+        if (cfg->lanes_per_chain > 1) {
+            if (L != cfg->lanes_per_chain) {
+                h->err = "demcz_create: the requested lanes_per_chain layout is not built for this target / d / block structure";
+                return bail(DEMCZ_ERR_INVALID_ARGUMENT);
+            }
+            h->lanes = L;
+        } else if (cfg->lanes_per_chain == 0 && L > 1 && cfg->N * L <= 65536) {
+            h->lanes = L;       // N*L/64 waves <= 1024 SIMDs
+        }
+    }
     // no pointer of the caller's survives create
     h->cfg.block_offsets = nullptr; h->cfg.block_indices = nullptr; h->cfg.eps_scale = nullptr;
     h->cfg.mu = nullptr; h->cfg.W = nullptr; h->cfg.design = nullptr; h->cfg.yobs = nullptr; h->cfg.stream = nullptr;
@@ -397,10 +412,55 @@ static void launch_window_generic(const demcz_handle* h, const WindowParams& P, 
     hipLaunchKernelGGL(window_kernel_generic<TARGET>, grid, dim3(WINDOW_BS), lds, h->stream, P);
 }
 
+template <int TARGET, int D, int L>
+static void launch_window_ml(const demcz_handle* h, const WindowParams& P)
+{
+    constexpr int G = 64 / L;
+    hipLaunchKernelGGL((window_kernel_ml<TARGET, D, L>), dim3((unsigned)((P.N + G - 1) / G)), dim3(64), 0, h->stream, P);
+}
+
+// which multi-lane layout is compiled for (target, d, full single block): 0 = none
+static int ml_lanes_available(int target_kind, int d, bool full_block)
+{
+    if (!full_block) return 0;
+    if (target_kind == DEMCZ_TARGET_MVNORMAL) {
+        if (d == 2 || d == 3 || d == 4 || d == 5 || d == 8 || d == 10) return 8;
+        if (d == 20) return 16;
+    }
+    if (target_kind == DEMCZ_TARGET_ISO_QUAD && d == 10) return 8;
+    return 0;
+}
+
+static bool try_launch_ml(const demcz_handle* h, const WindowParams& P)
+{
+    if (h->lanes <= 1) return false;
+    const int d = P.d;
+    if (h->cfg.target_kind == DEMCZ_TARGET_MVNORMAL) {
+        switch (d) {
+        case 2: launch_window_ml<TARGET_MVNORMAL, 2, 8>(h, P); return true;
+        case 3: launch_window_ml<TARGET_MVNORMAL, 3, 8>(h, P); return true;
+        case 4: launch_window_ml<TARGET_MVNORMAL, 4, 8>(h, P); return true;
+        case 5: launch_window_ml<TARGET_MVNORMAL, 5, 8>(h, P); return true;
+        case 8: launch_window_ml<TARGET_MVNORMAL, 8, 8>(h, P); return true;
+        case 10: launch_window_ml<TARGET_MVNORMAL, 10, 8>(h, P); return true;
+        case 20: launch_window_ml<TARGET_MVNORMAL, 20, 16>(h, P); return true;
+        }
+    } else if (h->cfg.target_kind == DEMCZ_TARGET_ISO_QUAD && d == 10) {
+        launch_window_ml<TARGET_ISO_QUAD, 10, 8>(h, P);
+        return true;
+    }
+    return false;
+}
+
 static int32_t launch_window(demcz_handle* h, const WindowParams& P)
 {
     const dim3 grid((unsigned)((P.N + WINDOW_BS - 1) / WINDOW_BS));
     const int d = P.d;
+    if (try_launch_ml(h, P)) {
+        HIPCHK(h, hipGetLastError());
+        ++h->launches;
+        return DEMCZ_OK;
+    }
     switch (h->cfg.target_kind) {
     case DEMCZ_TARGET_MVNORMAL:
         switch (d) {

@@ -1,0 +1,200 @@
+// demcz_kernels_ml.h -- K1 in the "latency layout": L lanes cooperate on one chain.
+//
+// The BASELINE metric is quoted at N = 1024 chains: with one lane per chain that is 16 wavefronts
+// on a chip with 1024 SIMDs, and a chain-update is a ~1100-instruction serial stream per wave.
+// Here a chain is spread over L = 8 (or 16) lanes, so the same N fills 8x (16x) as many SIMDs and
+// the per-wave stream shrinks to ~300 instructions:
+//   * lane r of a group generates Philox block r of the generation (role 0: the two archive row
+//     indices, roles 1..NPAIRS: one Box-Muller pair each, role S-1: the accept uniform), so the 5
+//     blocks of a d=5 update are produced side by side instead of one after another;
+//   * the draws are staged through LDS (one 16-byte entry per role) and read back by the lanes
+//     that need them (broadcast reads inside the group);
+//   * lane p owns parameter p: it gathers Z[i1][p], Z[i2][p] (adjacent lanes hit adjacent words of
+//     the same 64-byte row), forms its component of the proposal, and row p of the whitened
+//     residual y = W (x' - mu); the components travel through LDS and every lane of the group
+//     accumulates q = sum y_i^2 in the spec's order, so all lanes reach the same accept decision.
+// Arithmetic is the same operation sequence as the one-lane kernel and the oracle: results are
+// bit-identical (tests/test_gpu_parity.py runs both layouts against the oracle).
+// Restates the same reference functions as window_kernel (src/demcz.jl:80-93,167-203).
+#pragma once
+
+#include "demcz_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace demcz {
+
+// rocRAND's Philox4x32-10 round function used as a pure counter -> block map:
+// block(seed, chain, blk) == rocrand_init(seed, chain, 4*blk) followed by rocrand4().
+struct philox_blocks : rocrand_device::philox4x32_10_engine {
+    __device__ __forceinline__ philox_blocks() {}
+    __device__ __forceinline__ void block(uint64_t seed, uint64_t chain, uint64_t blk, uint64_t& r1, uint64_t& r2)
+    {
+        uint4 ctr = {(unsigned)blk, (unsigned)(blk >> 32), (unsigned)chain, (unsigned)(chain >> 32)};
+        uint2 key = {(unsigned)seed, (unsigned)(seed >> 32)};
+        uint4 w = this->ten_rounds(ctr, key);
+        r1 = (uint64_t)w.x | ((uint64_t)w.y << 32);
+        r2 = (uint64_t)w.z | ((uint64_t)w.w << 32);
+    }
+};
+
+// LDS hand-offs between lanes of ONE wave: the hardware keeps a wave's LDS operations in order, so
+// all that is needed is to stop the compiler from moving memory operations across the hand-off.
+__device__ __forceinline__ void wave_lds_handoff()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int TARGET, int D, int L>
+__global__ void __launch_bounds__(64) window_kernel_ml(const WindowParams P)
+{
+    static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "latency layout: MvNormal / isotropic targets");
+    constexpr int G = 64 / L;                              // chains per wave
+    constexpr int NPAIRS = (D == 1) ? 1 : (D + 1) / 2;
+    constexpr int S = NPAIRS + 2;                          // Philox blocks per generation (full block)
+    static_assert(S <= L, "one Philox block per lane");
+    constexpr int NP = (D + L - 1) / L;                    // parameters owned per lane
+    constexpr int DP = ((D + 1) / 2) * 2;                  // staging row, 16-byte multiple
+    __shared__ double2 rec[G * S];
+    __shared__ __attribute__((aligned(16))) double rvec[G * DP];
+    __shared__ __attribute__((aligned(16))) double yvec[G * DP];
+
+    const int lane = threadIdx.x;
+    const int r = lane % L, gq = lane / L;
+    const int64_t c = (int64_t)blockIdx.x * G + gq;
+    if (c >= P.N) return;
+    const uint64_t chain = (uint64_t)(P.chain_id0 + c);
+    const int role = (r < S) ? r : S - 1;
+
+    // per-lane constants: owned parameters, their eps / mu and rows of W
+    double x[NP], epsv[NP], muv[NP], Wrow[NP][D];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int p = r + L * k;
+        const bool own = p < D;
+        const int pc = own ? p : 0;
+        x[k] = own ? P.Xcur[c + P.N * pc] : 0.0;
+        epsv[k] = P.eps[pc];
+        muv[k] = P.tp.mu[pc];
+        if constexpr (TARGET == TARGET_MVNORMAL) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) Wrow[k][j] = (own && j <= pc) ? P.tp.Wp[(pc * (pc + 1)) / 2 + j] : 0.0;
+        }
+    }
+    double lp = P.lpcur[c];
+    const double scale = (D == 1) ? P.gamma : P.gamma / sqrt((double)(2 * D));
+    philox_blocks rng;
+
+    for (int gi = 0; gi < P.ngen; ++gi) {
+        // ---- draws (independent of the chain state) ------------------------------------------
+        uint64_t r1, r2, i1, i2;
+        rng.block(P.seed, chain, (uint64_t)(P.g_first + gi - 1) * (uint64_t)S + (uint64_t)role, r1, r2);
+        const double lg = dm_log(u_open(r1));
+        double z0, z1;
+        {
+            const double R = sqrt(-2.0 * lg);
+            double cs, sn;
+            dm_sincos2pi(r2 >> 11, cs, sn);
+            z0 = R * cs;
+            z1 = R * sn;
+        }
+        draw_rows(r1, r2, (uint64_t)P.M, i1, i2);
+        double2 e;
+        e.x = (r == 0) ? __longlong_as_double((long long)i1) : ((r == S - 1) ? lg : z0);
+        e.y = (r == 0) ? __longlong_as_double((long long)i2) : z1;
+        if (r < S) rec[gq * S + r] = e;
+        wave_lds_handoff();
+        const double2 ii = rec[gq * S];
+        const double logu = rec[gq * S + S - 1].x;
+        const int64_t row1 = __double_as_longlong(ii.x), row2 = __double_as_longlong(ii.y);
+        double delta[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int p = r + L * k;
+            const bool own = p < D;
+            const int pc = own ? p : 0;
+            const int zi = (D == 1) ? 0 : pc;
+            const double zt = reinterpret_cast<const double*>(rec)[(gq * S + 1 + zi / 2) * 2 + (zi & 1)];
+            const double diff = P.Z[row1 * P.ZS + pc] - P.Z[row2 * P.ZS + pc];
+            const double t1 = scale * diff;
+            const double t2 = epsv[k] * zt;
+            delta[k] = t1 + t2;
+        }
+        wave_lds_handoff();      // rec is rewritten by the next generation's draws
+
+        // ---- state-dependent part --------------------------------------------------------------
+        double xp[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int p = r + L * k;
+            xp[k] = x[k] + delta[k];
+            if (p < D) rvec[gq * DP + p] = xp[k] - muv[k];
+        }
+        wave_lds_handoff();
+        double rj[DP];
+#pragma unroll
+        for (int j = 0; j < DP / 2; ++j) {
+            const double2 t = reinterpret_cast<const double2*>(rvec + gq * DP)[j];
+            rj[2 * j] = t.x;
+            rj[2 * j + 1] = t.y;
+        }
+        double lpp;
+        if constexpr (TARGET == TARGET_MVNORMAL) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int p = r + L * k;
+                double acc = Wrow[k][0] * rj[0];
+#pragma unroll
+                for (int j = 1; j < D; ++j) {
+                    const double t = fma(Wrow[k][j], rj[j], acc);
+                    acc = (j <= p) ? t : acc;
+                }
+                if (p < D) yvec[gq * DP + p] = acc;
+            }
+            wave_lds_handoff();
+            double q = 0.0;
+#pragma unroll
+            for (int j = 0; j < DP / 2; ++j) {
+                const double2 t = reinterpret_cast<const double2*>(yvec + gq * DP)[j];
+                q = (j == 0) ? t.x * t.x : fma(t.x, t.x, q);
+                if (2 * j + 1 < D) q = fma(t.y, t.y, q);
+            }
+            lpp = fma(-0.5, q, P.tp.c0);
+        } else {
+            double q = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) q = (j == 0) ? rj[0] * rj[0] : fma(rj[j], rj[j], q);
+            lpp = -q;
+        }
+        double dlt = lpp - lp;
+        if (P.temperature) dlt = dlt / P.temperature[gi];
+        const bool acc = logu < dlt;
+        const double lp_before = lp;
+        lp = acc ? lpp : lp;
+        const int64_t slot = P.slot_first + gi;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int p = r + L * k;
+            x[k] = acc ? xp[k] : x[k];
+            if (P.chain && p < D) P.chain[c + P.N * (p + (int64_t)D * slot)] = x[k];
+        }
+        if (P.chain && r == 0) P.logobj[c + P.N * slot] = lp;
+        const unsigned long long m = __ballot(r == 0 && lp != lp_before);
+        if (m != 0ull && (unsigned)lane == (unsigned)__ffsll((long long)m) - 1u)
+            atomicAdd(&P.changed[slot], (unsigned int)__popcll(m));
+        wave_lds_handoff();      // rvec / yvec are rewritten by the next generation
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int p = r + L * k;
+        if (p < D) {
+            P.Xcur[c + P.N * p] = x[k];
+            if (P.do_append) P.Zw[(P.M + c) * P.ZS + p] = x[k];
+        }
+    }
+    if (r == 0) P.lpcur[c] = lp;
+}
+
+}  // namespace demcz

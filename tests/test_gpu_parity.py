@@ -22,12 +22,19 @@ def test_selftest_draws_bit_exact(demc, oracle):
     assert abs(normals.mean()) < 0.02 and abs(normals.std() - 1.0) < 0.02
 
 
-@pytest.mark.parametrize("N,d,G", [(4, 5, 200), (100, 5, 57), (1024, 5, 40), (64, 3, 30), (65, 8, 25), (32, 7, 25)])
-def test_mvnormal_full_block_bit_exact(demc, oracle, N, d, G):
+@pytest.mark.parametrize("lanes", [1, 0])
+@pytest.mark.parametrize("N,d,G", [(4, 5, 200), (100, 5, 57), (1024, 5, 40), (64, 3, 30), (65, 8, 25), (32, 7, 25),
+                                   (13, 2, 31), (77, 4, 33), (50, 10, 27), (41, 20, 23)])
+def test_mvnormal_full_block_bit_exact(demc, oracle, N, d, G, lanes):
+    """Both layouts: one lane per chain (lanes=1) and the library's choice (lanes=0: eight / sixteen
+    lanes per chain for the dimensions it is built for)."""
     w = demc.workloads.mvnormal_problem(d, N)
     seed = 99 + N
-    mc, Z = demc.demcz_sample(w["target"], w["Zinit"], N, w["K"], G, 1, [range(d)], w["eps_scale"], w["gamma"],
-                              verbose=False, seed=seed)
+    mc, Z, runner = demc.demcz_sample(w["target"], w["Zinit"], N, w["K"], G, 1, [range(d)], w["eps_scale"], w["gamma"],
+                                      verbose=False, seed=seed, lanes_per_chain=lanes, return_runner=True)
+    used = runner.engines[0].info()["lanes_per_chain"]
+    runner.close()
+    assert used == (1 if lanes == 1 or d == 7 else (16 if d == 20 else 8))
     ref = oracle_sample(oracle, w["target"], w["Zinit"], N, w["K"], G, None, w["eps_scale"], w["gamma"], seed)
     assert np.array_equal(mc.chain, ref["chain"])
     assert np.array_equal(mc.log_obj, ref["log_obj"])
@@ -58,13 +65,14 @@ def test_mvnormal_blocks_and_generic_d_bit_exact(demc, oracle, N, d, G, blocks):
     assert np.array_equal(mc.chain, ref["chain"]) and np.array_equal(mc.log_obj, ref["log_obj"]) and np.array_equal(Z, ref["Z"])
 
 
+@pytest.mark.parametrize("lanes", [1, 0])
 @pytest.mark.parametrize("kind,d,N,G", [("iso", 10, 50, 60), ("iso", 7, 20, 30), ("linreg", 10, 64, 40), ("linreg", 26, 10, 20),
                                         ("linreg", 4, 10, 20)])
-def test_anneal_targets_bit_exact(demc, oracle, kind, d, N, G):
+def test_anneal_targets_bit_exact(demc, oracle, kind, d, N, G, lanes):
     """Tempered accept (demcz_anneal.jl:172-178) on the isotropic quadratic and the regression SSE."""
     w = demc.workloads.iso_quad_problem(d, N) if kind == "iso" else demc.workloads.linreg_problem(d, N, nobs=120)
     mc, Z = demc.demcz_anneal(w["target"], w["Zinit"], N, 10, G, 1, [range(d)], w["eps_scale"], w["gamma"], verbose=False,
-                              T0=3, TN=1e-3, seed=17, adaptγ={"adapt": False})
+                              T0=3, TN=1e-3, seed=17, adaptγ={"adapt": False}, lanes_per_chain=lanes)
     temps = np.array([demc.tempbaseline(g, G, 3, 1e-3) for g in range(1, G + 1)])
     ref = oracle_sample(oracle, w["target"], w["Zinit"], N, 10, G, None, w["eps_scale"], w["gamma"], 17, temperature=temps)
     assert np.array_equal(mc.chain, ref["chain"]) and np.array_equal(mc.log_obj, ref["log_obj"]) and np.array_equal(Z, ref["Z"])
