@@ -15,7 +15,8 @@ import numpy as np
 
 PKG_DIR = Path(__file__).resolve().parent
 REPO_ROOT = PKG_DIR.parent
-LIB_PATH = PKG_DIR / "libdemcz_hip.so"
+# DEMCZ_LIB selects another build of the same HIP library (kernel A/B experiments); never a CPU path
+LIB_PATH = Path(os.environ["DEMCZ_LIB"]) if os.environ.get("DEMCZ_LIB") else PKG_DIR / "libdemcz_hip.so"
 ABI_VERSION = 1
 
 TARGET_MVNORMAL, TARGET_ISO_QUAD, TARGET_LINREG_SSE, TARGET_HOST_CALLBACK = 0, 1, 2, 3

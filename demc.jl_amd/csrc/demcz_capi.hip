@@ -37,7 +37,8 @@ struct demcz_handle {
     double* dlp = nullptr;
     double* dchain = nullptr;
     double* dlogobj = nullptr;
-    unsigned int* dchanged = nullptr;
+    double* dlp_origin = nullptr;   // log_obj of every chain when the history window opened
+    bool origin_valid = false;
     double* dtemp = nullptr;
     int64_t temp_cap = 0;
     int32_t* d_block_offsets = nullptr;
@@ -62,7 +63,6 @@ struct demcz_handle {
     // host-closure mode
     double* dXprop = nullptr;
     double* dlogu = nullptr;
-    double* dlp_before = nullptr;
     bool proposal_pending = false;
     bool gen_open = false;
     // multi-GPU
@@ -121,9 +121,9 @@ static hipError_t dev_alloc_copy(T** dst, const T* src, size_t n, hipStream_t s)
 
 static void free_all(demcz_handle* h)
 {
-    void* bufs[] = {h->dZ, h->dX, h->dlp, h->dchain, h->dlogobj, h->dchanged, h->dtemp, h->d_block_offsets,
+    void* bufs[] = {h->dZ, h->dX, h->dlp, h->dchain, h->dlogobj, h->dlp_origin, h->dtemp, h->d_block_offsets,
                     h->d_slot_of, h->d_eps, h->d_mu, h->d_Wp, h->d_design, h->d_y, h->d_scratch, h->dXprop,
-                    h->dlogu, h->dlp_before, h->d_gather};
+                    h->dlogu, h->d_gather};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->d_stage) (void)hipHostFree(h->d_stage);
@@ -240,9 +240,7 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         CRCHK(hipMemsetAsync(h->dchain, 0, (size_t)N * d * cfg->Gcap * sizeof(double), h->stream));   // demcz.jl:24
         CRCHK(hipMemsetAsync(h->dlogobj, 0, (size_t)N * cfg->Gcap * sizeof(double), h->stream));
     }
-    const int64_t ccap = std::max<int64_t>(cfg->Gcap, 1);
-    CRCHK(hipMalloc((void**)&h->dchanged, (size_t)ccap * sizeof(unsigned int)));
-    CRCHK(hipMemsetAsync(h->dchanged, 0, (size_t)ccap * sizeof(unsigned int), h->stream));
+    CRCHK(hipMalloc((void**)&h->dlp_origin, (size_t)N * sizeof(double)));
     CRCHK(dev_alloc_copy(&h->d_block_offsets, h->block_offsets.data(), h->block_offsets.size(), h->stream));
     CRCHK(dev_alloc_copy(&h->d_slot_of, h->slot_of.data(), h->slot_of.size(), h->stream));
     CRCHK(dev_alloc_copy(&h->d_eps, h->eps.data(), h->eps.size(), h->stream));
@@ -265,7 +263,6 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
     if (cfg->target_kind == DEMCZ_TARGET_HOST_CALLBACK) {
         CRCHK(hipMalloc((void**)&h->dXprop, (size_t)N * d * sizeof(double)));
         CRCHK(hipMalloc((void**)&h->dlogu, (size_t)N * sizeof(double)));
-        CRCHK(hipMalloc((void**)&h->dlp_before, (size_t)N * sizeof(double)));
     }
     h->stage_cap = std::max<int64_t>(4096, (int64_t)d * (d + 1) + 64);
     CRCHK(hipHostMalloc((void**)&h->d_stage, (size_t)h->stage_cap * sizeof(double), hipHostMallocDefault));
@@ -351,8 +348,11 @@ extern "C" int32_t demcz_set_state(demcz_handle* h, const double* X, const doubl
         int32_t rc = launch_logp(h, h->dX, N, N, h->dlp);
         if (rc) return rc;
     }
+    HIPCHK(h, hipMemcpyAsync(h->dlp_origin, h->dlp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->M = M0;
+    h->g_done = h->g0;
+    h->origin_valid = true;
     h->has_state = true;
     h->proposal_pending = false;
     h->gen_open = false;
@@ -389,9 +389,12 @@ extern "C" int32_t demcz_set_history_origin(demcz_handle* h, int64_t g0)
     if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
     if (g0 < 0) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_set_history_origin: g0 >= 0");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    // slot 0's predecessor is the current log_obj if exactly g0 generations have been run
+    h->origin_valid = h->has_state && (h->g_done == g0 || h->g_done == h->g0);
+    if (h->has_state)
+        HIPCHK(h, hipMemcpyAsync(h->dlp_origin, h->dlp, (size_t)h->cfg.N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (h->has_state && h->g_done == h->g0) h->g_done = g0;      // nothing run yet: renumbering only
     h->g0 = g0;
-    const int64_t ccap = std::max<int64_t>(h->cfg.Gcap, 1);
-    HIPCHK(h, hipMemsetAsync(h->dchanged, 0, (size_t)ccap * sizeof(unsigned int), h->stream));
     return DEMCZ_OK;
 }
 
@@ -554,7 +557,6 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     P.Z = h->dZ; P.Zw = h->dZ; P.ZS = h->ZS;
     P.Xcur = h->dX; P.lpcur = h->dlp;
     P.chain = hist ? h->dchain : nullptr; P.logobj = hist ? h->dlogobj : nullptr;
-    P.changed = h->dchanged;
     P.N = h->cfg.N; P.chain_id0 = h->cfg.chain_id0; P.d = h->cfg.d;
     P.gamma = gamma; P.seed = h->cfg.seed; P.S = h->S; P.Nblocks = h->cfg.Nblocks;
     P.block_offsets = h->d_block_offsets; P.slot_of = h->d_slot_of; P.eps = h->d_eps;
@@ -621,12 +623,20 @@ extern "C" int32_t demcz_get_changed(demcz_handle* h, int64_t g_from, int64_t g_
     if (!h || !changed) return DEMCZ_ERR_INVALID_ARGUMENT;
     int32_t rc = check_hist_range(h, g_from, g_to, "demcz_get_changed");
     if (rc) return rc;
-    HIPCHK(h, hipSetDevice(h->cfg.device_id));
     const int64_t G = g_to - g_from + 1, s0 = g_from - h->g0 - 1;
-    std::vector<unsigned int> tmp((size_t)G);
-    HIPCHK(h, hipMemcpyAsync(tmp.data(), h->dchanged + s0, (size_t)G * sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+    if (s0 == 0 && !h->origin_valid)
+        return fail(h, DEMCZ_ERR_STATE, "demcz_get_changed: the log_obj before the first history slot is not known "
+                                        "(set the history origin when exactly g0 generations have been run)");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    rc = ensure_scratch(h, G);
+    if (rc) return rc;
+    static_assert(sizeof(long long) == sizeof(double), "scratch reuse");
+    hipLaunchKernelGGL(changed_from_history_kernel, dim3((unsigned)G), dim3(256), 0, h->stream, (const double*)h->dlogobj,
+                       (const double*)h->dlp_origin, h->cfg.N, s0, (long long*)h->d_scratch);
+    HIPCHK(h, hipGetLastError());
+    static_assert(sizeof(int64_t) == sizeof(long long), "int64 layout");
+    HIPCHK(h, hipMemcpyAsync(changed, h->d_scratch, (size_t)G * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (int64_t i = 0; i < G; ++i) changed[i] = (int64_t)tmp[(size_t)i];
     return DEMCZ_OK;
 }
 
@@ -817,25 +827,18 @@ __global__ void accept_commit_kernel(int64_t N, int d, double* Xcur, double* lpc
     }
 }
 
-__global__ void end_generation_kernel(int64_t N, int d, const double* Xcur, const double* lpcur, const double* lp_before,
-                                      double* chain, double* logobj, unsigned int* changed, int64_t slot,
+__global__ void end_generation_kernel(int64_t N, int d, const double* Xcur, const double* lpcur,
+                                      double* chain, double* logobj, int64_t slot,
                                       double* Z, int64_t ZS, int64_t M, int do_append)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool ch = false;
-    if (c < N) {
-        const double lp = lpcur[c];
-        for (int p = 0; p < d; ++p) {
-            const double xv = Xcur[c + N * p];
-            if (chain) chain[c + N * (p + (int64_t)d * slot)] = xv;
-            if (do_append) Z[(M + c) * ZS + p] = xv;
-        }
-        if (logobj) logobj[c + N * slot] = lp;
-        ch = lp != lp_before[c];
+    if (c >= N) return;
+    for (int p = 0; p < d; ++p) {
+        const double xv = Xcur[c + N * p];
+        if (chain) chain[c + N * (p + (int64_t)d * slot)] = xv;
+        if (do_append) Z[(M + c) * ZS + p] = xv;
     }
-    const unsigned long long m = __ballot(ch);
-    if (m != 0ull && (unsigned)__lane_id() == (unsigned)__ffsll((long long)m) - 1u)
-        atomicAdd(&changed[slot], (unsigned int)__popcll(m));
+    if (logobj) logobj[c + N * slot] = lpcur[c];
 }
 }  // namespace demcz
 
@@ -849,10 +852,7 @@ extern "C" int32_t demcz_propose(demcz_handle* h, int64_t g, int32_t ib, double 
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     const int64_t N = h->cfg.N;
     const int d = h->cfg.d;
-    if (!h->gen_open) {
-        HIPCHK(h, hipMemcpyAsync(h->dlp_before, h->dlp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        h->gen_open = true;
-    }
+    h->gen_open = true;
     int64_t off = 0;
     for (int t = 0; t < ib; ++t) off += blockstep_nblk(h->block_offsets[t + 1] - h->block_offsets[t]);
     WindowParams P{};
@@ -899,7 +899,7 @@ extern "C" int32_t demcz_end_generation(demcz_handle* h, int64_t g)
     const bool kappend = boundary && !sharded && !h->external_append;
     if (kappend && h->M + N > h->cfg.Mcap) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_end_generation: Z capacity exceeded");
     hipLaunchKernelGGL(end_generation_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, h->stream, N, h->cfg.d, h->dX, h->dlp,
-                       h->dlp_before, hist ? h->dchain : nullptr, hist ? h->dlogobj : nullptr, h->dchanged,
+                       hist ? h->dchain : nullptr, hist ? h->dlogobj : nullptr,
                        hist ? (g - h->g0 - 1) : 0, h->dZ, h->ZS, h->M, kappend ? 1 : 0);
     HIPCHK(h, hipGetLastError());
     if (kappend) h->M += N;

@@ -46,7 +46,6 @@ struct WindowParams {
     // history (slot s holds generation g0 + 1 + s)
     double* chain;           // N x d x Gcap or nullptr
     double* logobj;          // N x Gcap or nullptr
-    unsigned int* changed;   // Gcap counters
     const double* temperature;  // per generation of this window, or nullptr
     int64_t N;
     int64_t chain_id0;
@@ -152,7 +151,6 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel(const WindowParams P)
     rng_seek(st, P.seed, (uint64_t)(P.chain_id0 + c), (uint64_t)(P.g_first - 1) * (uint64_t)P.S);
 
     for (int gi = 0; gi < P.ngen; ++gi) {
-        const double lp_before = lp;
         const int nblocks = FULL ? 1 : P.Nblocks;
         for (int ib = 0; ib < nblocks; ++ib) {
             uint64_t r1, r2, i1, i2;
@@ -225,9 +223,6 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel(const WindowParams P)
             for (int p = 0; p < D; ++p) P.chain[c + P.N * (p + (int64_t)D * slot)] = x[p];
             P.logobj[c + P.N * slot] = lp;
         }
-        const unsigned long long m = __ballot(lp != lp_before);
-        if (m != 0ull && (unsigned)__lane_id() == (unsigned)__ffsll((long long)m) - 1u)
-            atomicAdd(&P.changed[slot], (unsigned int)__popcll(m));
     }
 #pragma unroll
     for (int p = 0; p < D; ++p) P.Xcur[c + P.N * p] = x[p];
@@ -257,7 +252,6 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel_generic(const WindowP
     rng_seek(st, P.seed, (uint64_t)(P.chain_id0 + c), (uint64_t)(P.g_first - 1) * (uint64_t)P.S);
 
     for (int gi = 0; gi < P.ngen; ++gi) {
-        const double lp_before = lp;
         for (int ib = 0; ib < P.Nblocks; ++ib) {
             uint64_t r1, r2, i1, i2;
             rng_next(st, r1, r2);
@@ -304,9 +298,6 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel_generic(const WindowP
             for (int p = 0; p < d; ++p) P.chain[c + P.N * (p + (int64_t)d * slot)] = xs[p * WINDOW_BS + tid];
             P.logobj[c + P.N * slot] = lp;
         }
-        const unsigned long long m = __ballot(lp != lp_before);
-        if (m != 0ull && (unsigned)__lane_id() == (unsigned)__ffsll((long long)m) - 1u)
-            atomicAdd(&P.changed[slot], (unsigned int)__popcll(m));
     }
     for (int p = 0; p < d; ++p) {
         double xv = xs[p * WINDOW_BS + tid];
@@ -441,6 +432,29 @@ __global__ void __launch_bounds__(256) rhat_reduce_kernel(const double* mean_j, 
         out[p] = ra[0];
         if (stage) out[d + p] = rb[0];
     }
+}
+
+// K7c: changed[s - s_from] = number of chains whose log_obj in history slot s differs from the slot
+// before it (slot 0: from lp_origin, the log_obj the chains had when the history window opened) --
+// the event sum(diff(log_obj, dims=2) .!= 0) counts (demcz.jl:42, demcz_anneal.jl:50).  Computed
+// from the history on demand: a per-generation atomic inside the chain-update loop would put
+// N/8 atomics per generation on one cache line (measured: the dominant cost of the window kernel).
+__global__ void __launch_bounds__(256) changed_from_history_kernel(const double* logobj, const double* lp_origin, int64_t N,
+                                                                   int64_t s_from, long long* out)
+{
+    __shared__ int cnt[256];
+    const int64_t s = s_from + blockIdx.x;
+    const double* cur = logobj + N * s;
+    const double* prev = (s == 0) ? lp_origin : logobj + N * (s - 1);
+    int k = 0;
+    for (int64_t c = threadIdx.x; c < N; c += 256) k += (cur[c] != prev[c]) ? 1 : 0;
+    cnt[threadIdx.x] = k;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) cnt[threadIdx.x] += cnt[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = cnt[0];
 }
 
 // K7a: per-chain count of generations in slots s0+1 .. s0+w-1 whose log_obj differs from the

@@ -42,9 +42,15 @@ struct philox_blocks : rocrand_device::philox4x32_10_engine {
 // all that is needed is to stop the compiler from moving memory operations across the hand-off.
 __device__ __forceinline__ void wave_lds_handoff()
 {
+#ifdef DEMCZ_AB_FENCE
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+#endif
 }
 
 template <int TARGET, int D, int L>
@@ -87,8 +93,12 @@ __global__ void __launch_bounds__(64) window_kernel_ml(const WindowParams P)
     const double scale = (D == 1) ? P.gamma : P.gamma / sqrt((double)(2 * D));
     philox_blocks rng;
 
-    for (int gi = 0; gi < P.ngen; ++gi) {
-        // ---- draws (independent of the chain state) ------------------------------------------
+    // Draws and archive gathers do not depend on the chain state (the row indices come from the
+    // counter-based stream), so generation g+1's are issued before generation g's accept resolves:
+    // the gather's L2 / Infinity-Cache / HBM latency hides behind a whole generation of work.
+    double za[NP], zb[NP], zt[NP], logu_next;
+    double za_c[NP], zb_c[NP], zt_c[NP];
+    auto issue_draws = [&](int gi) {
         uint64_t r1, r2, i1, i2;
         rng.block(P.seed, chain, (uint64_t)(P.g_first + gi - 1) * (uint64_t)S + (uint64_t)role, r1, r2);
         const double lg = dm_log(u_open(r1));
@@ -107,22 +117,39 @@ __global__ void __launch_bounds__(64) window_kernel_ml(const WindowParams P)
         if (r < S) rec[gq * S + r] = e;
         wave_lds_handoff();
         const double2 ii = rec[gq * S];
-        const double logu = rec[gq * S + S - 1].x;
+        logu_next = rec[gq * S + S - 1].x;
         const int64_t row1 = __double_as_longlong(ii.x), row2 = __double_as_longlong(ii.y);
-        double delta[NP];
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int p = r + L * k;
-            const bool own = p < D;
-            const int pc = own ? p : 0;
+            const int pc = (p < D) ? p : 0;
             const int zi = (D == 1) ? 0 : pc;
-            const double zt = reinterpret_cast<const double*>(rec)[(gq * S + 1 + zi / 2) * 2 + (zi & 1)];
-            const double diff = P.Z[row1 * P.ZS + pc] - P.Z[row2 * P.ZS + pc];
+            zt[k] = reinterpret_cast<const double*>(rec)[(gq * S + 1 + zi / 2) * 2 + (zi & 1)];
+            za[k] = P.Z[row1 * P.ZS + pc];
+            zb[k] = P.Z[row2 * P.ZS + pc];
+        }
+        wave_lds_handoff();      // rec is rewritten by the next call
+    };
+    issue_draws(0);
+
+    for (int gi = 0; gi < P.ngen; ++gi) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { za_c[k] = za[k]; zb_c[k] = zb[k]; zt_c[k] = zt[k]; }
+        const double logu = logu_next;
+#ifndef DEMCZ_AB_EARLY
+        issue_draws(gi + 1);     // the one past the window is unused (kept to stay branch-free)
+#endif
+        double delta[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const double diff = za_c[k] - zb_c[k];
             const double t1 = scale * diff;
-            const double t2 = epsv[k] * zt;
+            const double t2 = epsv[k] * zt_c[k];
             delta[k] = t1 + t2;
         }
-        wave_lds_handoff();      // rec is rewritten by the next generation's draws
+#ifdef DEMCZ_AB_EARLY
+        issue_draws(gi + 1);
+#endif
 
         // ---- state-dependent part --------------------------------------------------------------
         double xp[NP];
@@ -171,7 +198,6 @@ __global__ void __launch_bounds__(64) window_kernel_ml(const WindowParams P)
         double dlt = lpp - lp;
         if (P.temperature) dlt = dlt / P.temperature[gi];
         const bool acc = logu < dlt;
-        const double lp_before = lp;
         lp = acc ? lpp : lp;
         const int64_t slot = P.slot_first + gi;
 #pragma unroll
@@ -181,9 +207,6 @@ __global__ void __launch_bounds__(64) window_kernel_ml(const WindowParams P)
             if (P.chain && p < D) P.chain[c + P.N * (p + (int64_t)D * slot)] = x[k];
         }
         if (P.chain && r == 0) P.logobj[c + P.N * slot] = lp;
-        const unsigned long long m = __ballot(r == 0 && lp != lp_before);
-        if (m != 0ull && (unsigned)lane == (unsigned)__ffsll((long long)m) - 1u)
-            atomicAdd(&P.changed[slot], (unsigned int)__popcll(m));
         wave_lds_handoff();      // rvec / yvec are rewritten by the next generation
     }
 #pragma unroll
