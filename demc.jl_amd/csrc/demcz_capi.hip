@@ -502,7 +502,7 @@ static int32_t append_after_window(demcz_handle* h)
     // the window kernel did not append (sharded or external): all-gather and scatter
     const int d = h->cfg.d;
     const int64_t N = h->cfg.N;
-    if (h->comm && h->nranks > 1) {
+    if (h->comm) {   // also at nranks == 1, so the collective path is exercised on a one-GPU box
         const int64_t total = N * h->nranks;
         if (h->M + total > h->cfg.Mcap) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_run: Z capacity exceeded");
         NCCLCHK(h, ncclAllGather(h->dX, h->d_gather, (size_t)N * d, ncclDouble, h->comm, h->stream));
@@ -528,7 +528,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     const int64_t G = g_to - g_from + 1;
     const int K = h->cfg.K;
-    const bool sharded = (h->comm && h->nranks > 1);
+    const bool sharded = (h->comm != nullptr);
     const bool kernel_appends = !sharded && !h->external_append;
     // capacity check for all appends of this call
     {
@@ -701,7 +701,7 @@ extern "C" int32_t demcz_rhat(demcz_handle* h, int64_t g_from, int64_t g_to, dou
     const int d = r.d;
     const int64_t n = r.n;
     const int64_t m = 2 * r.N * h->nranks;                   // utils.jl:5
-    const bool sharded = (h->comm && h->nranks > 1);
+    const bool sharded = (h->comm != nullptr);
     double* sums = r.sums;
     hipLaunchKernelGGL(rhat_reduce_kernel, dim3(d), dim3(256), 0, h->stream, r.mean_j, r.s2_j, r.N, d, 0, (const double*)nullptr, sums);
     HIPCHK(h, hipGetLastError());
@@ -895,7 +895,7 @@ extern "C" int32_t demcz_end_generation(demcz_handle* h, int64_t g)
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     const int64_t N = h->cfg.N;
     const bool boundary = (g % h->cfg.K) == 0;
-    const bool sharded = (h->comm && h->nranks > 1);
+    const bool sharded = (h->comm != nullptr);
     const bool kappend = boundary && !sharded && !h->external_append;
     if (kappend && h->M + N > h->cfg.Mcap) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_end_generation: Z capacity exceeded");
     hipLaunchKernelGGL(end_generation_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, h->stream, N, h->cfg.d, h->dX, h->dlp,
@@ -932,7 +932,7 @@ extern "C" int32_t demcz_comm_init(demcz_handle* h, const void* unique_id_128B, 
     NCCLCHK(h, ncclCommInitRank(&h->comm, nranks, id, rank));
     h->nranks = nranks;
     h->rank = rank;
-    if (nranks > 1) HIPCHK(h, hipMalloc((void**)&h->d_gather, (size_t)h->cfg.N * h->cfg.d * nranks * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_gather, (size_t)h->cfg.N * h->cfg.d * nranks * sizeof(double)));
     return DEMCZ_OK;
 }
 

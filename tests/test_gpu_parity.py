@@ -230,3 +230,23 @@ def test_full_size_c2_properties(demc, oracle):
     ref = oracle_sample(oracle, w["target"], w["Zinit"], N, 10, 300, None, w["eps_scale"], 2.38, 31953150)
     assert np.array_equal(mc.chain[:, :, :300], ref["chain"])
     runner.close()
+
+
+def test_bench_under_torchrun_single_rank(tmp_path):
+    """bench.py launched the way the driver launches it (torch.distributed.run, 127.0.0.1): one JSON
+    line with the contract's keys.  (N>1 needs N GPUs; the one-GPU box runs the N=1 form.)"""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", str(root / "bench.py"), "--gpus", "1", "--steps", "200", "--warmup", "50", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, check=True).stdout
+    line = [l for l in out.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d
+    assert d["n_gpus"] == 1 and d["steps"] == 200 and d["value"] > 1e6 and d["dtype"] == "f64"
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
