@@ -35,6 +35,21 @@ def algorithmic_bytes_per_update(d, K):
     return 8.0 * (3 * d + 1 + d / K)
 
 
+def measured_traffic(n_loc, d, lanes):
+    """HBM-side bytes per window-kernel launch from the committed rocprofv3 PMC passes
+    (scripts/collect_profiles.sh + summarize_profiles.py: FETCH_SIZE and WRITE_SIZE in separate
+    passes, KiB units; the window kernel's reads are single-line random gathers, reported raw --
+    see DESIGN.md section 6).  Only valid for the workload the passes were taken on."""
+    f = ROOT / "profiles" / "latest_traffic.json"
+    if not f.exists() or (n_loc, d) != (1024, 5):
+        return None
+    name = f"window_kernel_ml<0, {d}, {lanes}>" if lanes > 1 else f"window_kernel<0, {d}, true>"
+    for k, v in json.loads(f.read_text())["kernels"].items():
+        if name in k:
+            return v.get("bytes_per_launch_raw")
+    return None
+
+
 def cpu_baseline(w, N, d, K, seed, budget_updates):
     """Time the oracle (test infrastructure, used here only as the reported CPU baseline)."""
     sys.path.insert(0, str(ROOT / "oracle"))
@@ -174,7 +189,7 @@ def main():
                        "parallelism": f"chains sharded x{world}, Z replicated" if world > 1 else "single GPU"},
             "gens_to_rhat_1p05": gens_to_rhat, "rhat_trace": rhat_trace[-12:], "accept_ratio_mean": acc,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "kernel": "demcz::window_kernel", "launches": launches,
+                         "traffic": measured_traffic(n_loc, d, eng.info()["lanes_per_chain"]) if K == 10 else None, "kernel": "demcz::window_kernel", "launches": launches,
                          "avg_launch_us": avg_launch_s * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_chain_update": B},
         }

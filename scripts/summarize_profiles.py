@@ -31,4 +31,6 @@ for k, v in out.items():
     v["bytes_per_launch_raw"] = (f_ + w_) * 1024
     v["bytes_per_launch_fetch_x2"] = (2 * f_ + w_) * 1024
 json.dump(out, open(f"profiles/{tag}_traffic.json", "w"), indent=1, sort_keys=True)
+json.dump({"tag": tag, "workload": "bench.py defaults (C2: N=1024, d=5, K=10)", "kernels": out},
+          open("profiles/latest_traffic.json", "w"), indent=1, sort_keys=True)
 print(json.dumps({k: v for k, v in out.items() if "window" in k}, indent=1))
