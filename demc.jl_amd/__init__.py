@@ -15,4 +15,6 @@ from .targets import MvNormalTarget, IsoQuadTarget, LinRegSSETarget, is_device_t
 from .sampler import (MC, DEMCopt, demcopt, demcz_sample, demcz_anneal, tempbaseline,   # noqa: F401
                       make_runner, initial_state,
                       Sharding, DEFAULT_ADAPT)
+from .utils import (Rhat_gelman, flatten_chain, accept_ratio, mean_cov_chain, convergence_check,   # noqa: F401
+                    save_checkpoint, load_checkpoint)
 from . import workloads                                         # noqa: F401

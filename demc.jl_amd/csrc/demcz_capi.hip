@@ -57,6 +57,7 @@ struct demcz_handle {
     int64_t M = 0;
     int64_t g_done = 0;
     int64_t g0 = 0;           // history origin
+    int64_t rng_offset = 0;   // generations already consumed from every chain's stream (resume)
     bool has_state = false;
     int64_t launches = 0;
     bool external_append = false;
@@ -566,7 +567,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         const int64_t next_boundary = ((g - 1) / K + 1) * K;      // first multiple of K that is >= g
         const int64_t w_end = std::min(next_boundary, g_to);
         P.M = h->M;
-        P.g_first = g;
+        P.g_first = g + h->rng_offset;      // only positions the Philox streams
         P.ngen = (int32_t)(w_end - g + 1);
         P.slot_first = hist ? (g - h->g0 - 1) : 0;
         P.temperature = temperature ? h->dtemp + (g - g_from) : nullptr;
@@ -858,7 +859,7 @@ extern "C" int32_t demcz_propose(demcz_handle* h, int64_t g, int32_t ib, double 
     WindowParams P{};
     P.Z = h->dZ; P.ZS = h->ZS; P.M = h->M; P.Xcur = h->dX; P.N = N; P.chain_id0 = h->cfg.chain_id0; P.d = d;
     P.gamma = gamma; P.seed = h->cfg.seed; P.block_offsets = h->d_block_offsets; P.slot_of = h->d_slot_of; P.eps = h->d_eps;
-    const uint64_t blk0 = (uint64_t)(g - 1) * (uint64_t)h->S + (uint64_t)off;
+    const uint64_t blk0 = (uint64_t)(g + h->rng_offset - 1) * (uint64_t)h->S + (uint64_t)off;
     hipLaunchKernelGGL(propose_kernel, dim3((unsigned)((N + WINDOW_BS - 1) / WINDOW_BS)), dim3(WINDOW_BS),
                        (size_t)(d + 1) * WINDOW_BS * sizeof(double), h->stream, P, (int)ib, blk0, h->dXprop, h->dlogu);
     HIPCHK(h, hipGetLastError());
@@ -983,6 +984,78 @@ extern "C" int32_t demcz_set_external_append(demcz_handle* h, int32_t enabled)
     if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
     h->external_append = enabled != 0;
     return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_set_rng_offset(demcz_handle* h, int64_t generations)
+{
+    if (!h || generations < 0) return DEMCZ_ERR_INVALID_ARGUMENT;
+    h->rng_offset = generations;
+    return DEMCZ_OK;
+}
+
+// ---- stateless diagnostics on caller arrays (src/utils.jl) ------------------------------------------
+namespace {
+struct ScratchHandle {
+    demcz_handle h;
+    int32_t open(int32_t device_id, int64_t N, int d, int64_t G, const double* chain, const double* log_obj)
+    {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, DEMCZ_ERR_NO_DEVICE, "no HIP device visible (there is no CPU fallback)");
+        if (device_id < 0 || device_id >= ndev || N < 1 || d < 1 || G < 1) return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT, "bad device or shape");
+        h.cfg.N = N; h.cfg.d = d; h.cfg.Gcap = G; h.cfg.device_id = device_id; h.g0 = 0; h.nranks = 1;
+        HIPCHK(&h, hipSetDevice(device_id));
+        HIPCHK(&h, hipStreamCreateWithFlags(&h.stream, hipStreamNonBlocking));
+        h.own_stream = true;
+        if (chain) {
+            HIPCHK(&h, hipMalloc((void**)&h.dchain, (size_t)N * d * G * sizeof(double)));
+            HIPCHK(&h, hipMemcpyAsync(h.dchain, chain, (size_t)N * d * G * sizeof(double), hipMemcpyHostToDevice, h.stream));
+        }
+        if (log_obj) {
+            HIPCHK(&h, hipMalloc((void**)&h.dlogobj, (size_t)N * G * sizeof(double)));
+            HIPCHK(&h, hipMemcpyAsync(h.dlogobj, log_obj, (size_t)N * G * sizeof(double), hipMemcpyHostToDevice, h.stream));
+        }
+        h.stage_cap = 4096 + (int64_t)d * (d + 1);
+        HIPCHK(&h, hipHostMalloc((void**)&h.d_stage, (size_t)h.stage_cap * sizeof(double), hipHostMallocDefault));
+        return DEMCZ_OK;
+    }
+    ~ScratchHandle()
+    {
+        if (h.stream) (void)hipStreamSynchronize(h.stream);
+        free_all(&h);
+    }
+};
+int32_t diag_fail(const ScratchHandle& s, int32_t rc)
+{
+    if (rc) g_create_error = s.h.err;
+    return rc;
+}
+}  // namespace
+
+extern "C" int32_t demcz_rhat_array(int32_t device_id, const double* chain, int64_t N, int32_t d, int64_t G, double* rhat)
+{
+    if (!chain || !rhat) return DEMCZ_ERR_INVALID_ARGUMENT;
+    ScratchHandle s;
+    int32_t rc = s.open(device_id, N, d, G, chain, nullptr);
+    if (rc) return diag_fail(s, rc);
+    return diag_fail(s, demcz_rhat(&s.h, 1, G, rhat));
+}
+
+extern "C" int32_t demcz_accept_ratio_array(int32_t device_id, const double* log_obj, int64_t N, int64_t G, double* ratio)
+{
+    if (!log_obj || !ratio) return DEMCZ_ERR_INVALID_ARGUMENT;
+    ScratchHandle s;
+    int32_t rc = s.open(device_id, N, 1, G, nullptr, log_obj);
+    if (rc) return diag_fail(s, rc);
+    return diag_fail(s, demcz_accept_ratio(&s.h, 1, G, ratio));
+}
+
+extern "C" int32_t demcz_mean_cov_array(int32_t device_id, const double* chain, int64_t N, int32_t d, int64_t G, double* mean, double* cov)
+{
+    if (!chain || !mean || !cov) return DEMCZ_ERR_INVALID_ARGUMENT;
+    ScratchHandle s;
+    int32_t rc = s.open(device_id, N, d, G, chain, nullptr);
+    if (rc) return diag_fail(s, rc);
+    return diag_fail(s, demcz_mean_cov(&s.h, 1, G, mean, cov));
 }
 
 extern "C" int32_t demcz_get_info(const demcz_handle* h, int64_t* M, int64_t* launches_window, int32_t* lanes_per_chain)

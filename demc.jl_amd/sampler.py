@@ -221,7 +221,7 @@ class _Runner:
 
 
 def make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp, *, seed, sharding, device_id,
-                 engine_factory, lanes_per_chain, stream):
+                 engine_factory, lanes_per_chain, stream, rng_offset=0):
     M0, d = Zmat.shape
     if M0 < 2:
         raise ValueError("Zmat needs at least 2 rows (two distinct archive rows per proposal, demcz.jl:176-179)")
@@ -241,6 +241,8 @@ def make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp,
                     seed=seed, target=logobj, chain_id0=c0, device_id=device_id, stream=stream,
                     lanes_per_chain=lanes_per_chain)
         e.set_state(X[c0:c0 + n_loc], None if logp is None else logp[c0:c0 + n_loc], Zmat)
+        if rng_offset:
+            e.set_rng_offset(rng_offset)
         engines.append(e)
     if sh and sh.mode == "rccl" and sh.world_size > 1:
         uid = engines[0].comm_unique_id() if sh.rank == 0 else None
@@ -327,7 +329,7 @@ def print_status_anneal(runner, ig):
 def demcz_sample(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockindex=None, eps_scale=None, γ=2.38, *,
                  prevrun=None, verbose=True, print_step=100, autostop="no", autostop_Rhat=1.01,
                  autostop_every=1000, seed=0, init="last_rows", padded_Z=False, sharding=None, device_id=0,
-                 lanes_per_chain=0, stream=None, engine_factory=None, return_runner=False):
+                 lanes_per_chain=0, stream=None, engine_factory=None, return_runner=False, rng_offset=None):
     """Serial-driver surface of src/demcz.jl: pass a ``DEMCopt`` as the third argument
     (``demcz_sample(logobj, Zmat, opts; prevrun)``, :1-3) or the positional arguments with
     the positional method's defaults (:9).  Returns ``(mc, Z)``."""
@@ -346,9 +348,11 @@ def demcz_sample(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
         raise ValueError("Nblocks != length(blockindex)")
     autostop = _sym(autostop)
     X, logp = initial_state(logobj, Zmat, N, Ngeneration, K, prevrun, init)
+    if rng_offset is None:       # a resumed run continues the chains' random streams where prevrun stopped
+        rng_offset = 0 if prevrun is None else prevrun.chain.shape[2]
     runner = make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp, seed=seed,
                           sharding=sharding, device_id=device_id, engine_factory=engine_factory,
-                          lanes_per_chain=lanes_per_chain, stream=stream)
+                          lanes_per_chain=lanes_per_chain, stream=stream, rng_offset=rng_offset)
     Mcap = M0 + int(math.ceil(N * Ngeneration / K))
     try:
         if verbose:
@@ -386,7 +390,7 @@ def demcz_sample(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
 def demcz_anneal(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockindex=None, eps_scale=None, γ=2.38, *,
                  prevrun=None, verbose=True, print_step=100, temperaturefun=tempbaseline, T0=3, TN=0.0,
                  adaptγ=None, seed=0, init="last_rows", padded_Z=False, compat_serial_temp=False, sharding=None,
-                 device_id=0, lanes_per_chain=0, stream=None, engine_factory=None):
+                 device_id=0, lanes_per_chain=0, stream=None, engine_factory=None, rng_offset=None):
     """Simulated-annealing variant, src/demcz_anneal.jl:14-65: tempered accept
     ``log(u) < (lp' - lp)/T(ig)`` (:172-178), ``T(ig) = temperaturefun(ig, Ngeneration, T0, TN)``,
     gamma adapted from the windowed acceptance ratio every ``adapt_every`` generations (:48-57).
@@ -407,9 +411,11 @@ def demcz_anneal(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
     if eps_scale is None:
         eps_scale = 1e-4 * np.ones(d)
     X, logp = initial_state(logobj, Zmat, N, Ngeneration, K, prevrun, init)
+    if rng_offset is None:
+        rng_offset = 0 if prevrun is None else prevrun.chain.shape[2]
     runner = make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp, seed=seed,
                           sharding=sharding, device_id=device_id, engine_factory=engine_factory,
-                          lanes_per_chain=lanes_per_chain, stream=stream)
+                          lanes_per_chain=lanes_per_chain, stream=stream, rng_offset=rng_offset)
     Mcap = M0 + int(math.ceil(N * Ngeneration / K))
 
     def temp(ig):

@@ -184,6 +184,22 @@ int32_t demcz_append_rows(demcz_handle* h, const double* rows, int64_t nrows, in
  * caller (demcz_export_current_device + host collective + demcz_append_rows_device). */
 int32_t demcz_set_external_append(demcz_handle* h, int32_t enabled);
 
+/* Resume: the chains' Philox streams have already been advanced by `generations` generations (the
+ * length of a previous run, demcz.jl:18-22): generation g of this handle draws what generation
+ * generations+g of an uninterrupted run would draw.  K boundaries still follow this handle's own g,
+ * like the reference's restarted `ig`. */
+int32_t demcz_set_rng_offset(demcz_handle* h, int64_t generations);
+
+/* Stateless diagnostics on caller (host) arrays, for code that post-processes returned histories
+ * the way the reference's examples do (test/example_normpdf.jl:35-47): the array is uploaded, reduced
+ * on the device, and nothing is kept.
+ *   demcz_rhat_array          Rhat_gelman(chain, N, G, d)              src/utils.jl:2-20
+ *   demcz_accept_ratio_array  sum(diff(log_obj,dims=2).!=0,dims=2)./(G-1)   src/utils.jl:61
+ *   demcz_mean_cov_array      mean_cov_chain(chain, N, G, d)           src/utils.jl:96-111 */
+int32_t demcz_rhat_array(int32_t device_id, const double* chain, int64_t N, int32_t d, int64_t G, double* rhat);
+int32_t demcz_accept_ratio_array(int32_t device_id, const double* log_obj, int64_t N, int64_t G, double* ratio);
+int32_t demcz_mean_cov_array(int32_t device_id, const double* chain, int64_t N, int32_t d, int64_t G, double* mean, double* cov);
+
 /* Introspection for benchmarks and tests. */
 int32_t demcz_get_info(const demcz_handle* h, int64_t* M, int64_t* launches_window, int32_t* lanes_per_chain);
 

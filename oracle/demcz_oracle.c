@@ -375,7 +375,7 @@ enum { ORACLE_SCHED_SYNCHRONOUS = 0, ORACLE_SCHED_SEQUENTIAL = 1 };
 ORACLE_API int oracle_demcz_run(const oracle_problem* p, double* X, double* logp, double* Z, int64_t* M,
                                 int64_t g_from, int64_t g_to, double gamma, const double* temperature,
                                 double* chain_out, double* logobj_out, int64_t* changed_out,
-                                int schedule, int do_append)
+                                int schedule, int do_append, int64_t rng_offset)
 {
     const int64_t N = p->N;
     const int d = p->d;
@@ -392,7 +392,8 @@ ORACLE_API int oracle_demcz_run(const oracle_problem* p, double* X, double* logp
             double lp = logp[c];
             const double lp_before = lp;
             const int64_t Mvis = (schedule == ORACLE_SCHED_SEQUENTIAL) ? *M : Mgen;
-            uint64_t blk0 = (uint64_t)(g - 1) * (uint64_t)S;
+            /* rng_offset: generations a previous run already drew from every chain's stream (resume) */
+            uint64_t blk0 = (uint64_t)(g + rng_offset - 1) * (uint64_t)S;
             for (int ib = 0; ib < p->Nblocks; ++ib) {
                 block_step(p, Z, Mvis, (uint64_t)(p->chain_id0 + c), blk0, ib, gamma, T, x, &lp, NULL);
                 blk0 += (uint64_t)blockstep_nblk(p->block_offsets[ib + 1] - p->block_offsets[ib]);

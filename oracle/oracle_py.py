@@ -182,7 +182,7 @@ def block_step(prob: Problem, Z, M, chain_local, g, ib, gamma, x, lp, temperatur
 
 
 def run(prob: Problem, X, lp, Z, M, g_from, g_to, gamma, temperature=None, schedule=SCHED_SYNCHRONOUS,
-        do_append=True, history=True, native=False):
+        do_append=True, history=True, native=False, rng_offset=0):
     """Advance generations g_from..g_to (1-based, inclusive) IN PLACE on X (N,d) F-order,
     lp (N,), Z (Mcap,d) F-order.  Returns (M_new, chain (N,d,G) or None, log_obj (N,G) or None,
     changed (G,))."""
@@ -200,7 +200,7 @@ def run(prob: Problem, X, lp, Z, M, g_from, g_to, gamma, temperature=None, sched
     rc = lib(native).oracle_demcz_run(C.byref(prob.c), _ptr(X), _ptr(lp), _ptr(Z), C.byref(Mc),
                                       C.c_int64(g_from), C.c_int64(g_to), C.c_double(gamma), _ptr(temp),
                                       _ptr(chain), _ptr(lobj), _ptr(changed, _lp),
-                                      C.c_int(schedule), C.c_int(1 if do_append else 0))
+                                      C.c_int(schedule), C.c_int(1 if do_append else 0), C.c_int64(rng_offset))
     if rc != 0:
         raise RuntimeError(f"oracle_demcz_run failed rc={rc}")
     return int(Mc.value), chain, lobj, changed

@@ -3,7 +3,7 @@ import numpy as np
 
 
 def oracle_sample(O, target, Z0, N, K, G, blocks, eps, gamma, seed, temperature=None, schedule=0, init="last_rows",
-                  X0=None, lp0=None):
+                  X0=None, lp0=None, rng_offset=0):
     """Oracle twin of demcz_sample's generation loop.  Returns dict(chain, log_obj, X, logp, Z, M, changed)."""
     M0, d = Z0.shape
     Mcap = M0 + -(-N * G // K)
@@ -15,5 +15,6 @@ def oracle_sample(O, target, Z0, N, K, G, blocks, eps, gamma, seed, temperature=
     lp = O.logp(prob, X) if lp0 is None else np.array(lp0, dtype=np.float64)
     Z = np.zeros((Mcap, d), order="F")
     Z[:M0] = Z0
-    M, chain, lobj, changed = O.run(prob, X, lp, Z, M0, 1, G, gamma, temperature=temperature, schedule=schedule)
+    M, chain, lobj, changed = O.run(prob, X, lp, Z, M0, 1, G, gamma, temperature=temperature, schedule=schedule,
+                                     rng_offset=rng_offset)
     return dict(chain=chain, log_obj=lobj, X=X, logp=lp, Z=Z[:M].copy(), M=M, changed=changed, prob=prob)

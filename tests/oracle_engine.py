@@ -20,6 +20,10 @@ class OracleEngine:
         self.changed = np.zeros(Gcap, dtype=np.int64)
         self.external = False
         self.M = 0
+        self.rng_offset = 0
+
+    def set_rng_offset(self, generations):
+        self.rng_offset = int(generations)
 
     def set_state(self, X, logp, Z):
         self.X = np.array(X, dtype=np.float64, order="F")
@@ -33,7 +37,7 @@ class OracleEngine:
 
     def run(self, g_from, g_to, gamma, temperature=None):
         M, ch, lo, cg = O.run(self.prob, self.X, self.lp, self.Z, self.M, g_from, g_to, gamma,
-                              temperature=temperature, do_append=not self.external)
+                              temperature=temperature, do_append=not self.external, rng_offset=self.rng_offset)
         self.M = M
         self.chain[:, :, g_from - 1:g_to] = ch
         self.log_obj[:, g_from - 1:g_to] = lo

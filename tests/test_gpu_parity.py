@@ -250,3 +250,32 @@ def test_bench_under_torchrun_single_rank(tmp_path):
         assert k in d
     assert d["n_gpus"] == 1 and d["steps"] == 200 and d["value"] > 1e6 and d["dtype"] == "f64"
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+
+
+def test_utils_mirror_reference_postprocessing(demc, oracle, tmp_path):
+    """The post-processing of test/example_normpdf.jl:35-51 with the reference's function names,
+    reduced on the GPU from host arrays; plus resume (prevrun) and the checkpoint file."""
+    d, N, G = 5, 5, 2000
+    w = demc.workloads.mvnormal_problem(d, N)
+    Z0 = w["Zinit"][:50]
+    args = (N, 10, G, 1, [range(d)], w["eps_scale"], 2.38)
+    mc, Z = demc.demcz_sample(w["target"], Z0, *args, verbose=False, seed=7)
+    mc2, Z2 = demc.demcz_sample(w["target"], Z[-51:], *args, prevrun=mc, verbose=False, seed=7)   # example_normpdf.jl:32
+    assert mc2.chain.shape == (N, d, 2 * G)
+    keep = slice(2 * G - G // 2, 2 * G)                              # :35-39
+    chain_burned, logobj_burned = mc2.chain[:, :, keep], mc2.log_obj[:, keep]
+    flat = demc.flatten_chain(chain_burned, N, G // 2, d)           # :40
+    assert flat.shape == (d, N * (G // 2)) and flat[2, 3 * N + 1] == chain_burned[1, 2, 3]   # utils.jl:26-29 ordering
+    b, Sb = demc.mean_cov_chain(chain_burned, N, G // 2, d)         # :44
+    ob, oS = oracle.mean_cov_chain(chain_burned)
+    assert np.allclose(b, ob, rtol=1e-12) and np.allclose(Sb, oS, rtol=1e-9, atol=1e-18)
+    acc, Rhat = demc.convergence_check(chain_burned, logobj_burned, "none", verbose=False)   # :47
+    assert np.allclose(Rhat, oracle.rhat_gelman(chain_burned), rtol=1e-9)
+    assert np.allclose(acc, oracle.changed_per_chain(logobj_burned) / (G // 2 - 1), rtol=1e-15)
+    assert np.allclose(demc.Rhat_gelman(chain_burned, N, G // 2, d), Rhat)
+    # resume == uninterrupted run (K | G), through the checkpoint file
+    one, Zone = demc.demcz_sample(w["target"], Z0, N, 10, 2 * G, 1, [range(d)], w["eps_scale"], 2.38, verbose=False, seed=7)
+    demc.save_checkpoint(tmp_path / "ck.npz", mc, Z, G, 7)
+    prev, Zc, done, seed = demc.load_checkpoint(tmp_path / "ck.npz")
+    res, Zres = demc.demcz_sample(w["target"], Zc, *args, prevrun=prev, rng_offset=done, verbose=False, seed=seed)
+    assert np.array_equal(res.chain[:, :, 1:], one.chain[:, :, G:]) and np.array_equal(Zres, Zone)

@@ -66,8 +66,12 @@ def test_prevrun_concatenates_and_resumes(oracle):
     assert mc2.chain.shape == (N, d, 2 * G) and mc2.log_obj.shape == (N, 2 * G)
     assert np.array_equal(mc2.chain[:, :, :G], mc1.chain)
     ref = oracle_sample(oracle, w["target"], Z1[-51:], N, 10, G, None, w["eps_scale"], 2.38, 2,
-                        X0=mc1.chain[:, :, -1], lp0=mc1.log_objcurrent)
+                        X0=mc1.chain[:, :, -1], lp0=mc1.log_objcurrent, rng_offset=G)
     assert np.array_equal(mc2.chain[:, :, G:], ref["chain"])
+    # same seed, resumed: the chains' streams continue, so (G then G more) == 2G in one go when K | G
+    a, Za = demc.demcz_sample(w["target"], w["Zinit"][:50], N, 10, 2 * G, 1, [range(d)], w["eps_scale"], 2.38, seed=1, **kw)
+    b, Zb = demc.demcz_sample(w["target"], Z1, N, 10, G, 1, [range(d)], w["eps_scale"], 2.38, seed=1, prevrun=mc1, **kw)
+    assert np.array_equal(a.chain, b.chain) and np.array_equal(Za, Zb)
 
 
 def test_autostop_truncates_at_first_passing_check(oracle):
