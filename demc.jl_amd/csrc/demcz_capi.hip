@@ -102,7 +102,8 @@ static int64_t blockstep_nblk(int b)
     return 1 + (nn + 1) / 2 + 1;
 }
 
-static int ml_lanes_available(int target_kind, int d, bool full_block);
+constexpr size_t ML_MAX_DYNAMIC_LDS = 160 * 1024;      // LDS per CU on gfx950
+static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t nobs);
 
 extern "C" int32_t demcz_abi_version(void) { return DEMCZ_ABI_VERSION; }
 
@@ -214,7 +215,7 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
     if (h->full_block)
         for (int p = 0; p < d; ++p) h->full_block = h->full_block && (h->block_indices[p] == p);
     {   // layout: L lanes per chain when the chip would otherwise sit idle (small N), else one lane
-        const int L = ml_lanes_available(cfg->target_kind, d, h->full_block);
+        const int L = ml_lanes_available(cfg->target_kind, d, h->full_block, cfg->nobs);
         if (cfg->lanes_per_chain > 1) {
             if (L != cfg->lanes_per_chain) {
                 h->err = "demcz_create: the requested lanes_per_chain layout is not built for this target / d / block structure";
@@ -419,14 +420,27 @@ static void launch_window_generic(const demcz_handle* h, const WindowParams& P, 
 template <int TARGET, int D, int L>
 static void launch_window_ml(const demcz_handle* h, const WindowParams& P)
 {
-    constexpr int G = 64 / L;
-    hipLaunchKernelGGL((window_kernel_ml<TARGET, D, L>), dim3((unsigned)((P.N + G - 1) / G)), dim3(64), 0, h->stream, P);
+    constexpr int NG = ml_waves<TARGET>() * (64 / L);      // chains per workgroup
+    const size_t dyn = ml_dynamic_lds<TARGET, D, L>(P.tp.nobs);
+    if (dyn > 48 * 1024) {
+        static bool raised = false;                         // once per process and instantiation
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_ml<TARGET, D, L>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL((window_kernel_ml<TARGET, D, L>), dim3((unsigned)((P.N + NG - 1) / NG)), dim3(64 * ml_waves<TARGET>()),
+                       dyn, h->stream, P);
 }
 
 // which multi-lane layout is compiled for (target, d, full single block): 0 = none
-static int ml_lanes_available(int target_kind, int d, bool full_block)
+static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t nobs)
 {
     if (!full_block) return 0;
+    if (target_kind == DEMCZ_TARGET_LINREG_SSE && d == 10 &&
+        ml_dynamic_lds<TARGET_LINREG_SSE, 10, 16>(nobs) <= ML_MAX_DYNAMIC_LDS)
+        return 16;      // design + y resident in LDS
     if (target_kind == DEMCZ_TARGET_MVNORMAL) {
         if (d == 2 || d == 3 || d == 4 || d == 5 || d == 8 || d == 10) return 8;
         if (d == 20) return 16;
@@ -451,6 +465,9 @@ static bool try_launch_ml(const demcz_handle* h, const WindowParams& P)
         }
     } else if (h->cfg.target_kind == DEMCZ_TARGET_ISO_QUAD && d == 10) {
         launch_window_ml<TARGET_ISO_QUAD, 10, 8>(h, P);
+        return true;
+    } else if (h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE && d == 10) {
+        launch_window_ml<TARGET_LINREG_SSE, 10, 16>(h, P);
         return true;
     }
     return false;

@@ -20,6 +20,7 @@ namespace demcz {
 enum { TARGET_MVNORMAL = 0, TARGET_ISO_QUAD = 1, TARGET_LINREG_SSE = 2, TARGET_HOST_CALLBACK = 3 };
 
 constexpr int MAX_D = 64;        // generic (runtime-d) path keeps x / xprop / normals in LDS
+constexpr int LINREG_PARTIALS = 16;   // interleaved partial sums of the regression SSE (arithmetic spec)
 constexpr int WINDOW_BS = 64;    // one wave per workgroup: small N spreads over as many CUs as waves
 
 struct TargetParams {
@@ -116,16 +117,42 @@ __device__ __forceinline__ double target_logp(const TargetParams& tp, int d, XF 
         }
         return -q;
     } else {
-        double sse = 0.0;
-        for (int64_t o = 0; o < tp.nobs; ++o) {
-            const double* row = tp.design + o * dd;
-            double acc = row[0] * X(0);
+        // 16 interleaved partial sums (observation o -> partial o mod 16), then the fixed tree
+        // (l, l+8), (l, l+4), (l, l+2), (0, 1): the spec's order, shared with the 16-lane layout.
+        double part[LINREG_PARTIALS];
+        const int64_t nfull = tp.nobs / LINREG_PARTIALS;       // rounds in which every partial gets a term
 #pragma unroll
-            for (int j = 1; j < dd; ++j) acc = fma(row[j], X(j), acc);
-            double r = tp.yobs[o] - acc;
-            sse = (o == 0) ? r * r : fma(r, r, sse);
+        for (int l = 0; l < LINREG_PARTIALS; ++l) part[l] = 0.0;
+        for (int64_t k = 0; k < nfull; ++k) {
+#pragma unroll
+            for (int l = 0; l < LINREG_PARTIALS; ++l) {
+                const int64_t o = k * LINREG_PARTIALS + l;
+                const double* row = tp.design + o * dd;
+                double acc = row[0] * X(0);
+#pragma unroll
+                for (int j = 1; j < dd; ++j) acc = fma(row[j], X(j), acc);
+                const double r = tp.yobs[o] - acc;
+                part[l] = (k == 0) ? r * r : fma(r, r, part[l]);
+            }
         }
-        return -0.5 * sse;
+#pragma unroll
+        for (int l = 0; l < LINREG_PARTIALS; ++l) {
+            const int64_t o = nfull * LINREG_PARTIALS + l;
+            if (o < tp.nobs) {
+                const double* row = tp.design + o * dd;
+                double acc = row[0] * X(0);
+#pragma unroll
+                for (int j = 1; j < dd; ++j) acc = fma(row[j], X(j), acc);
+                const double r = tp.yobs[o] - acc;
+                part[l] = (nfull == 0) ? r * r : fma(r, r, part[l]);
+            }
+        }
+#pragma unroll
+        for (int h = LINREG_PARTIALS / 2; h >= 1; h >>= 1) {
+#pragma unroll
+            for (int l = 0; l < h; ++l) part[l] = part[l] + part[l + h];
+        }
+        return -0.5 * part[0];
     }
 }
 

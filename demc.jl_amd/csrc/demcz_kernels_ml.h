@@ -53,29 +53,76 @@ __device__ __forceinline__ void wave_lds_handoff()
 #endif
 }
 
+// Workgroup geometry: MvNormal / isotropic targets run one wave per workgroup (small N spreads
+// over as many CUs as there are waves).  The regression target keeps the whole design matrix and
+// y in LDS, shared by ML_LR_WAVES waves (= 4 * 64/L chains) of one workgroup.
+// (measured on C5: 4 waves/workgroup 64.7 us per K-window, 8 waves 78.0, 16 waves 133.1, 2 waves 68.9)
+constexpr int ML_LR_WAVES = 4;
+
+template <int TARGET>
+constexpr int ml_waves() { return TARGET == TARGET_LINREG_SSE ? ML_LR_WAVES : 1; }
+
+// bytes of dynamic LDS the regression layout needs (0 for the other targets)
 template <int TARGET, int D, int L>
-__global__ void __launch_bounds__(64) window_kernel_ml(const WindowParams P)
+__host__ __device__ constexpr size_t ml_dynamic_lds(int64_t nobs)
 {
-    static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "latency layout: MvNormal / isotropic targets");
+    if (TARGET != TARGET_LINREG_SSE) return 0;
+    constexpr int G = 64 / L, NPAIRS = (D == 1) ? 1 : (D + 1) / 2, S = NPAIRS + 2, DP = ((D + 1) / 2) * 2;
+    constexpr int NG = ML_LR_WAVES * G;
+    return (size_t)NG * S * 16 + (size_t)NG * DP * 8 + (size_t)NG * L * 8 + (size_t)(((nobs + 1) / 2) * 2) * 8 + (size_t)nobs * D * 8;
+}
+
+template <int TARGET, int D, int L>
+__global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(const WindowParams P)
+{
+    constexpr bool LR = (TARGET == TARGET_LINREG_SSE);
+    constexpr int WAVES = ml_waves<TARGET>();
     constexpr int G = 64 / L;                              // chains per wave
+    constexpr int NG = WAVES * G;                          // chains per workgroup
     constexpr int NPAIRS = (D == 1) ? 1 : (D + 1) / 2;
     constexpr int S = NPAIRS + 2;                          // Philox blocks per generation (full block)
     static_assert(S <= L, "one Philox block per lane");
+    static_assert(!LR || L == LINREG_PARTIALS, "regression: one partial sum per lane of the group");
     constexpr int NP = (D + L - 1) / L;                    // parameters owned per lane
     constexpr int DP = ((D + 1) / 2) * 2;                  // staging row, 16-byte multiple
-    __shared__ double2 rec[G * S];
-    __shared__ __attribute__((aligned(16))) double rvec[G * DP];
-    __shared__ __attribute__((aligned(16))) double yvec[G * DP];
+    constexpr int YP = LR ? L : DP;                        // second staging row: y components / SSE partials
 
-    const int lane = threadIdx.x;
-    const int r = lane % L, gq = lane / L;
-    const int64_t c = (int64_t)blockIdx.x * G + gq;
-    if (c >= P.N) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ml_dyn_lds[];
+    __shared__ double2 rec_s[LR ? 1 : NG * S];
+    __shared__ __attribute__((aligned(16))) double rvec_s[LR ? 2 : NG * DP];
+    __shared__ __attribute__((aligned(16))) double yvec_s[LR ? 2 : NG * YP];
+    double2* rec = rec_s;
+    double* rvec = rvec_s;
+    double* yvec = yvec_s;
+    const double* y_l = nullptr;
+    const double* design_l = nullptr;
+    if constexpr (LR) {
+        // everything is carved from the dynamic region (no static LDS in front of it: 16-byte base)
+        unsigned char* q = ml_dyn_lds;
+        rec = reinterpret_cast<double2*>(q);   q += (size_t)NG * S * 16;
+        rvec = reinterpret_cast<double*>(q);   q += (size_t)NG * DP * 8;
+        yvec = reinterpret_cast<double*>(q);   q += (size_t)NG * YP * 8;
+        double* yl = reinterpret_cast<double*>(q);   q += (size_t)(((P.tp.nobs + 1) / 2) * 2) * 8;
+        double* dl = reinterpret_cast<double*>(q);
+        const int64_t nd = P.tp.nobs * D;
+        for (int64_t i = threadIdx.x; i < nd; i += 64 * WAVES) dl[i] = P.tp.design[i];
+        for (int64_t i = threadIdx.x; i < P.tp.nobs; i += 64 * WAVES) yl[i] = P.tp.yobs[i];
+        __syncthreads();
+        y_l = yl;
+        design_l = dl;
+    }
+
+    const int lane = threadIdx.x & 63;
+    const int r = lane % L, gq = (threadIdx.x >> 6) * G + lane / L;
+    const int64_t c_raw = (int64_t)blockIdx.x * NG + gq;
+    if (!LR && c_raw >= P.N) return;
+    const bool active = c_raw < P.N;                       // regression: idle groups of the last workgroup keep pace
+    const int64_t c = active ? c_raw : P.N - 1;
     const uint64_t chain = (uint64_t)(P.chain_id0 + c);
     const int role = (r < S) ? r : S - 1;
 
     // per-lane constants: owned parameters, their eps / mu and rows of W
-    double x[NP], epsv[NP], muv[NP], Wrow[NP][D];
+    double x[NP], epsv[NP], muv[NP], Wrow[NP][(TARGET == TARGET_MVNORMAL) ? D : 1];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int p = r + L * k;
@@ -83,7 +130,7 @@ __global__ void __launch_bounds__(64) window_kernel_ml(const WindowParams P)
         const int pc = own ? p : 0;
         x[k] = own ? P.Xcur[c + P.N * pc] : 0.0;
         epsv[k] = P.eps[pc];
-        muv[k] = P.tp.mu[pc];
+        muv[k] = LR ? 0.0 : P.tp.mu[pc];
         if constexpr (TARGET == TARGET_MVNORMAL) {
 #pragma unroll
             for (int j = 0; j < D; ++j) Wrow[k][j] = (own && j <= pc) ? P.tp.Wp[(pc * (pc + 1)) / 2 + j] : 0.0;
@@ -136,9 +183,7 @@ __global__ void __launch_bounds__(64) window_kernel_ml(const WindowParams P)
 #pragma unroll
         for (int k = 0; k < NP; ++k) { za_c[k] = za[k]; zb_c[k] = zb[k]; zt_c[k] = zt[k]; }
         const double logu = logu_next;
-#ifndef DEMCZ_AB_EARLY
         issue_draws(gi + 1);     // the one past the window is unused (kept to stay branch-free)
-#endif
         double delta[NP];
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -147,9 +192,6 @@ __global__ void __launch_bounds__(64) window_kernel_ml(const WindowParams P)
             const double t2 = epsv[k] * zt_c[k];
             delta[k] = t1 + t2;
         }
-#ifdef DEMCZ_AB_EARLY
-        issue_draws(gi + 1);
-#endif
 
         // ---- state-dependent part --------------------------------------------------------------
         double xp[NP];
@@ -157,7 +199,7 @@ __global__ void __launch_bounds__(64) window_kernel_ml(const WindowParams P)
         for (int k = 0; k < NP; ++k) {
             const int p = r + L * k;
             xp[k] = x[k] + delta[k];
-            if (p < D) rvec[gq * DP + p] = xp[k] - muv[k];
+            if (p < D) rvec[gq * DP + p] = LR ? xp[k] : xp[k] - muv[k];
         }
         wave_lds_handoff();
         double rj[DP];
@@ -178,22 +220,83 @@ __global__ void __launch_bounds__(64) window_kernel_ml(const WindowParams P)
                     const double t = fma(Wrow[k][j], rj[j], acc);
                     acc = (j <= p) ? t : acc;
                 }
-                if (p < D) yvec[gq * DP + p] = acc;
+                if (p < D) yvec[gq * YP + p] = acc;
             }
             wave_lds_handoff();
             double q = 0.0;
 #pragma unroll
             for (int j = 0; j < DP / 2; ++j) {
-                const double2 t = reinterpret_cast<const double2*>(yvec + gq * DP)[j];
+                const double2 t = reinterpret_cast<const double2*>(yvec + gq * YP)[j];
                 q = (j == 0) ? t.x * t.x : fma(t.x, t.x, q);
                 if (2 * j + 1 < D) q = fma(t.y, t.y, q);
             }
             lpp = fma(-0.5, q, P.tp.c0);
-        } else {
+        } else if constexpr (TARGET == TARGET_ISO_QUAD) {
             double q = 0.0;
 #pragma unroll
             for (int j = 0; j < D; ++j) q = (j == 0) ? rj[0] * rj[0] : fma(rj[j], rj[j], q);
             lpp = -q;
+        } else {
+            // lane r accumulates SSE partial r (observations r, r+16, ...) from the LDS copy of the
+            // design; rows of 16 consecutive observations sit on distinct banks (stride D*8 bytes).
+            double sacc = 0.0;
+            {
+                int64_t o = r;
+                if (o < P.tp.nobs) {
+                    const double* row = design_l + o * D;
+                    double acc = row[0] * rj[0];
+#pragma unroll
+                    for (int j = 1; j < D; ++j) acc = fma(row[j], rj[j], acc);
+                    const double res = y_l[o] - acc;
+                    sacc = res * res;
+                }
+                o += L;
+                // four observations in flight: their dot products are independent dependency
+                // chains (the order inside each, and of the four additions into sacc, is the spec's)
+                for (; o + 3 * L < P.tp.nobs; o += 4 * L) {
+                    const double* q0 = design_l + o * D;
+                    const double* q1 = q0 + L * D;
+                    const double* q2 = q1 + L * D;
+                    const double* q3 = q2 + L * D;
+                    double a0 = q0[0] * rj[0], a1 = q1[0] * rj[0], a2 = q2[0] * rj[0], a3 = q3[0] * rj[0];
+#pragma unroll
+                    for (int j = 1; j < D; ++j) {
+                        a0 = fma(q0[j], rj[j], a0);
+                        a1 = fma(q1[j], rj[j], a1);
+                        a2 = fma(q2[j], rj[j], a2);
+                        a3 = fma(q3[j], rj[j], a3);
+                    }
+                    const double e0 = y_l[o] - a0, e1 = y_l[o + L] - a1, e2 = y_l[o + 2 * L] - a2, e3 = y_l[o + 3 * L] - a3;
+                    sacc = fma(e0, e0, sacc);
+                    sacc = fma(e1, e1, sacc);
+                    sacc = fma(e2, e2, sacc);
+                    sacc = fma(e3, e3, sacc);
+                }
+#pragma unroll 1
+                for (; o < P.tp.nobs; o += L) {
+                    const double* row = design_l + o * D;
+                    double acc = row[0] * rj[0];
+#pragma unroll
+                    for (int j = 1; j < D; ++j) acc = fma(row[j], rj[j], acc);
+                    const double res = y_l[o] - acc;
+                    sacc = fma(res, res, sacc);
+                }
+            }
+            yvec[gq * YP + r] = sacc;
+            wave_lds_handoff();
+            double part[L];
+#pragma unroll
+            for (int j = 0; j < L / 2; ++j) {
+                const double2 t = reinterpret_cast<const double2*>(yvec + gq * YP)[j];
+                part[2 * j] = t.x;
+                part[2 * j + 1] = t.y;
+            }
+#pragma unroll
+            for (int h = L / 2; h >= 1; h >>= 1) {
+#pragma unroll
+                for (int l = 0; l < h; ++l) part[l] = part[l] + part[l + h];
+            }
+            lpp = -0.5 * part[0];
         }
         double dlt = lpp - lp;
         if (P.temperature) dlt = dlt / P.temperature[gi];
@@ -204,20 +307,20 @@ __global__ void __launch_bounds__(64) window_kernel_ml(const WindowParams P)
         for (int k = 0; k < NP; ++k) {
             const int p = r + L * k;
             x[k] = acc ? xp[k] : x[k];
-            if (P.chain && p < D) P.chain[c + P.N * (p + (int64_t)D * slot)] = x[k];
+            if (P.chain && p < D && active) P.chain[c + P.N * (p + (int64_t)D * slot)] = x[k];
         }
-        if (P.chain && r == 0) P.logobj[c + P.N * slot] = lp;
+        if (P.chain && r == 0 && active) P.logobj[c + P.N * slot] = lp;
         wave_lds_handoff();      // rvec / yvec are rewritten by the next generation
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int p = r + L * k;
-        if (p < D) {
+        if (p < D && active) {
             P.Xcur[c + P.N * p] = x[k];
             if (P.do_append) P.Zw[(P.M + c) * P.ZS + p] = x[k];
         }
     }
-    if (r == 0) P.lpcur[c] = lp;
+    if (r == 0 && active) P.lpcur[c] = lp;
 }
 
 }  // namespace demcz

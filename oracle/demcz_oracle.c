@@ -248,16 +248,29 @@ static double target_logp(const oracle_problem* p, const double* x)
         }
         return -q;
     } else {
-        /* -0.5 * sum((y - X*b).^2), test/example_linreg.jl:32 */
-        double sse = 0.0;
-        for (int64_t o = 0; o < p->nobs; ++o) {
-            double acc = p->design[o] * x[0];
-            for (int j = 1; j < d; ++j)
-                acc = fma(p->design[o + p->nobs * j], x[j], acc);
-            double r = p->yobs[o] - acc;
-            sse = (o == 0) ? r * r : fma(r, r, sse);
+        /* -0.5 * sum((y - X*b).^2), test/example_linreg.jl:32.
+         * Summation order of the spec: 16 interleaved partial sums (observation o goes to partial
+         * o mod 16, accumulated in increasing o: first term r*r, then fma(r, r, partial)), combined
+         * by the fixed tree (l, l+8), (l, l+4), (l, l+2), (0, 1).  A sum of 1000 squares has no
+         * canonical order in the reference (Julia's sum() is itself a pairwise reduction); this one
+         * lets 16 lanes / 16 accumulators work on one chain. */
+        double part[16];
+        for (int l = 0; l < 16; ++l) {
+            double s = 0.0;
+            int first = 1;
+            for (int64_t o = l; o < p->nobs; o += 16) {
+                double acc = p->design[o] * x[0];
+                for (int j = 1; j < d; ++j)
+                    acc = fma(p->design[o + p->nobs * j], x[j], acc);
+                double r = p->yobs[o] - acc;
+                s = first ? r * r : fma(r, r, s);
+                first = 0;
+            }
+            part[l] = s;
         }
-        return -0.5 * sse;
+        for (int h = 8; h >= 1; h >>= 1)
+            for (int l = 0; l < h; ++l) part[l] = part[l] + part[l + h];
+        return -0.5 * part[0];
     }
 }
 

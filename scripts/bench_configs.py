@@ -58,4 +58,4 @@ if __name__ == "__main__":
     w = demc.workloads.mvnormal_problem(20, 1024); gpu_row("C4 shard MvNormal d=20 N=1024/GPU", w, 1024, 20, [range(20)])
     w = demc.workloads.mvnormal_problem(20, 8192); gpu_row("C4 whole MvNormal d=20 N=8192 on 1 GPU", w, 8192, 20, [range(20)])
     w = demc.workloads.linreg_problem(10, 2048); gpu_row("C5 linreg SSE d=10 nobs=1000 N=2048 anneal", w, 2048, 10, [range(10)], anneal=True)
-    cpu_rows()
+    if len(sys.argv) <= 2: cpu_rows()
