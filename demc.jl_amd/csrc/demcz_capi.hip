@@ -103,7 +103,7 @@ static int64_t blockstep_nblk(int b)
 }
 
 constexpr size_t ML_MAX_DYNAMIC_LDS = 160 * 1024;      // LDS per CU on gfx950
-static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t nobs);
+static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t nobs, int max_blocklen, int nblocks);
 
 extern "C" int32_t demcz_abi_version(void) { return DEMCZ_ABI_VERSION; }
 
@@ -215,7 +215,9 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
     if (h->full_block)
         for (int p = 0; p < d; ++p) h->full_block = h->full_block && (h->block_indices[p] == p);
     {   // layout: L lanes per chain when the chip would otherwise sit idle (small N), else one lane
-        const int L = ml_lanes_available(cfg->target_kind, d, h->full_block, cfg->nobs);
+        int maxb = 0;
+        for (int ib = 0; ib < cfg->Nblocks; ++ib) maxb = std::max(maxb, h->block_offsets[ib + 1] - h->block_offsets[ib]);
+        const int L = ml_lanes_available(cfg->target_kind, d, h->full_block, cfg->nobs, maxb, cfg->Nblocks);
         if (cfg->lanes_per_chain > 1) {
             if (L != cfg->lanes_per_chain) {
                 h->err = "demcz_create: the requested lanes_per_chain layout is not built for this target / d / block structure";
@@ -435,9 +437,17 @@ static void launch_window_ml(const demcz_handle* h, const WindowParams& P)
 }
 
 // which multi-lane layout is compiled for (target, d, full single block): 0 = none
-static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t nobs)
+static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t nobs, int max_blocklen = 0, int nblocks = 1)
 {
-    if (!full_block) return 0;
+    if (!full_block) {
+        // block updates: every block-step must fit one Philox block per lane: 2 + ceil(b/2) <= L
+        if (nblocks > MLB_MAX_BLOCKS) return 0;
+        if (target_kind == DEMCZ_TARGET_MVNORMAL) {
+            if ((d == 5 || d == 6 || d == 10) && 2 + (max_blocklen + 1) / 2 <= 8) return 8;
+            if (d == 20 && 2 + (max_blocklen + 1) / 2 <= 16) return 16;
+        }
+        return 0;
+    }
     if (target_kind == DEMCZ_TARGET_LINREG_SSE && d == 10 &&
         ml_dynamic_lds<TARGET_LINREG_SSE, 10, 16>(nobs) <= ML_MAX_DYNAMIC_LDS)
         return 16;      // design + y resident in LDS
@@ -449,10 +459,27 @@ static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t n
     return 0;
 }
 
+template <int TARGET, int D, int L>
+static void launch_window_mlb(const demcz_handle* h, const WindowParams& P)
+{
+    constexpr int G = 64 / L;
+    hipLaunchKernelGGL((window_kernel_mlb<TARGET, D, L>), dim3((unsigned)((P.N + G - 1) / G)), dim3(64), 0, h->stream, P);
+}
+
 static bool try_launch_ml(const demcz_handle* h, const WindowParams& P)
 {
     if (h->lanes <= 1) return false;
     const int d = P.d;
+    if (!h->full_block) {
+        if (h->cfg.target_kind != DEMCZ_TARGET_MVNORMAL) return false;
+        switch (d) {
+        case 5: launch_window_mlb<TARGET_MVNORMAL, 5, 8>(h, P); return true;
+        case 6: launch_window_mlb<TARGET_MVNORMAL, 6, 8>(h, P); return true;
+        case 10: launch_window_mlb<TARGET_MVNORMAL, 10, 8>(h, P); return true;
+        case 20: launch_window_mlb<TARGET_MVNORMAL, 20, 16>(h, P); return true;
+        }
+        return false;
+    }
     if (h->cfg.target_kind == DEMCZ_TARGET_MVNORMAL) {
         switch (d) {
         case 2: launch_window_ml<TARGET_MVNORMAL, 2, 8>(h, P); return true;

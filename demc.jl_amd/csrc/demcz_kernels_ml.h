@@ -323,4 +323,198 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
     if (r == 0 && active) P.lpcur[c] = lp;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Latency layout with block updates (DEMCopt.Nblocks > 1 or a permuted block; update_blocks,
+// src/demcz.jl:167-172): the same L-lane cooperation, one block-step at a time.  Block tables
+// (position of every parameter inside every block, Philox offset and gamma scale of each block)
+// sit in LDS; each block-step proposes only the block's parameters and re-evaluates the full
+// log-density, exactly as the reference does.  Every block needs S_ib = 2 + ceil(nn/2) <= L
+// Philox blocks (checked on the host).
+// ------------------------------------------------------------------------------------------------
+constexpr int MLB_MAX_BLOCKS = 64;
+
+template <int TARGET, int D, int L>
+__global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
+{
+    static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "block layout: MvNormal / isotropic targets");
+    constexpr int G = 64 / L;
+    constexpr int NP = (D + L - 1) / L;
+    constexpr int DP = ((D + 1) / 2) * 2;
+    __shared__ double2 rec[G * L];
+    __shared__ __attribute__((aligned(16))) double rvec[G * DP];
+    __shared__ __attribute__((aligned(16))) double yvec[G * DP];
+    __shared__ int slot_l[MLB_MAX_BLOCKS * D];             // position of parameter p in block ib, or -1
+    __shared__ int blen_l[MLB_MAX_BLOCKS], boff_l[MLB_MAX_BLOCKS];
+    __shared__ double bscale_l[MLB_MAX_BLOCKS];
+
+    const int lane = threadIdx.x;
+    const int NB = P.Nblocks;
+    for (int i = lane; i < NB * D; i += 64) slot_l[i] = P.slot_of[i];
+    if (lane == 0) {
+        int off = 0;
+        for (int ib = 0; ib < NB; ++ib) {
+            const int b = P.block_offsets[ib + 1] - P.block_offsets[ib];
+            const int nn = (b == 1) ? 1 : b;
+            blen_l[ib] = b;
+            boff_l[ib] = off;
+            bscale_l[ib] = (b == 1) ? P.gamma : P.gamma / sqrt((double)(2 * b));
+            off += 1 + (nn + 1) / 2 + 1;
+        }
+    }
+    __syncthreads();                                       // one wave per workgroup: table hand-off only
+
+    const int r = lane % L, gq = lane / L;
+    const int64_t c = (int64_t)blockIdx.x * G + gq;
+    if (c >= P.N) return;
+    const uint64_t chain = (uint64_t)(P.chain_id0 + c);
+
+    double x[NP], epsv[NP], muv[NP], Wrow[NP][(TARGET == TARGET_MVNORMAL) ? D : 1];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int p = r + L * k;
+        const bool own = p < D;
+        const int pc = own ? p : 0;
+        x[k] = own ? P.Xcur[c + P.N * pc] : 0.0;
+        epsv[k] = P.eps[pc];
+        muv[k] = P.tp.mu[pc];
+        if constexpr (TARGET == TARGET_MVNORMAL) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) Wrow[k][j] = (own && j <= pc) ? P.tp.Wp[(pc * (pc + 1)) / 2 + j] : 0.0;
+        }
+    }
+    double lp = P.lpcur[c];
+    philox_blocks rng;
+
+    // draws of block-step (gi, ib), issued one block-step ahead of their use
+    double za[NP], zb[NP], zt[NP], logu_next;
+    int tslot[NP];
+    auto issue_draws = [&](int gi, int ib) {
+        const int b = blen_l[ib];
+        const int nn = (b == 1) ? 1 : b;
+        const int Sb = 2 + (nn + 1) / 2;
+        const int role = (r < Sb) ? r : Sb - 1;
+        uint64_t r1, r2, i1, i2;
+        rng.block(P.seed, chain, (uint64_t)(P.g_first + gi - 1) * (uint64_t)P.S + (uint64_t)(boff_l[ib] + role), r1, r2);
+        const double lg = dm_log(u_open(r1));
+        double z0, z1;
+        {
+            const double R = sqrt(-2.0 * lg);
+            double cs, sn;
+            dm_sincos2pi(r2 >> 11, cs, sn);
+            z0 = R * cs;
+            z1 = R * sn;
+        }
+        draw_rows(r1, r2, (uint64_t)P.M, i1, i2);
+        double2 e;
+        e.x = (r == 0) ? __longlong_as_double((long long)i1) : ((r == Sb - 1) ? lg : z0);
+        e.y = (r == 0) ? __longlong_as_double((long long)i2) : z1;
+        if (r < Sb) rec[gq * L + r] = e;
+        wave_lds_handoff();
+        const double2 ii = rec[gq * L];
+        logu_next = rec[gq * L + Sb - 1].x;
+        const int64_t row1 = __double_as_longlong(ii.x), row2 = __double_as_longlong(ii.y);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int p = r + L * k;
+            const int pc = (p < D) ? p : 0;
+            const int ts = (p < D) ? slot_l[ib * D + pc] : -1;
+            tslot[k] = ts;
+            const int zi = (b == 1 || ts < 0) ? 0 : ts;
+            zt[k] = reinterpret_cast<const double*>(rec)[(gq * L + 1 + zi / 2) * 2 + (zi & 1)];
+            za[k] = (ts >= 0) ? P.Z[row1 * P.ZS + pc] : 0.0;
+            zb[k] = (ts >= 0) ? P.Z[row2 * P.ZS + pc] : 0.0;
+        }
+        wave_lds_handoff();
+    };
+    issue_draws(0, 0);
+
+    int ib_n = 0, gi_n = 0;                                // block-step whose draws are in flight
+    for (int gi = 0; gi < P.ngen; ++gi) {
+        for (int ib = 0; ib < NB; ++ib) {
+            double delta[NP];
+            bool inb[NP];
+            const double scale = bscale_l[ib];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const double diff = za[k] - zb[k];
+                const double t1 = scale * diff;
+                const double t2 = epsv[k] * zt[k];
+                delta[k] = t1 + t2;
+                inb[k] = tslot[k] >= 0;
+            }
+            const double logu = logu_next;
+            ib_n = (ib + 1 == NB) ? 0 : ib + 1;
+            gi_n = (ib + 1 == NB) ? gi + 1 : gi;
+            issue_draws(gi_n, ib_n);                       // the one past the window is unused
+
+            double xp[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int p = r + L * k;
+                xp[k] = inb[k] ? x[k] + delta[k] : x[k];
+                if (p < D) rvec[gq * DP + p] = xp[k] - muv[k];
+            }
+            wave_lds_handoff();
+            double rj[DP];
+#pragma unroll
+            for (int j = 0; j < DP / 2; ++j) {
+                const double2 t = reinterpret_cast<const double2*>(rvec + gq * DP)[j];
+                rj[2 * j] = t.x;
+                rj[2 * j + 1] = t.y;
+            }
+            double lpp;
+            if constexpr (TARGET == TARGET_MVNORMAL) {
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const int p = r + L * k;
+                    double acc = Wrow[k][0] * rj[0];
+#pragma unroll
+                    for (int j = 1; j < D; ++j) {
+                        const double t = fma(Wrow[k][j], rj[j], acc);
+                        acc = (j <= p) ? t : acc;
+                    }
+                    if (p < D) yvec[gq * DP + p] = acc;
+                }
+                wave_lds_handoff();
+                double q = 0.0;
+#pragma unroll
+                for (int j = 0; j < DP / 2; ++j) {
+                    const double2 t = reinterpret_cast<const double2*>(yvec + gq * DP)[j];
+                    q = (j == 0) ? t.x * t.x : fma(t.x, t.x, q);
+                    if (2 * j + 1 < D) q = fma(t.y, t.y, q);
+                }
+                lpp = fma(-0.5, q, P.tp.c0);
+            } else {
+                double q = 0.0;
+#pragma unroll
+                for (int j = 0; j < D; ++j) q = (j == 0) ? rj[0] * rj[0] : fma(rj[j], rj[j], q);
+                lpp = -q;
+            }
+            double dlt = lpp - lp;
+            if (P.temperature) dlt = dlt / P.temperature[gi];
+            const bool acc = logu < dlt;
+            lp = acc ? lpp : lp;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) x[k] = acc ? xp[k] : x[k];
+            wave_lds_handoff();
+        }
+        const int64_t slot = P.slot_first + gi;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int p = r + L * k;
+            if (P.chain && p < D) P.chain[c + P.N * (p + (int64_t)D * slot)] = x[k];
+        }
+        if (P.chain && r == 0) P.logobj[c + P.N * slot] = lp;
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int p = r + L * k;
+        if (p < D) {
+            P.Xcur[c + P.N * p] = x[k];
+            if (P.do_append) P.Zw[(P.M + c) * P.ZS + p] = x[k];
+        }
+    }
+    if (r == 0) P.lpcur[c] = lp;
+}
+
 }  // namespace demcz

@@ -55,12 +55,14 @@ BLOCKS_D20 = [range(0, 5), range(5, 10), range(10, 15), range(15, 20)]
 @pytest.mark.parametrize("N,d,G,blocks", [(70, 6, 35, BLOCKS_D6), (256, 20, 23, BLOCKS_D20), (64, 20, 21, None),
                                           (33, 10, 30, [range(0, 10)]), (40, 5, 30, [[4, 3, 2, 1, 0]]),
                                           (16, 13, 25, [range(0, 7), range(7, 13)]), (8, 64, 12, None)])
-def test_mvnormal_blocks_and_generic_d_bit_exact(demc, oracle, N, d, G, blocks):
-    """Block updates (C3 layout), permuted single block (not the FULL fast path), runtime-d kernel."""
+@pytest.mark.parametrize("lanes", [1, 0])
+def test_mvnormal_blocks_and_generic_d_bit_exact(demc, oracle, N, d, G, blocks, lanes):
+    """Block updates (C3 layout), permuted single block (not the FULL fast path), runtime-d kernel;
+    in the one-lane layout and in the library's choice (8/16 lanes per chain where built)."""
     w = demc.workloads.mvnormal_problem(d, N)
     bl = blocks or [range(d)]
     mc, Z = demc.demcz_sample(w["target"], w["Zinit"], N, w["K"], G, len(bl), bl, w["eps_scale"], w["gamma"],
-                              verbose=False, seed=5)
+                              verbose=False, seed=5, lanes_per_chain=lanes)
     ref = oracle_sample(oracle, w["target"], w["Zinit"], N, w["K"], G, [list(b) for b in bl], w["eps_scale"], w["gamma"], 5)
     assert np.array_equal(mc.chain, ref["chain"]) and np.array_equal(mc.log_obj, ref["log_obj"]) and np.array_equal(Z, ref["Z"])
 
