@@ -35,7 +35,7 @@ SYMBOLS = [
     "demcz_comm_init", "demcz_export_current_device", "demcz_append_rows_device",
     "demcz_set_external_append", "demcz_get_info", "demcz_selftest_draws", "demcz_append_rows",
     "demcz_rhat_partial", "demcz_set_rng_offset", "demcz_rhat_array", "demcz_accept_ratio_array",
-    "demcz_mean_cov_array",
+    "demcz_mean_cov_array", "demcz_set_append_lag",
 ]
 
 
@@ -115,6 +115,7 @@ def load():
     L.demcz_append_rows.argtypes = [C.c_void_p, _dp, C.c_int64, C.c_int64]
     L.demcz_rhat_partial.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, _dp, _dp]
     L.demcz_set_rng_offset.argtypes = [C.c_void_p, C.c_int64]
+    L.demcz_set_append_lag.argtypes = [C.c_void_p, C.c_int32]
     L.demcz_rhat_array.argtypes = [C.c_int32, _dp, C.c_int64, C.c_int32, C.c_int64, _dp]
     L.demcz_accept_ratio_array.argtypes = [C.c_int32, _dp, C.c_int64, C.c_int64, _dp]
     L.demcz_mean_cov_array.argtypes = [C.c_int32, _dp, C.c_int64, C.c_int32, C.c_int64, _dp, _dp]

@@ -9,6 +9,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <deque>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -70,6 +71,20 @@ struct demcz_handle {
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
     double* d_gather = nullptr;
+    // deferred visibility of appended rows (demcz_set_append_lag): M counts the rows proposals may
+    // draw from, M_app the rows written or reserved; equal when lag == 0
+    int lag = 0;
+    int64_t M_app = 0;
+    struct PendingRows { int64_t visible_from; int64_t M_after; hipEvent_t ev; };
+    std::deque<PendingRows> pending;
+    int64_t batch_J = -1;              // boundary index that closes the batch the last pending entry belongs to
+    // sharded + lag: snapshots of a batch travel together on a side stream
+    hipStream_t comm_stream = nullptr;
+    double* d_send[2] = {nullptr, nullptr};
+    double* d_recv[2] = {nullptr, nullptr};
+    hipEvent_t buf_done[2] = {nullptr, nullptr};
+    int batch_buf = 0, batch_cnt = 0;
+    int64_t batch_base = 0;
 };
 
 #define HIPCHK(h, expr)                                                                          \
@@ -104,6 +119,7 @@ static int64_t blockstep_nblk(int b)
 
 constexpr size_t ML_MAX_DYNAMIC_LDS = 160 * 1024;      // LDS per CU on gfx950
 static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t nobs, int max_blocklen, int nblocks);
+static int32_t flush_exchanges(demcz_handle* h);
 
 extern "C" int32_t demcz_abi_version(void) { return DEMCZ_ABI_VERSION; }
 
@@ -128,6 +144,14 @@ static void free_all(demcz_handle* h)
                     h->dlogu, h->d_gather};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    for (auto& pe : h->pending) if (pe.ev) (void)hipEventDestroy(pe.ev);
+    h->pending.clear();
+    for (int b = 0; b < 2; ++b) {
+        if (h->d_send[b]) (void)hipFree(h->d_send[b]);
+        if (h->d_recv[b]) (void)hipFree(h->d_recv[b]);
+        if (h->buf_done[b]) (void)hipEventDestroy(h->buf_done[b]);
+    }
+    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     if (h->d_stage) (void)hipHostFree(h->d_stage);
     if (h->comm) (void)ncclCommDestroy(h->comm);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -355,6 +379,10 @@ extern "C" int32_t demcz_set_state(demcz_handle* h, const double* X, const doubl
     HIPCHK(h, hipMemcpyAsync(h->dlp_origin, h->dlp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->M = M0;
+    h->M_app = M0;
+    for (auto& pe : h->pending) if (pe.ev) (void)hipEventDestroy(pe.ev);
+    h->pending.clear();
+    h->batch_cnt = 0; h->batch_J = -1;
     h->g_done = h->g0;
     h->origin_valid = true;
     h->has_state = true;
@@ -373,18 +401,21 @@ extern "C" int32_t demcz_get_state(demcz_handle* h, double* X, double* logp, dou
     if (X) HIPCHK(h, hipMemcpyAsync(X, h->dX, (size_t)N * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (logp) HIPCHK(h, hipMemcpyAsync(logp, h->dlp, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (Z) {
-        if (ldZ < h->M) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_get_state: ldZ < M");
-        int32_t rcz = ensure_scratch(h, h->M * d);
+        const int64_t Mall = h->M_app;       // every appended row, visible to proposals yet or not
+        if (ldZ < Mall) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_get_state: ldZ < M");
+        int32_t rcz = flush_exchanges(h);
         if (rcz) return rcz;
-        const int64_t tot = h->M * d;
+        rcz = ensure_scratch(h, Mall * d);
+        if (rcz) return rcz;
+        const int64_t tot = Mall * d;
         hipLaunchKernelGGL(export_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->dZ,
-                           h->ZS, (int64_t)0, h->d_scratch, h->M, h->M, d);
+                           h->ZS, (int64_t)0, h->d_scratch, Mall, Mall, d);
         HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipMemcpy2DAsync(Z, (size_t)ldZ * sizeof(double), h->d_scratch, (size_t)h->M * sizeof(double),
-                                   (size_t)h->M * sizeof(double), (size_t)d, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpy2DAsync(Z, (size_t)ldZ * sizeof(double), h->d_scratch, (size_t)Mall * sizeof(double),
+                                   (size_t)Mall * sizeof(double), (size_t)d, hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (M) *M = h->M;
+    if (M) *M = h->M_app;
     return DEMCZ_OK;
 }
 
@@ -542,20 +573,78 @@ static int32_t launch_window(demcz_handle* h, const WindowParams& P)
     return DEMCZ_OK;
 }
 
+// Synchronous exchange (lag == 0) of a sharded run: all-gather the end-of-window states and
+// scatter them into every replica of the archive; the next window sees them.
 static int32_t append_after_window(demcz_handle* h)
 {
-    // the window kernel did not append (sharded or external): all-gather and scatter
     const int d = h->cfg.d;
     const int64_t N = h->cfg.N;
     if (h->comm) {   // also at nranks == 1, so the collective path is exercised on a one-GPU box
         const int64_t total = N * h->nranks;
-        if (h->M + total > h->cfg.Mcap) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_run: Z capacity exceeded");
+        if (h->M_app + total > h->cfg.Mcap) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_run: Z capacity exceeded");
         NCCLCHK(h, ncclAllGather(h->dX, h->d_gather, (size_t)N * d, ncclDouble, h->comm, h->stream));
         const int64_t tot = total * d;
         hipLaunchKernelGGL(append_gathered_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->dZ,
-                           h->ZS, h->M, h->d_gather, N, h->nranks, d);
+                           h->ZS, h->M_app, h->d_gather, N, h->nranks, d);
         HIPCHK(h, hipGetLastError());
-        h->M += total;
+        h->M_app += total;
+        h->M = h->M_app;
+    }
+    return DEMCZ_OK;
+}
+
+// Deferred exchange (lag E >= 1) of a sharded run: the snapshots of up to E boundaries travel in one
+// all-gather on a side stream while the next windows compute; the rows become visible E windows after
+// the batch closes (see demcz_set_append_lag), by which time the compute stream waits on the event.
+static int32_t exchange_batch(demcz_handle* h)
+{
+    if (h->batch_cnt == 0) return DEMCZ_OK;
+    const int d = h->cfg.d, cnt = h->batch_cnt, buf = h->batch_buf;
+    const int64_t N = h->cfg.N;
+    hipEvent_t ready;
+    HIPCHK(h, hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    HIPCHK(h, hipEventRecord(ready, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->comm_stream, ready, 0));
+    HIPCHK(h, hipEventDestroy(ready));
+    NCCLCHK(h, ncclAllGather(h->d_send[buf], h->d_recv[buf], (size_t)N * d * cnt, ncclDouble, h->comm, h->comm_stream));
+    const int64_t tot = N * d * cnt * h->nranks;
+    hipLaunchKernelGGL(append_batch_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->comm_stream, h->dZ, h->ZS,
+                       h->batch_base, (const double*)h->d_recv[buf], N, h->nranks, cnt, d);
+    HIPCHK(h, hipGetLastError());
+    hipEvent_t done;
+    HIPCHK(h, hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    HIPCHK(h, hipEventRecord(done, h->comm_stream));
+    h->pending.back().ev = done;                       // the entry that covers this batch
+    HIPCHK(h, hipEventRecord(h->buf_done[buf], h->comm_stream));
+    h->batch_cnt = 0;
+    h->batch_buf ^= 1;
+    h->batch_J = -1;                                   // later boundaries of the same batch open a new entry
+    return DEMCZ_OK;
+}
+
+// Rows whose visibility generation has been reached join the part of the archive proposals draw from.
+static int32_t admit_pending(demcz_handle* h, int64_t g)
+{
+    while (!h->pending.empty() && h->pending.front().visible_from <= g) {
+        auto pe = h->pending.front();
+        if (pe.ev) {
+            HIPCHK(h, hipStreamWaitEvent(h->stream, pe.ev, 0));
+            HIPCHK(h, hipEventDestroy(pe.ev));
+        }
+        h->M = pe.M_after;
+        h->pending.pop_front();
+    }
+    return DEMCZ_OK;
+}
+
+// Everything appended so far is in the archive when this returns (used before reading Z back).
+static int32_t flush_exchanges(demcz_handle* h)
+{
+    if (h->comm && h->lag > 0) {
+        int32_t rc = exchange_batch(h);
+        if (rc) return rc;
+        for (auto& pe : h->pending)
+            if (pe.ev) HIPCHK(h, hipStreamWaitEvent(h->stream, pe.ev, 0));
     }
     return DEMCZ_OK;
 }
@@ -579,7 +668,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     {
         const int64_t nb = g_to / K - (g_from - 1) / K;
         const int64_t rows = h->cfg.N * (sharded ? h->nranks : 1);
-        if (!h->external_append && h->M + nb * rows > h->cfg.Mcap)
+        if (!h->external_append && h->M_app + nb * rows > h->cfg.Mcap)
             return fail(h, DEMCZ_ERR_CAPACITY, "demcz_run: Z row capacity (Mcap) would be exceeded");
         if (h->external_append && nb > 1)
             return fail(h, DEMCZ_ERR_STATE, "demcz_run: with external append a call may cross at most one K boundary, at its end");
@@ -606,24 +695,60 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     P.gamma = gamma; P.seed = h->cfg.seed; P.S = h->S; P.Nblocks = h->cfg.Nblocks;
     P.block_offsets = h->d_block_offsets; P.slot_of = h->d_slot_of; P.eps = h->d_eps;
     P.tp = target_params(h);
+    P.snap = nullptr;
+    const int E = h->lag;
     int64_t g = g_from;
     while (g <= g_to) {
         const int64_t next_boundary = ((g - 1) / K + 1) * K;      // first multiple of K that is >= g
         const int64_t w_end = std::min(next_boundary, g_to);
+        int32_t rc = admit_pending(h, g);
+        if (rc) return rc;
         P.M = h->M;
+        P.M_append = h->M_app;
         P.g_first = g + h->rng_offset;      // only positions the Philox streams
         P.ngen = (int32_t)(w_end - g + 1);
         P.slot_first = hist ? (g - h->g0 - 1) : 0;
         P.temperature = temperature ? h->dtemp + (g - g_from) : nullptr;
         const bool boundary = (w_end % K) == 0;
         P.do_append = (boundary && kernel_appends) ? 1 : 0;
-        int32_t rc = launch_window(h, P);
+        P.snap = nullptr;
+        if (boundary && sharded && E > 0) {
+            if (h->batch_cnt == 0) {
+                // the buffer was last read by the exchange two batches ago
+                HIPCHK(h, hipStreamWaitEvent(h->stream, h->buf_done[h->batch_buf], 0));
+                h->batch_base = h->M_app;
+            }
+            P.snap = h->d_send[h->batch_buf] + (size_t)h->batch_cnt * h->cfg.N * h->cfg.d;
+        }
+        rc = launch_window(h, P);
         if (rc) return rc;
-        if (boundary) {
-            if (kernel_appends) h->M += h->cfg.N;
-            else if (sharded) { rc = append_after_window(h); if (rc) return rc; }
+        if (boundary && !h->external_append) {
+            const int64_t rows = h->cfg.N * (sharded ? h->nranks : 1);
+            if (E == 0) {
+                if (kernel_appends) { h->M_app += rows; h->M = h->M_app; }
+                else { rc = append_after_window(h); if (rc) return rc; }
+            } else {
+                // boundary j belongs to the batch closing at J = ceil(j/E)*E; its rows are drawn from
+                // generation (J + E)*K + 1 on -- the same rule on every rank and for any sharding
+                const int64_t j = w_end / K, J = ((j + E - 1) / E) * E;
+                h->M_app += rows;
+                if (h->batch_J != J) {
+                    h->pending.push_back({(J + E) * (int64_t)K + 1, h->M_app, nullptr});
+                    h->batch_J = J;
+                } else {
+                    h->pending.back().M_after = h->M_app;
+                }
+                if (sharded) {
+                    ++h->batch_cnt;
+                    if (j == J) { rc = exchange_batch(h); if (rc) return rc; }
+                }
+            }
         }
         g = w_end + 1;
+    }
+    if (sharded && E > 0) {                 // nothing stays un-exchanged across calls
+        int32_t rc = exchange_batch(h);
+        if (rc) return rc;
     }
     h->g_done = g_to;
     return DEMCZ_OK;
@@ -634,6 +759,7 @@ extern "C" int32_t demcz_synchronize(demcz_handle* h)
     if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
     return DEMCZ_OK;
 }
 
@@ -942,12 +1068,13 @@ extern "C" int32_t demcz_end_generation(demcz_handle* h, int64_t g)
     const bool boundary = (g % h->cfg.K) == 0;
     const bool sharded = (h->comm != nullptr);
     const bool kappend = boundary && !sharded && !h->external_append;
-    if (kappend && h->M + N > h->cfg.Mcap) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_end_generation: Z capacity exceeded");
+    if (h->lag != 0) return fail(h, DEMCZ_ERR_STATE, "demcz_end_generation: the host-closure path runs with append lag 0");
+    if (kappend && h->M_app + N > h->cfg.Mcap) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_end_generation: Z capacity exceeded");
     hipLaunchKernelGGL(end_generation_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, h->stream, N, h->cfg.d, h->dX, h->dlp,
                        hist ? h->dchain : nullptr, hist ? h->dlogobj : nullptr,
                        hist ? (g - h->g0 - 1) : 0, h->dZ, h->ZS, h->M, kappend ? 1 : 0);
     HIPCHK(h, hipGetLastError());
-    if (kappend) h->M += N;
+    if (kappend) { h->M_app += N; h->M = h->M_app; }
     else if (boundary && sharded) { int32_t rc = append_after_window(h); if (rc) return rc; }
     h->gen_open = false;
     h->g_done = g;
@@ -994,13 +1121,15 @@ extern "C" int32_t demcz_append_rows_device(demcz_handle* h, const double* rows_
 {
     if (!h || !rows_device || nrows < 1 || ldrows < nrows) return DEMCZ_ERR_INVALID_ARGUMENT;
     if (!h->has_state) return fail(h, DEMCZ_ERR_STATE, "demcz_append_rows_device: no state");
-    if (h->M + nrows > h->cfg.Mcap) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_append_rows_device: Z capacity exceeded");
+    if (h->M_app + nrows > h->cfg.Mcap) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_append_rows_device: Z capacity exceeded");
+    if (h->lag != 0) return fail(h, DEMCZ_ERR_STATE, "demcz_append_rows_device: caller-driven appends need append lag 0 on the handle");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     const int64_t tot = nrows * h->cfg.d;
-    hipLaunchKernelGGL(append_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->dZ, h->ZS, h->M,
+    hipLaunchKernelGGL(append_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->dZ, h->ZS, h->M_app,
                        rows_device, nrows, ldrows, h->cfg.d);
     HIPCHK(h, hipGetLastError());
-    h->M += nrows;
+    h->M_app += nrows;
+    h->M = h->M_app;
     return DEMCZ_OK;
 }
 
@@ -1008,18 +1137,20 @@ extern "C" int32_t demcz_append_rows(demcz_handle* h, const double* rows, int64_
 {
     if (!h || !rows || nrows < 1 || ldrows < nrows) return DEMCZ_ERR_INVALID_ARGUMENT;
     if (!h->has_state) return fail(h, DEMCZ_ERR_STATE, "demcz_append_rows: no state");
-    if (h->M + nrows > h->cfg.Mcap) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_append_rows: Z capacity exceeded");
+    if (h->M_app + nrows > h->cfg.Mcap) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_append_rows: Z capacity exceeded");
+    if (h->lag != 0) return fail(h, DEMCZ_ERR_STATE, "demcz_append_rows: caller-driven appends need append lag 0 on the handle");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     int32_t rcz = ensure_scratch(h, nrows * h->cfg.d);
     if (rcz) return rcz;
     HIPCHK(h, hipMemcpy2DAsync(h->d_scratch, (size_t)nrows * sizeof(double), rows, (size_t)ldrows * sizeof(double),
                                (size_t)nrows * sizeof(double), (size_t)h->cfg.d, hipMemcpyHostToDevice, h->stream));
     const int64_t tot = nrows * h->cfg.d;
-    hipLaunchKernelGGL(append_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->dZ, h->ZS, h->M,
+    hipLaunchKernelGGL(append_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->dZ, h->ZS, h->M_app,
                        (const double*)h->d_scratch, nrows, nrows, h->cfg.d);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));   // the caller may reuse `rows` on return
-    h->M += nrows;
+    h->M_app += nrows;
+    h->M = h->M_app;
     return DEMCZ_OK;
 }
 
@@ -1027,6 +1158,35 @@ extern "C" int32_t demcz_set_external_append(demcz_handle* h, int32_t enabled)
 {
     if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
     h->external_append = enabled != 0;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_set_append_lag(demcz_handle* h, int32_t batches)
+{
+    if (!h || batches < 0 || batches > 64) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (h->M_app != h->M || !h->pending.empty()) return fail(h, DEMCZ_ERR_STATE, "demcz_set_append_lag: rows are still pending");
+    if (h->external_append && batches) return fail(h, DEMCZ_ERR_STATE, "demcz_set_append_lag: caller-driven appends schedule their own visibility");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    if (h->comm && batches > 0) {
+        // side stream + double-buffered batch slabs: [E][d][n_loc] out, [R][E][d][n_loc] in
+        if (!h->comm_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+        const size_t one = (size_t)h->cfg.N * h->cfg.d * sizeof(double);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+        for (int b = 0; b < 2; ++b) {
+            if (h->d_send[b]) HIPCHK(h, hipFree(h->d_send[b]));
+            if (h->d_recv[b]) HIPCHK(h, hipFree(h->d_recv[b]));
+            h->d_send[b] = h->d_recv[b] = nullptr;
+            HIPCHK(h, hipMalloc((void**)&h->d_send[b], one * batches));
+            HIPCHK(h, hipMalloc((void**)&h->d_recv[b], one * batches * h->nranks));
+            if (!h->buf_done[b]) {
+                HIPCHK(h, hipEventCreateWithFlags(&h->buf_done[b], hipEventDisableTiming));
+                HIPCHK(h, hipEventRecord(h->buf_done[b], h->comm_stream));
+            }
+        }
+    }
+    h->lag = batches;
+    h->batch_cnt = 0; h->batch_buf = 0; h->batch_J = -1;
     return DEMCZ_OK;
 }
 
@@ -1105,7 +1265,7 @@ extern "C" int32_t demcz_mean_cov_array(int32_t device_id, const double* chain, 
 extern "C" int32_t demcz_get_info(const demcz_handle* h, int64_t* M, int64_t* launches_window, int32_t* lanes_per_chain)
 {
     if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
-    if (M) *M = h->M;
+    if (M) *M = h->M_app;
     if (launches_window) *launches_window = h->launches;
     if (lanes_per_chain) *lanes_per_chain = h->lanes;
     return DEMCZ_OK;

@@ -58,7 +58,9 @@ struct WindowParams {
     uint64_t seed;
     int64_t S;               // Philox blocks per generation
     int32_t Nblocks;
-    int32_t do_append;       // window ends on a K multiple and the kernel appends rows M + ic
+    int32_t do_append;       // window ends on a K multiple and the kernel appends rows M_append + ic
+    int64_t M_append;        // first free archive row (== M unless appended rows become visible later)
+    double* snap;            // sharded runs with deferred exchange: end-of-window states, N x d (ld N)
     const int32_t* block_offsets;
     const int32_t* slot_of;  // Nblocks x d: position of parameter p inside block ib, or -1
     const double* eps;
@@ -257,7 +259,11 @@ __global__ void __launch_bounds__(WINDOW_BS, DEMCZ_AB_WPE) window_kernel(const W
 #pragma unroll
     for (int p = 0; p < D; ++p) P.Xcur[c + P.N * p] = x[p];
     P.lpcur[c] = lp;
-    if (P.do_append) store_row<D>(P.Zw + (P.M + c) * P.ZS, x);
+    if (P.do_append) store_row<D>(P.Zw + (P.M_append + c) * P.ZS, x);
+    if (P.snap) {
+#pragma unroll
+        for (int p = 0; p < D; ++p) P.snap[c + P.N * p] = x[p];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -332,7 +338,8 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel_generic(const WindowP
     for (int p = 0; p < d; ++p) {
         double xv = xs[p * WINDOW_BS + tid];
         P.Xcur[c + P.N * p] = xv;
-        if (P.do_append) P.Zw[(P.M + c) * P.ZS + p] = xv;
+        if (P.do_append) P.Zw[(P.M_append + c) * P.ZS + p] = xv;
+        if (P.snap) P.snap[c + P.N * p] = xv;
     }
     P.lpcur[c] = lp;
 }
@@ -375,6 +382,17 @@ __global__ void append_gathered_kernel(double* Z, int64_t ZS, int64_t M, const d
     if (i >= per * R) return;
     const int64_t r = i / per, rem = i % per, p = rem / n_loc, j = rem % n_loc;
     Z[(M + r * n_loc + j) * ZS + p] = slab[i];
+}
+
+// All-gather slab of a BATCH of cnt boundaries: [R][cnt][d][n_loc] -> archive rows
+// base + (s*R + r)*n_loc + j (boundary-major, then rank: the order an unsharded run appends in).
+__global__ void append_batch_kernel(double* Z, int64_t ZS, int64_t base, const double* slab, int64_t n_loc, int R, int cnt, int d)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per = n_loc * d;
+    if (i >= per * cnt * R) return;
+    const int64_t r = i / (per * cnt), rem = i % (per * cnt), sidx = rem / per, rem2 = rem % per, p = rem2 / n_loc, j = rem2 % n_loc;
+    Z[(base + (sidx * R + r) * n_loc + j) * ZS + p] = slab[i];
 }
 
 // ------------------------------------------------------------------------------------------------

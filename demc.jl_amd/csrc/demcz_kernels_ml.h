@@ -317,7 +317,8 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
         const int p = r + L * k;
         if (p < D && active) {
             P.Xcur[c + P.N * p] = x[k];
-            if (P.do_append) P.Zw[(P.M + c) * P.ZS + p] = x[k];
+            if (P.do_append) P.Zw[(P.M_append + c) * P.ZS + p] = x[k];
+            if (P.snap) P.snap[c + P.N * p] = x[k];
         }
     }
     if (r == 0 && active) P.lpcur[c] = lp;
@@ -511,7 +512,8 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
         const int p = r + L * k;
         if (p < D) {
             P.Xcur[c + P.N * p] = x[k];
-            if (P.do_append) P.Zw[(P.M + c) * P.ZS + p] = x[k];
+            if (P.do_append) P.Zw[(P.M_append + c) * P.ZS + p] = x[k];
+            if (P.snap) P.snap[c + P.N * p] = x[k];
         }
     }
     if (r == 0) P.lpcur[c] = lp;

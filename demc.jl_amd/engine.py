@@ -114,6 +114,9 @@ class HipEngine:
         self._chk(self._L.demcz_get_info(self._h, C.byref(M), C.byref(nl), C.byref(lanes)))
         return dict(M=int(M.value), window_launches=int(nl.value), lanes_per_chain=int(lanes.value))
 
+    def set_append_lag(self, batches):
+        self._chk(self._L.demcz_set_append_lag(self._h, int(batches)))
+
     def set_rng_offset(self, generations):
         self._chk(self._L.demcz_set_rng_offset(self._h, int(generations)))
 

@@ -121,6 +121,7 @@ class Sharding:
     world_size: int = 1
     mode: str = "host"
     local_shards: int = 1
+    host_exchange_always: bool = False          # drive appends from the host even with one shard
     all_gather: Optional[Callable] = None       # np.ndarray -> list of np.ndarray, one per rank
     all_reduce_sum: Optional[Callable] = None   # np.ndarray -> np.ndarray
     broadcast_bytes: Optional[Callable] = None  # (bytes or None, src=0) -> bytes
@@ -133,15 +134,21 @@ class Sharding:
 class _Runner:
     """The engines of this process plus the exchange between shards."""
 
-    def __init__(self, engines, sharding: Optional[Sharding], K, N_total, d):
+    def __init__(self, engines, sharding: Optional[Sharding], K, N_total, d, append_lag=0):
         self.engines = engines
         self.sh = sharding
         self.K, self.N_total, self.d = K, N_total, d
+        self.lag = int(append_lag)
+        self.pending = []           # host exchange with lag: (visible_from_generation, rows)
         self.lib_exchange = sharding is not None and sharding.mode == "rccl" and sharding.world_size > 1
-        self.host_exchange = sharding is not None and not self.lib_exchange and sharding.total_shards > 1
+        self.host_exchange = sharding is not None and not self.lib_exchange and (
+            sharding.total_shards > 1 or sharding.host_exchange_always)
         if self.host_exchange:
             for e in engines:
                 e.set_external_append(True)
+        elif self.lag:
+            for e in engines:
+                e.set_append_lag(self.lag)      # the library applies the same visibility rule
 
     # generation loop --------------------------------------------------------------------------
     def run(self, g_from, g_to, gamma, temperature=None):
@@ -152,6 +159,7 @@ class _Runner:
         g = g_from
         while g <= g_to:
             w_end = min(((g - 1) // self.K + 1) * self.K, g_to)
+            self._admit(g)
             t = None if temperature is None else temperature[g - g_from:w_end - g_from + 1]
             for e in self.engines:
                 e.run(g, w_end, gamma, t)
@@ -160,9 +168,26 @@ class _Runner:
                 if self.sh.world_size > 1:
                     rows = np.concatenate(self.sh.all_gather(np.ascontiguousarray(rows)), axis=0)
                 rows = np.asfortranarray(rows)
-                for e in self.engines:
-                    e.append_rows(rows)
+                if self.lag == 0:
+                    for e in self.engines:
+                        e.append_rows(rows)
+                else:
+                    # demcz_set_append_lag's rule: boundary j's batch closes at J = ceil(j/E)*E and its
+                    # rows are drawn from generation (J + E)*K + 1 on
+                    j = w_end // self.K
+                    J = -(-j // self.lag) * self.lag
+                    self.pending.append(((J + self.lag) * self.K + 1, rows))
             g = w_end + 1
+
+    def _admit(self, g):
+        while self.pending and self.pending[0][0] <= g:
+            rows = self.pending.pop(0)[1]
+            for e in self.engines:
+                e.append_rows(rows)
+
+    def flush(self):
+        """Every appended row is in the archive afterwards (end of a run)."""
+        self._admit(float("inf"))
 
     # statistics -------------------------------------------------------------------------------
     def _allsum(self, a):
@@ -206,6 +231,7 @@ class _Runner:
         return chain, lobj
 
     def state(self):
+        self.flush()
         sts = [e.get_state(with_Z=(i == 0)) for i, e in enumerate(self.engines)]
         X = np.asfortranarray(np.concatenate([s[0] for s in sts], axis=0))
         lp = np.concatenate([s[1] for s in sts])
@@ -221,7 +247,7 @@ class _Runner:
 
 
 def make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp, *, seed, sharding, device_id,
-                 engine_factory, lanes_per_chain, stream, rng_offset=0):
+                 engine_factory, lanes_per_chain, stream, rng_offset=0, append_lag=0):
     M0, d = Zmat.shape
     if M0 < 2:
         raise ValueError("Zmat needs at least 2 rows (two distinct archive rows per proposal, demcz.jl:176-179)")
@@ -248,7 +274,7 @@ def make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp,
         uid = engines[0].comm_unique_id() if sh.rank == 0 else None
         uid = sh.broadcast_bytes(uid)
         engines[0].comm_init(uid, sh.world_size, sh.rank)
-    return _Runner(engines, sh, K, N, d)
+    return _Runner(engines, sh, K, N, d, append_lag=append_lag)
 
 
 def initial_state(logobj, Zmat, N, Ngeneration, K, prevrun, init):
@@ -329,7 +355,8 @@ def print_status_anneal(runner, ig):
 def demcz_sample(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockindex=None, eps_scale=None, γ=2.38, *,
                  prevrun=None, verbose=True, print_step=100, autostop="no", autostop_Rhat=1.01,
                  autostop_every=1000, seed=0, init="last_rows", padded_Z=False, sharding=None, device_id=0,
-                 lanes_per_chain=0, stream=None, engine_factory=None, return_runner=False, rng_offset=None):
+                 lanes_per_chain=0, stream=None, engine_factory=None, return_runner=False, rng_offset=None,
+                 append_lag=0):
     """Serial-driver surface of src/demcz.jl: pass a ``DEMCopt`` as the third argument
     (``demcz_sample(logobj, Zmat, opts; prevrun)``, :1-3) or the positional arguments with
     the positional method's defaults (:9).  Returns ``(mc, Z)``."""
@@ -352,7 +379,7 @@ def demcz_sample(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
         rng_offset = 0 if prevrun is None else prevrun.chain.shape[2]
     runner = make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp, seed=seed,
                           sharding=sharding, device_id=device_id, engine_factory=engine_factory,
-                          lanes_per_chain=lanes_per_chain, stream=stream, rng_offset=rng_offset)
+                          lanes_per_chain=lanes_per_chain, stream=stream, rng_offset=rng_offset, append_lag=append_lag)
     Mcap = M0 + int(math.ceil(N * Ngeneration / K))
     try:
         if verbose:
@@ -390,7 +417,7 @@ def demcz_sample(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
 def demcz_anneal(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockindex=None, eps_scale=None, γ=2.38, *,
                  prevrun=None, verbose=True, print_step=100, temperaturefun=tempbaseline, T0=3, TN=0.0,
                  adaptγ=None, seed=0, init="last_rows", padded_Z=False, compat_serial_temp=False, sharding=None,
-                 device_id=0, lanes_per_chain=0, stream=None, engine_factory=None, rng_offset=None):
+                 device_id=0, lanes_per_chain=0, stream=None, engine_factory=None, rng_offset=None, append_lag=0):
     """Simulated-annealing variant, src/demcz_anneal.jl:14-65: tempered accept
     ``log(u) < (lp' - lp)/T(ig)`` (:172-178), ``T(ig) = temperaturefun(ig, Ngeneration, T0, TN)``,
     gamma adapted from the windowed acceptance ratio every ``adapt_every`` generations (:48-57).
@@ -415,7 +442,7 @@ def demcz_anneal(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
         rng_offset = 0 if prevrun is None else prevrun.chain.shape[2]
     runner = make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp, seed=seed,
                           sharding=sharding, device_id=device_id, engine_factory=engine_factory,
-                          lanes_per_chain=lanes_per_chain, stream=stream, rng_offset=rng_offset)
+                          lanes_per_chain=lanes_per_chain, stream=stream, rng_offset=rng_offset, append_lag=append_lag)
     Mcap = M0 + int(math.ceil(N * Ngeneration / K))
 
     def temp(ig):

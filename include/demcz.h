@@ -184,6 +184,17 @@ int32_t demcz_append_rows(demcz_handle* h, const double* rows, int64_t nrows, in
  * caller (demcz_export_current_device + host collective + demcz_append_rows_device). */
 int32_t demcz_set_external_append(demcz_handle* h, int32_t enabled);
 
+/* Deferred visibility of appended rows.  E = 0 (default): the rows appended after generation j*K are
+ * drawn from in generation j*K + 1 already -- the reference's schedule with all chains of a
+ * generation updated against the same archive.  E >= 1: boundaries are grouped in batches of E
+ * (batch of boundary j closes at J = ceil(j/E)*E) and a batch's rows are drawn from generation
+ * (J + E)*K + 1 on.  On a sharded handle the batch travels in ONE all-gather on a side stream while
+ * the next E windows compute, so the latency-bound collective is off the critical path; on an
+ * unsharded handle the same rule is applied so results do not depend on the sharding.  Any past
+ * state is a legitimate DEMCz archive row (ter Braak & Vrugt 2008); this changes WHEN a row becomes
+ * eligible, not the target distribution.  Call after demcz_comm_init, before demcz_run. */
+int32_t demcz_set_append_lag(demcz_handle* h, int32_t batches);
+
 /* Resume: the chains' Philox streams have already been advanced by `generations` generations (the
  * length of a previous run, demcz.jl:18-22): generation g of this handle draws what generation
  * generations+g of an uninterrupted run would draw.  K boundaries still follow this handle's own g,
