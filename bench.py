@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--dim", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lanes-per-chain", type=int, default=0)
+    ap.add_argument("--append-lag", type=int, default=-1,
+                    help="demcz_set_append_lag batches; default 0 on one GPU (the reference's schedule), 3 when sharded "
+                         "(the K-boundary all-gather overlaps the next windows)")
     args = ap.parse_args()
 
     import torch
@@ -108,6 +111,7 @@ def main():
         from demc_jl_amd.dist import torch_sharding
         sharding = torch_sharding(mode="rccl")
 
+    lag = args.append_lag if args.append_lag >= 0 else (0 if world == 1 else 3)
     d, K, n_loc = args.dim, 10, args.chains_per_gpu
     N = n_loc * world
     W, S = args.warmup, args.steps
@@ -118,7 +122,7 @@ def main():
     X, logp = demc.initial_state(w["target"], w["Zinit"], N, G, K, None, "last_rows")
     runner = demc.make_runner(w["target"], w["Zinit"], N, K, G, [range(d)], w["eps_scale"], X, logp, seed=seed,
                               sharding=sharding, device_id=local_rank, engine_factory=None,
-                              lanes_per_chain=args.lanes_per_chain, stream=stream.cuda_stream)
+                              lanes_per_chain=args.lanes_per_chain, stream=stream.cuda_stream, append_lag=lag)
     eng = runner.engines[0]
     gens_to_rhat = None
     rhat_trace = []
@@ -185,7 +189,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"C2: MvNormal d={d} correlated Sigma, N={n_loc} chains/GPU x {world} GPU, K={K}, "
                                    f"gamma=2.38, eps=1e-5, full-history + Z append + split-Rhat every {every}",
-                       "chains_total": N, "dim": d, "K": K, "lanes_per_chain": eng.info()["lanes_per_chain"],
+                       "chains_total": N, "dim": d, "K": K, "lanes_per_chain": eng.info()["lanes_per_chain"], "append_lag": lag,
                        "parallelism": f"chains sharded x{world}, Z replicated" if world > 1 else "single GPU"},
             "gens_to_rhat_1p05": gens_to_rhat, "rhat_trace": rhat_trace[-12:], "accept_ratio_mean": acc,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,

@@ -20,6 +20,8 @@
 
 #include "demcz_kernels.h"
 
+#include <type_traits>
+
 #pragma clang fp contract(off)
 
 namespace demcz {
@@ -179,11 +181,13 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
     };
     issue_draws(0);
 
-    for (int gi = 0; gi < P.ngen; ++gi) {
+    // One generation; PREFETCH issues the next generation's draws in the middle of it.  The last
+    // generation of the window is a second instantiation without the prefetch (nothing to draw for).
+    auto generation = [&](int gi, auto prefetch) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) { za_c[k] = za[k]; zb_c[k] = zb[k]; zt_c[k] = zt[k]; }
         const double logu = logu_next;
-        issue_draws(gi + 1);     // the one past the window is unused (kept to stay branch-free)
+        if constexpr (decltype(prefetch)::value) issue_draws(gi + 1);
         double delta[NP];
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -311,7 +315,9 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
         }
         if (P.chain && r == 0 && active) P.logobj[c + P.N * slot] = lp;
         wave_lds_handoff();      // rvec / yvec are rewritten by the next generation
-    }
+    };
+    for (int gi = 0; gi + 1 < P.ngen; ++gi) generation(gi, std::true_type{});
+    generation(P.ngen - 1, std::false_type{});
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int p = r + L * k;
