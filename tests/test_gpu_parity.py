@@ -281,3 +281,54 @@ def test_utils_mirror_reference_postprocessing(demc, oracle, tmp_path):
     prev, Zc, done, seed = demc.load_checkpoint(tmp_path / "ck.npz")
     res, Zres = demc.demcz_sample(w["target"], Zc, *args, prevrun=prev, rng_offset=done, verbose=False, seed=seed)
     assert np.array_equal(res.chain[:, :, 1:], one.chain[:, :, G:]) and np.array_equal(Zres, Zone)
+
+
+@pytest.mark.parametrize("case", ["d1", "K1", "N1", "M0_2", "nobs5", "nobs17", "eps0", "single_param_blocks"])
+def test_edge_cases_bit_exact(demc, oracle, case):
+    """Smallest / degenerate shapes: d = 1 (unscaled gamma and ONE scalar normal, demcz.jl:183-184),
+    K = 1 (append after every generation), one chain, two archive rows (the minimum for two distinct
+    draws, demcz.jl:176-179), fewer observations than SSE partials, zero jitter, all blocks of size 1."""
+    kw = dict(verbose=False, seed=77)
+    if case == "d1":
+        w = demc.workloads.mvnormal_problem(1, 9); N, K, G, blocks = 9, 10, 40, [range(1)]
+    elif case == "K1":
+        w = demc.workloads.mvnormal_problem(5, 12); N, K, G, blocks = 12, 1, 25, [range(5)]
+    elif case == "N1":
+        w = demc.workloads.mvnormal_problem(3, 1); N, K, G, blocks = 1, 10, 60, [range(3)]
+    elif case == "M0_2":
+        w = demc.workloads.mvnormal_problem(4, 2); w["Zinit"] = np.asfortranarray(w["Zinit"][:2]); N, K, G, blocks = 2, 10, 35, [range(4)]
+    elif case in ("nobs5", "nobs17"):
+        w = demc.workloads.linreg_problem(10, 8, nobs=5 if case == "nobs5" else 17); N, K, G, blocks = 8, 10, 30, [range(10)]
+    elif case == "eps0":
+        w = demc.workloads.mvnormal_problem(5, 16); w["eps_scale"] = np.zeros(5); N, K, G, blocks = 16, 10, 30, [range(5)]
+    else:
+        w = demc.workloads.mvnormal_problem(5, 10); N, K, G, blocks = 10, 10, 30, [[3], [0], [4], [1], [2]]
+    mc, Z = demc.demcz_sample(w["target"], w["Zinit"], N, K, G, len(blocks), blocks, w["eps_scale"], w["gamma"], **kw)
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, [list(b) for b in blocks], w["eps_scale"], w["gamma"], 77)
+    assert np.array_equal(mc.chain, ref["chain"]) and np.array_equal(mc.log_obj, ref["log_obj"]) and np.array_equal(Z, ref["Z"])
+    assert Z.shape[0] == w["Zinit"].shape[0] + N * (G // K)
+
+
+def test_no_history_handle_and_closure_anneal(demc, oracle):
+    """Gcap = 0 (states and archive only, e.g. burn-in): same final state; and an annealed Python
+    closure through the host-closure path equals the device target."""
+    d, N, G = 5, 40, 37
+    w = demc.workloads.mvnormal_problem(d, N)
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, 10, G, None, w["eps_scale"], 2.38, 4)
+    e = demc.HipEngine(N=N, d=d, K=10, Mcap=w["Zinit"].shape[0] + N * 4, Gcap=0, blockindex=[range(d)], eps_scale=w["eps_scale"],
+                       seed=4, target=w["target"])
+    e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+    e.run(1, G, 2.38)
+    X, lp, Z, M = e.get_state()
+    assert np.array_equal(X, ref["X"]) and np.array_equal(lp, ref["logp"]) and np.array_equal(Z, ref["Z"])
+    with pytest.raises(demc.DemczError):
+        e.get_history(1, G)
+    e.close()
+    w = demc.workloads.iso_quad_problem(10, 12)
+    prob = oracle.Problem(1, 10, 10, 10, w["eps_scale"], 0, target=w["target"].oracle_spec())
+    closure = lambda x: float(oracle.logp(prob, x[None, :])[0])      # noqa: E731
+    args = (w["Zinit"], 12, 10, 30, 1, [range(10)], w["eps_scale"], 2.38)
+    kw = dict(verbose=False, T0=2, TN=1e-2, seed=8, adaptγ={"adapt_every": 10})
+    a, Za = demc.demcz_anneal(closure, *args, **kw)
+    b, Zb = demc.demcz_anneal(w["target"], *args, **kw)
+    assert np.array_equal(a.chain, b.chain) and np.array_equal(Za, Zb)
