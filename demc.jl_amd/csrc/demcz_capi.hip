@@ -696,23 +696,32 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     P.block_offsets = h->d_block_offsets; P.slot_of = h->d_slot_of; P.eps = h->d_eps;
     P.tp = target_params(h);
     P.snap = nullptr;
+    P.K = K;
     const int E = h->lag;
     int64_t g = g_from;
     while (g <= g_to) {
         const int64_t next_boundary = ((g - 1) / K + 1) * K;      // first multiple of K that is >= g
-        const int64_t w_end = std::min(next_boundary, g_to);
+        // Synchronous schedule: a launch ends at the next K boundary, the kernel boundary is the
+        // grid-wide barrier before the new rows are drawn from.  Deferred schedule: nothing appended
+        // inside a batch becomes visible inside it, so one launch covers the rest of the batch.
+        int64_t w_end = std::min(next_boundary, g_to);
+        if (E > 0 && !h->external_append) {
+            const int64_t jn = next_boundary / K, J = ((jn + E - 1) / E) * E;
+            w_end = std::min(J * (int64_t)K, g_to);
+        }
         int32_t rc = admit_pending(h, g);
         if (rc) return rc;
+        const int64_t nbound = w_end / K - (g - 1) / K;           // boundaries inside this launch
         P.M = h->M;
         P.M_append = h->M_app;
         P.g_first = g + h->rng_offset;      // only positions the Philox streams
         P.ngen = (int32_t)(w_end - g + 1);
+        P.to_boundary = (int32_t)(next_boundary - g + 1);
         P.slot_first = hist ? (g - h->g0 - 1) : 0;
         P.temperature = temperature ? h->dtemp + (g - g_from) : nullptr;
-        const bool boundary = (w_end % K) == 0;
-        P.do_append = (boundary && kernel_appends) ? 1 : 0;
+        P.do_append = (nbound > 0 && kernel_appends) ? 1 : 0;
         P.snap = nullptr;
-        if (boundary && sharded && E > 0) {
+        if (nbound > 0 && sharded && E > 0) {
             if (h->batch_cnt == 0) {
                 // the buffer was last read by the exchange two batches ago
                 HIPCHK(h, hipStreamWaitEvent(h->stream, h->buf_done[h->batch_buf], 0));
@@ -722,7 +731,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         }
         rc = launch_window(h, P);
         if (rc) return rc;
-        if (boundary && !h->external_append) {
+        if (nbound > 0 && !h->external_append) {
             const int64_t rows = h->cfg.N * (sharded ? h->nranks : 1);
             if (E == 0) {
                 if (kernel_appends) { h->M_app += rows; h->M = h->M_app; }
@@ -730,17 +739,19 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
             } else {
                 // boundary j belongs to the batch closing at J = ceil(j/E)*E; its rows are drawn from
                 // generation (J + E)*K + 1 on -- the same rule on every rank and for any sharding
-                const int64_t j = w_end / K, J = ((j + E - 1) / E) * E;
-                h->M_app += rows;
-                if (h->batch_J != J) {
-                    h->pending.push_back({(J + E) * (int64_t)K + 1, h->M_app, nullptr});
-                    h->batch_J = J;
-                } else {
-                    h->pending.back().M_after = h->M_app;
-                }
-                if (sharded) {
-                    ++h->batch_cnt;
-                    if (j == J) { rc = exchange_batch(h); if (rc) return rc; }
+                for (int64_t j = (g - 1) / K + 1; j <= w_end / K; ++j) {
+                    const int64_t J = ((j + E - 1) / E) * E;
+                    h->M_app += rows;
+                    if (h->batch_J != J) {
+                        h->pending.push_back({(J + E) * (int64_t)K + 1, h->M_app, nullptr});
+                        h->batch_J = J;
+                    } else {
+                        h->pending.back().M_after = h->M_app;
+                    }
+                    if (sharded) {
+                        ++h->batch_cnt;
+                        if (j == J) { rc = exchange_batch(h); if (rc) return rc; }
+                    }
                 }
             }
         }

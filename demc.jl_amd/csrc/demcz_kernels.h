@@ -58,9 +58,11 @@ struct WindowParams {
     uint64_t seed;
     int64_t S;               // Philox blocks per generation
     int32_t Nblocks;
-    int32_t do_append;       // window ends on a K multiple and the kernel appends rows M_append + ic
+    int32_t do_append;       // at every K boundary inside the launch the kernel appends rows M_append + b*N + ic
     int64_t M_append;        // first free archive row (== M unless appended rows become visible later)
-    double* snap;            // sharded runs with deferred exchange: end-of-window states, N x d (ld N)
+    double* snap;            // sharded runs with deferred exchange: boundary states, one N x d (ld N) slab per boundary
+    int32_t K;
+    int32_t to_boundary;     // generations from the first one of the launch to the next K boundary (1 = the first one is it)
     const int32_t* block_offsets;
     const int32_t* slot_of;  // Nblocks x d: position of parameter p inside block ib, or -1
     const double* eps;
@@ -181,6 +183,8 @@ __global__ void __launch_bounds__(WINDOW_BS, DEMCZ_AB_WPE) window_kernel(const W
 
     rng_state st;
     rng_seek(st, P.seed, (uint64_t)(P.chain_id0 + c), (uint64_t)(P.g_first - 1) * (uint64_t)P.S);
+    int to_b = P.to_boundary;            // countdown to the next K boundary
+    int64_t nb = 0;                      // boundaries passed inside this launch
 
     for (int gi = 0; gi < P.ngen; ++gi) {
         const int nblocks = FULL ? 1 : P.Nblocks;
@@ -255,15 +259,19 @@ __global__ void __launch_bounds__(WINDOW_BS, DEMCZ_AB_WPE) window_kernel(const W
             for (int p = 0; p < D; ++p) P.chain[c + P.N * (p + (int64_t)D * slot)] = x[p];
             P.logobj[c + P.N * slot] = lp;
         }
+        if (--to_b == 0) {                  // generation divisible by K: runchain!'s append, demcz.jl:88-91
+            to_b = P.K;
+            if (P.do_append) store_row<D>(P.Zw + (P.M_append + nb * P.N + c) * P.ZS, x);
+            if (P.snap) {
+#pragma unroll
+                for (int p = 0; p < D; ++p) P.snap[nb * P.N * D + c + P.N * p] = x[p];
+            }
+            ++nb;
+        }
     }
 #pragma unroll
     for (int p = 0; p < D; ++p) P.Xcur[c + P.N * p] = x[p];
     P.lpcur[c] = lp;
-    if (P.do_append) store_row<D>(P.Zw + (P.M_append + c) * P.ZS, x);
-    if (P.snap) {
-#pragma unroll
-        for (int p = 0; p < D; ++p) P.snap[c + P.N * p] = x[p];
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -286,6 +294,8 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel_generic(const WindowP
     double lp = P.lpcur[c];
     rng_state st;
     rng_seek(st, P.seed, (uint64_t)(P.chain_id0 + c), (uint64_t)(P.g_first - 1) * (uint64_t)P.S);
+    int to_b = P.to_boundary;            // countdown to the next K boundary
+    int64_t nb = 0;                      // boundaries passed inside this launch
 
     for (int gi = 0; gi < P.ngen; ++gi) {
         for (int ib = 0; ib < P.Nblocks; ++ib) {
@@ -334,13 +344,17 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel_generic(const WindowP
             for (int p = 0; p < d; ++p) P.chain[c + P.N * (p + (int64_t)d * slot)] = xs[p * WINDOW_BS + tid];
             P.logobj[c + P.N * slot] = lp;
         }
+        if (--to_b == 0) {
+            to_b = P.K;
+            for (int p = 0; p < d; ++p) {
+                const double xv = xs[p * WINDOW_BS + tid];
+                if (P.do_append) P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p] = xv;
+                if (P.snap) P.snap[nb * P.N * d + c + P.N * p] = xv;
+            }
+            ++nb;
+        }
     }
-    for (int p = 0; p < d; ++p) {
-        double xv = xs[p * WINDOW_BS + tid];
-        P.Xcur[c + P.N * p] = xv;
-        if (P.do_append) P.Zw[(P.M_append + c) * P.ZS + p] = xv;
-        if (P.snap) P.snap[c + P.N * p] = xv;
-    }
+    for (int p = 0; p < d; ++p) P.Xcur[c + P.N * p] = xs[p * WINDOW_BS + tid];
     P.lpcur[c] = lp;
 }
 

@@ -147,6 +147,8 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
     // the gather's L2 / Infinity-Cache / HBM latency hides behind a whole generation of work.
     double za[NP], zb[NP], zt[NP], logu_next;
     double za_c[NP], zb_c[NP], zt_c[NP];
+    int to_b = P.to_boundary;            // countdown to the next K boundary
+    int64_t nb = 0;                      // boundaries passed inside this launch
     auto issue_draws = [&](int gi) {
         uint64_t r1, r2, i1, i2;
         rng.block(P.seed, chain, (uint64_t)(P.g_first + gi - 1) * (uint64_t)S + (uint64_t)role, r1, r2);
@@ -314,6 +316,18 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
             if (P.chain && p < D && active) P.chain[c + P.N * (p + (int64_t)D * slot)] = x[k];
         }
         if (P.chain && r == 0 && active) P.logobj[c + P.N * slot] = lp;
+        if (--to_b == 0) {                  // generation divisible by K: runchain!'s append, demcz.jl:88-91
+            to_b = P.K;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int p = r + L * k;
+                if (p < D && active) {
+                    if (P.do_append) P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p] = x[k];
+                    if (P.snap) P.snap[nb * P.N * D + c + P.N * p] = x[k];
+                }
+            }
+            ++nb;
+        }
         wave_lds_handoff();      // rvec / yvec are rewritten by the next generation
     };
     for (int gi = 0; gi + 1 < P.ngen; ++gi) generation(gi, std::true_type{});
@@ -321,11 +335,7 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int p = r + L * k;
-        if (p < D && active) {
-            P.Xcur[c + P.N * p] = x[k];
-            if (P.do_append) P.Zw[(P.M_append + c) * P.ZS + p] = x[k];
-            if (P.snap) P.snap[c + P.N * p] = x[k];
-        }
+        if (p < D && active) P.Xcur[c + P.N * p] = x[k];
     }
     if (r == 0 && active) P.lpcur[c] = lp;
 }
@@ -436,6 +446,8 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
     issue_draws(0, 0);
 
     int ib_n = 0, gi_n = 0;                                // block-step whose draws are in flight
+    int to_b = P.to_boundary;
+    int64_t nb = 0;
     for (int gi = 0; gi < P.ngen; ++gi) {
         for (int ib = 0; ib < NB; ++ib) {
             double delta[NP];
@@ -512,15 +524,23 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
             if (P.chain && p < D) P.chain[c + P.N * (p + (int64_t)D * slot)] = x[k];
         }
         if (P.chain && r == 0) P.logobj[c + P.N * slot] = lp;
+        if (--to_b == 0) {
+            to_b = P.K;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int p = r + L * k;
+                if (p < D) {
+                    if (P.do_append) P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p] = x[k];
+                    if (P.snap) P.snap[nb * P.N * D + c + P.N * p] = x[k];
+                }
+            }
+            ++nb;
+        }
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int p = r + L * k;
-        if (p < D) {
-            P.Xcur[c + P.N * p] = x[k];
-            if (P.do_append) P.Zw[(P.M_append + c) * P.ZS + p] = x[k];
-            if (P.snap) P.snap[c + P.N * p] = x[k];
-        }
+        if (p < D) P.Xcur[c + P.N * p] = x[k];
     }
     if (r == 0) P.lpcur[c] = lp;
 }
