@@ -50,6 +50,26 @@ def measured_traffic(n_loc, d, lanes):
     return None
 
 
+def throughput_point(demc, N, d, K, seed, gens, device_id):
+    """One point of the chain-count sweep (not the headline): the same generation loop at N chains,
+    history and appends included, to show where the path leaves the latency regime."""
+    w = demc.workloads.mvnormal_problem(d, N)
+    M0 = w["Zinit"].shape[0]
+    e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (2 * gens // K + 1), Gcap=2 * gens, blockindex=[range(d)],
+                       eps_scale=w["eps_scale"], seed=seed, target=w["target"], device_id=device_id)
+    e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+    e.run(1, gens, w["gamma"])
+    e.synchronize()
+    t0 = time.perf_counter()
+    e.run(gens + 1, 2 * gens, w["gamma"])
+    e.synchronize()
+    dt = time.perf_counter() - t0
+    lanes = e.info()["lanes_per_chain"]
+    e.close()
+    gbs = N * gens / dt * algorithmic_bytes_per_update(d, K) / 1e9
+    return {"chains": N, "lanes_per_chain": lanes, "value": N * gens / dt, "achieved_GBps": gbs, "frac_of_8TBps": gbs / 8000.0}
+
+
 def cpu_baseline(w, N, d, K, seed, budget_updates):
     """Time the oracle (test infrastructure, used here only as the reported CPU baseline)."""
     sys.path.insert(0, str(ROOT / "oracle"))
@@ -84,6 +104,7 @@ def main():
     ap.add_argument("--chains-per-gpu", type=int, default=1024)
     ap.add_argument("--dim", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the chain-count sweep object")
     ap.add_argument("--lanes-per-chain", type=int, default=0)
     ap.add_argument("--append-lag", type=int, default=-1,
                     help="demcz_set_append_lag batches; default 0 on one GPU (the reference's schedule), 3 when sharded "
@@ -197,6 +218,12 @@ def main():
                          "avg_launch_us": avg_launch_s * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_chain_update": B},
         }
+        if world == 1 and not args.no_sweep and (n_loc, d) == (1024, 5):
+            try:     # reporting only: throughput regime of the same path
+                out["chain_count_sweep"] = [throughput_point(demc, n, d, K, seed, g, local_rank)
+                                            for n, g in ((16384, 400), (131072, 200), (1048576, 100))]
+            except Exception as e:
+                out["chain_count_sweep"] = f"failed: {e}"
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(demc.workloads.mvnormal_problem(d, n_loc), n_loc, d, K, seed, 1.0e7)

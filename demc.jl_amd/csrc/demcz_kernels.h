@@ -166,10 +166,8 @@ __device__ __forceinline__ double target_logp(const TargetParams& tp, int d, XF 
 // of a block-step are staged per lane in LDS (uniform runtime index).
 // ------------------------------------------------------------------------------------------------
 template <int TARGET, int D, bool FULL>
-#ifndef DEMCZ_AB_WPE
-#define DEMCZ_AB_WPE 1
-#endif
-__global__ void __launch_bounds__(WINDOW_BS, DEMCZ_AB_WPE) window_kernel(const WindowParams P)
+// (forcing 5/6/8 waves per SIMD through __launch_bounds__ spills and measured 0.72x/0.91x/0.81x: not used)
+__global__ void __launch_bounds__(WINDOW_BS) window_kernel(const WindowParams P)
 {
     __shared__ double zlds[FULL ? 1 : (D + 1) * WINDOW_BS];
     const int64_t c = (int64_t)blockIdx.x * WINDOW_BS + threadIdx.x;

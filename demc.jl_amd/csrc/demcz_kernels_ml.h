@@ -44,15 +44,9 @@ struct philox_blocks : rocrand_device::philox4x32_10_engine {
 // all that is needed is to stop the compiler from moving memory operations across the hand-off.
 __device__ __forceinline__ void wave_lds_handoff()
 {
-#ifdef DEMCZ_AB_FENCE
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#else
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
-#endif
 }
 
 // Workgroup geometry: MvNormal / isotropic targets run one wave per workgroup (small N spreads
