@@ -861,12 +861,12 @@ extern "C" int32_t demcz_rhat_partial(demcz_handle* h, int64_t g_from, int64_t g
     if (rc) return rc;
     const int d = r.d;
     if (stage == 0) {
-        hipLaunchKernelGGL(rhat_reduce_kernel, dim3(d), dim3(256), 0, h->stream, r.mean_j, r.s2_j, r.N, d, 0, (const double*)nullptr, r.sums);
+        hipLaunchKernelGGL(rhat_reduce_kernel, dim3(d), dim3(256), 0, h->stream, r.mean_j, r.s2_j, r.N, d, 0, (const double*)nullptr, 1.0, r.sums);
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipMemcpyAsync(out, r.sums, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     } else {
         HIPCHK(h, hipMemcpyAsync(r.sums, grand, (size_t)d * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(rhat_reduce_kernel, dim3(d), dim3(256), 0, h->stream, r.mean_j, r.s2_j, r.N, d, 1, (const double*)r.sums, r.sums + d);
+        hipLaunchKernelGGL(rhat_reduce_kernel, dim3(d), dim3(256), 0, h->stream, r.mean_j, r.s2_j, r.N, d, 1, (const double*)r.sums, 1.0, r.sums + d);
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipMemcpyAsync(out, r.sums + d, (size_t)2 * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     }
@@ -884,26 +884,19 @@ extern "C" int32_t demcz_rhat(demcz_handle* h, int64_t g_from, int64_t g_to, dou
     const int64_t n = r.n;
     const int64_t m = 2 * r.N * h->nranks;                   // utils.jl:5
     const bool sharded = (h->comm != nullptr);
-    double* sums = r.sums;
-    hipLaunchKernelGGL(rhat_reduce_kernel, dim3(d), dim3(256), 0, h->stream, r.mean_j, r.s2_j, r.N, d, 0, (const double*)nullptr, sums);
+    double* sums = r.sums;               // [0,d): sum_j mean_j; [d,3d): stage-1 sums; [3d,4d): R-hat
+    // stage 0 -> (all-reduce) -> stage 1 with the grand mean formed on the device -> (all-reduce) ->
+    // utils.jl:13-18 on the device: one copy and one synchronisation per check
+    hipLaunchKernelGGL(rhat_reduce_kernel, dim3(d), dim3(256), 0, h->stream, r.mean_j, r.s2_j, r.N, d, 0, (const double*)nullptr, 1.0, sums);
     HIPCHK(h, hipGetLastError());
     if (sharded) NCCLCHK(h, ncclAllReduce(sums, sums, (size_t)d, ncclDouble, ncclSum, h->comm, h->stream));
-    // grand mean = sum_j mean_j / m   (all split-chains have equal length: utils.jl:10)
-    HIPCHK(h, hipMemcpyAsync(h->d_stage, sums, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (int p = 0; p < d; ++p) h->d_stage[p] /= (double)m;
-    HIPCHK(h, hipMemcpyAsync(sums, h->d_stage, (size_t)d * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(rhat_reduce_kernel, dim3(d), dim3(256), 0, h->stream, r.mean_j, r.s2_j, r.N, d, 1, (const double*)sums, sums + d);
+    hipLaunchKernelGGL(rhat_reduce_kernel, dim3(d), dim3(256), 0, h->stream, r.mean_j, r.s2_j, r.N, d, 1, (const double*)sums, (double)m, sums + d);
     HIPCHK(h, hipGetLastError());
     if (sharded) NCCLCHK(h, ncclAllReduce(sums + d, sums + d, (size_t)2 * d, ncclDouble, ncclSum, h->comm, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_stage, sums + d, (size_t)2 * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    hipLaunchKernelGGL(rhat_final_kernel, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, h->stream, (const double*)(sums + d), d, (double)n, (double)m, sums + 3 * d);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(rhat, sums + 3 * d, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (int p = 0; p < d; ++p) {
-        const double B = (double)n / (double)(m - 1) * h->d_stage[p];                  // utils.jl:13
-        const double W = h->d_stage[d + p] / (double)m;                                // utils.jl:15
-        const double varhat = (double)(n - 1) / (double)n * W + B / (double)n;        // utils.jl:16
-        rhat[p] = std::sqrt(varhat / W);                                               // utils.jl:18
-    }
     return DEMCZ_OK;
 }
 

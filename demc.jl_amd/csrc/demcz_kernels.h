@@ -459,14 +459,16 @@ __global__ void rhat_chainstats_kernel(const double* chain, int64_t N, int d, in
 }
 
 // one workgroup of 256 per parameter; out[p] (stage 0) or out[p], out[d + p] (stage 1)
+// (stage 1 takes the summed means and divides by `grand_div` = m itself, so no host round trip is
+// needed between the stages)
 __global__ void __launch_bounds__(256) rhat_reduce_kernel(const double* mean_j, const double* s2_j, int64_t N, int d,
-                                                          int stage, const double* grand, double* out)
+                                                          int stage, const double* grand, double grand_div, double* out)
 {
     __shared__ double ra[256], rb[256];
     const int p = blockIdx.x;
     const int64_t stride = N * d;
     double a = 0.0, b = 0.0;
-    const double gm = stage ? grand[p] : 0.0;
+    const double gm = stage ? grand[p] / grand_div : 0.0;
     for (int64_t k = threadIdx.x; k < 2 * N; k += 256) {
         const int64_t h = k / N, c = k % N;
         const double mj = mean_j[c + N * p + stride * h];
@@ -492,6 +494,17 @@ __global__ void __launch_bounds__(256) rhat_reduce_kernel(const double* mean_j, 
         out[p] = ra[0];
         if (stage) out[d + p] = rb[0];
     }
+}
+
+// utils.jl:13-18 from the reduced sums: in[p] = sum_j (mean_j - grand)^2, in[d+p] = sum_j s_j^2
+__global__ void rhat_final_kernel(const double* in, int d, double n, double m, double* rhat)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d) return;
+    const double B = n / (m - 1.0) * in[p];                     // utils.jl:13
+    const double W = in[d + p] / m;                              // utils.jl:15
+    const double varhat = (n - 1.0) / n * W + B / n;             // utils.jl:16
+    rhat[p] = sqrt(varhat / W);                                  // utils.jl:18
 }
 
 // K7c: changed[s - s_from] = number of chains whose log_obj in history slot s differs from the slot

@@ -1,0 +1,178 @@
+# DEMCHip.jl -- `ccall` shim over libdemcz_hip.so (C ABI: include/demcz.h) with the call surface of
+# chrished/DEMC.jl: demcopt / demcz_sample / demcz_anneal returning (mc::MC, Z::Matrix{Float64}).
+#
+# STATUS: written against include/demcz.h but NOT executed -- there is no Julia in the build image or
+# on the GPU box.  The identical call sequence is what the Python host (demc.jl_amd/sampler.py) runs
+# and what tests/ verify; keep the two in step.  Field order of DemczConfig must match demcz_config.
+module DEMCHip
+
+using LinearAlgebra
+
+const libdemcz = get(ENV, "DEMCZ_LIB", "libdemcz_hip")
+
+# ---- types of src/DEMC.jl:10-43 ---------------------------------------------------------------------
+struct MC
+    chain::Array{Float64,3}
+    log_obj::Array{Float64,2}
+    Xcurrent::Array{Float64,2}
+    log_objcurrent::Array{Float64,1}
+end
+
+mutable struct DEMCopt
+    N::Int; K::Int; Ngeneration::Int; Nblocks::Int; blockindex::Array; eps_scale::Array{Float64,1}; γ::Float64
+    verbose::Bool; print_step::Int; T0::Float64; TN::Float64; autostop::Symbol; autostop_every::Int; autostop_Rhat
+end
+
+demcopt(Npar; N=4, K=10, Ngeneration=5000, Nblocks=1, blockindex=[1:Npar], eps_scale=1e-4 * ones(Npar), γ=2.38,
+        verbose=true, print_step=100, T0=3, TN=1e-3, autostop=:Rhat, autostop_every=1000, autostop_Rhat=1.05) =
+    DEMCopt(N, K, Ngeneration, Nblocks, blockindex, eps_scale, γ, verbose, print_step, T0, TN, autostop, autostop_every, autostop_Rhat)
+
+# ---- device targets (the closures of the reference's tests) -------------------------------------------
+abstract type DeviceTarget end
+struct MvNormalTarget <: DeviceTarget       # logpdf(MvNormal(μ, Σ), x), test/example_normpdf.jl:13-16
+    μ::Vector{Float64}; W::Matrix{Float64}; c0::Float64
+end
+function MvNormalTarget(μ, Σ)
+    L = cholesky(Symmetric(Matrix{Float64}(Σ))).L
+    MvNormalTarget(Vector{Float64}(μ), Matrix(inv(L)), -0.5 * (length(μ) * log(2π) + 2 * sum(log, diag(L))))
+end
+struct IsoQuadTarget <: DeviceTarget; μ::Vector{Float64}; end                       # -sum((x .- μ).^2)
+struct LinRegSSETarget <: DeviceTarget; X::Matrix{Float64}; y::Vector{Float64}; end  # -0.5*sum((y .- X*b).^2)
+
+# ---- C ABI ----------------------------------------------------------------------------------------------
+struct DemczConfig
+    N::Int64; chain_id0::Int64; d::Int32; K::Int32; Mcap::Int64; Gcap::Int64; Nblocks::Int32
+    block_offsets::Ptr{Int32}; block_indices::Ptr{Int32}; eps_scale::Ptr{Float64}
+    seed::UInt64; device_id::Int32; target_kind::Int32
+    mu::Ptr{Float64}; W::Ptr{Float64}; c0::Float64; design::Ptr{Float64}; yobs::Ptr{Float64}; nobs::Int64
+    stream::Ptr{Cvoid}; lanes_per_chain::Int32; reserved0::Int32
+end
+
+struct DemczError <: Exception; code::Int32; msg::String; end
+lasterr(h) = unsafe_string(ccall((:demcz_last_error, libdemcz), Cstring, (Ptr{Cvoid},), h))
+chk(rc, h=C_NULL) = rc == 0 ? nothing : throw(DemczError(rc, lasterr(h)))
+
+function create(t::DeviceTarget, N, d, K, Mcap, Gcap, blockindex, eps_scale, seed; device_id=0)
+    offs = Int32[0; cumsum(length.(blockindex))]
+    idx = Int32[i - 1 for b in blockindex for i in b]                       # 1-based -> 0-based
+    eps = Vector{Float64}(eps_scale)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve offs idx eps t begin
+        kind, mu, W, c0, design, y, nobs =
+            t isa MvNormalTarget ? (Int32(0), pointer(t.μ), pointer(t.W), t.c0, Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0) :
+            t isa IsoQuadTarget ? (Int32(1), pointer(t.μ), Ptr{Float64}(C_NULL), 0.0, Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0) :
+            (Int32(2), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0.0, pointer(t.X), pointer(t.y), size(t.X, 1))
+        cfg = DemczConfig(N, 0, d, K, Mcap, Gcap, length(blockindex), pointer(offs), pointer(idx), pointer(eps),
+                          UInt64(seed), device_id, kind, mu, W, c0, design, y, nobs, C_NULL, 0, 0)
+        chk(ccall((:demcz_create, libdemcz), Int32, (Ref{Ptr{Cvoid}}, Ref{DemczConfig}), h, cfg))   # config is copied
+    end
+    h[]
+end
+destroy(h) = ccall((:demcz_destroy, libdemcz), Int32, (Ptr{Cvoid},), h)
+
+set_state(h, X::Matrix{Float64}, logp, Z::Matrix{Float64}) =
+    chk(ccall((:demcz_set_state, libdemcz), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64),
+              h, X, logp === nothing ? C_NULL : logp, Z, size(Z, 1), size(Z, 1)), h)
+run!(h, g_from, g_to, γ, temperature=nothing) =
+    chk(ccall((:demcz_run, libdemcz), Int32, (Ptr{Cvoid}, Int64, Int64, Float64, Ptr{Float64}),
+              h, g_from, g_to, γ, temperature === nothing ? C_NULL : temperature), h)
+set_rng_offset(h, g) = chk(ccall((:demcz_set_rng_offset, libdemcz), Int32, (Ptr{Cvoid}, Int64), h, g), h)
+function rhat(h, g_from, g_to, d)
+    r = zeros(d)
+    chk(ccall((:demcz_rhat, libdemcz), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}), h, g_from, g_to, r), h); r
+end
+function changed(h, g_from, g_to)
+    c = zeros(Int64, g_to - g_from + 1)
+    chk(ccall((:demcz_get_changed, libdemcz), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}), h, g_from, g_to, c), h); c
+end
+function accept_ratio(h, g_from, g_to, N)
+    a = zeros(N)
+    chk(ccall((:demcz_accept_ratio, libdemcz), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}), h, g_from, g_to, a), h); a
+end
+function history(h, N, d, g_from, g_to)
+    G = g_to - g_from + 1
+    chain = Array{Float64,3}(undef, N, d, G); log_obj = Matrix{Float64}(undef, N, G)
+    chk(ccall((:demcz_get_history, libdemcz), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Float64}), h, g_from, g_to, chain, log_obj), h)
+    chain, log_obj
+end
+function state(h, N, d)
+    M = Ref{Int64}(0); X = Matrix{Float64}(undef, N, d); lp = Vector{Float64}(undef, N)
+    chk(ccall((:demcz_get_state, libdemcz), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ref{Int64}), h, X, lp, C_NULL, 0, M), h)
+    Z = Matrix{Float64}(undef, M[], d)
+    chk(ccall((:demcz_get_state, libdemcz), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int64}), h, C_NULL, C_NULL, Z, M[], C_NULL), h)
+    X, lp, Z
+end
+
+# ---- drivers: src/demcz.jl:1-63 and src/demcz_anneal.jl:14-65 with the device below runchain! -------------
+demcz_sample(t::DeviceTarget, Zmat, opts::DEMCopt; prevrun=nothing, seed=0) =
+    demcz_sample(t, Zmat, opts.N, opts.K, opts.Ngeneration, opts.Nblocks, opts.blockindex, opts.eps_scale, opts.γ;
+                 prevrun=prevrun, verbose=opts.verbose, print_step=opts.print_step, autostop=opts.autostop,
+                 autostop_Rhat=opts.autostop_Rhat, autostop_every=opts.autostop_every, seed=seed)
+
+function demcz_sample(t::DeviceTarget, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockindex=[1:size(Zmat, 2)],
+                      eps_scale=1e-4 * ones(size(Zmat, 2)), γ=2.38; prevrun=nothing, verbose=true, print_step=100,
+                      autostop=:no, autostop_Rhat=1.01, autostop_every=1000, seed=0)
+    nrowZ, d = size(Zmat)
+    Mcap = nrowZ + Int(ceil(N * Ngeneration / K))                                     # demcz.jl:11
+    X = prevrun === nothing ? Zmat[end-N+1:end, :] : prevrun.chain[:, :, end]         # demcz.jl:15 (intent), :20
+    lp = prevrun === nothing ? nothing : prevrun.log_objcurrent[:, end]               # :17 on the device, :21
+    h = create(t, N, d, K, Mcap, Ngeneration, blockindex, eps_scale, seed)
+    try
+        set_state(h, Matrix{Float64}(X), lp, Matrix{Float64}(Zmat))
+        prevrun === nothing || set_rng_offset(h, size(prevrun.chain, 3))
+        ig = 0
+        while ig < Ngeneration                                                         # demcz.jl:30
+            nxt = autostop == :Rhat ? min(Ngeneration, (ig ÷ autostop_every + 1) * autostop_every) : Ngeneration
+            run!(h, ig + 1, nxt, γ); ig = nxt
+            if autostop == :Rhat && ig % autostop_every == 0                           # demcz.jl:39-53
+                if maximum(rhat(h, ig - autostop_every + 1, ig, d)) < autostop_Rhat
+                    sum(accept_ratio(h, ig - autostop_every + 1, ig, N)) / N < 0.1 && println("Warning: accept ratio below 10% on average")
+                    break
+                end
+            end
+        end
+        chain, log_obj = history(h, N, d, 1, ig)
+        Xc, lpc, Z = state(h, N, d)
+        mc = prevrun === nothing ? MC(chain, log_obj, Xc, lpc) :
+             MC(cat(prevrun.chain, chain, dims=3), cat(prevrun.log_obj, log_obj, dims=2), Xc, lpc)   # demcz.jl:58-59
+        return mc, Z
+    finally
+        destroy(h)
+    end
+end
+
+tempbaseline(ig, Ng, T0, TN) = T0 * (TN / T0)^(ig / Ng)                                 # demcz_anneal.jl:1-3
+
+function demcz_anneal(t::DeviceTarget, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockindex=[1:size(Zmat, 2)],
+                      eps_scale=1e-4 * ones(size(Zmat, 2)), γ=2.38; prevrun=nothing, verbose=true, print_step=100,
+                      temperaturefun::Function=tempbaseline, T0=3, TN=0.0,
+                      adaptγ=Dict("adapt" => true, "minγ" => 0.1, "maxγ" => 4.0, "adapt_every" => 500), seed=0)
+    nrowZ, d = size(Zmat)
+    Mcap = nrowZ + Int(ceil(N * Ngeneration / K))
+    X = prevrun === nothing ? Zmat[end-N+1:end, :] : prevrun.chain[:, :, end]
+    lp = prevrun === nothing ? nothing : prevrun.log_objcurrent[:, end]
+    h = create(t, N, d, K, Mcap, Ngeneration, blockindex, eps_scale, seed)
+    try
+        set_state(h, Matrix{Float64}(X), lp, Matrix{Float64}(Zmat))
+        prevrun === nothing || set_rng_offset(h, size(prevrun.chain, 3))
+        ae = adaptγ["adapt_every"]; ig = 0
+        while ig < Ngeneration                                                         # demcz_anneal.jl:39
+            nxt = adaptγ["adapt"] ? min(Ngeneration, (ig ÷ ae + 1) * ae) : Ngeneration
+            temps = Float64[temperaturefun(g, Ngeneration, T0, TN) for g in ig+1:nxt]   # demcz_anneal.jl:69
+            run!(h, ig + 1, nxt, γ, temps); ig = nxt
+            if adaptγ["adapt"] && ig % ae == 0                                         # demcz_anneal.jl:48-57
+                accept = (ae > 1 ? sum(changed(h, ig - ae + 2, ig)) : 0) / (N * ae)
+                if accept < 0.1; γ = max(adaptγ["minγ"], γ * 0.5) elseif accept > 0.5; γ = min(adaptγ["maxγ"], γ * 1.5) end
+            end
+        end
+        chain, log_obj = history(h, N, d, 1, Ngeneration)
+        Xc, lpc, Z = state(h, N, d)
+        mc = prevrun === nothing ? MC(chain, log_obj, Xc, lpc) :
+             MC(cat(prevrun.chain, chain, dims=3), cat(prevrun.log_obj, log_obj, dims=2), Xc, lpc)
+        return mc, Z
+    finally
+        destroy(h)
+    end
+end
+
+end # module
