@@ -5,6 +5,7 @@
 #include "../../include/demcz.h"
 #include "demcz_kernels.h"
 #include "demcz_kernels_ml.h"
+#include "demcz_kernels_pc.h"
 
 #include <rccl/rccl.h>
 
@@ -67,6 +68,11 @@ struct demcz_handle {
     double* dlogu = nullptr;
     bool proposal_pending = false;
     bool gen_open = false;
+    // split layout: draw records, double-buffered (this launch reads one, its producer half fills the other)
+    double* d_rec[2] = {nullptr, nullptr};
+    int64_t rec_cap = 0;              // generations each buffer holds
+    int rec_cur = 0;
+    struct RecDesc { bool valid = false; int64_t g_first = 0; int64_t M = 0; int32_t ngen = 0; } rec_desc[2];
     // multi-GPU
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
@@ -119,6 +125,7 @@ static int64_t blockstep_nblk(int b)
 
 constexpr size_t ML_MAX_DYNAMIC_LDS = 160 * 1024;      // LDS per CU on gfx950
 static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t nobs, int max_blocklen, int nblocks);
+static bool pc_available(int target_kind, int d, bool full_block);
 static int32_t flush_exchanges(demcz_handle* h);
 
 extern "C" int32_t demcz_abi_version(void) { return DEMCZ_ABI_VERSION; }
@@ -147,6 +154,7 @@ static void free_all(demcz_handle* h)
     for (auto& pe : h->pending) if (pe.ev) (void)hipEventDestroy(pe.ev);
     h->pending.clear();
     for (int b = 0; b < 2; ++b) {
+        if (h->d_rec[b]) (void)hipFree(h->d_rec[b]);
         if (h->d_send[b]) (void)hipFree(h->d_send[b]);
         if (h->d_recv[b]) (void)hipFree(h->d_recv[b]);
         if (h->buf_done[b]) (void)hipEventDestroy(h->buf_done[b]);
@@ -165,8 +173,9 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         cfg->Nblocks < 1 || !cfg->block_offsets || !cfg->block_indices || !cfg->eps_scale || cfg->chain_id0 < 0)
         return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT,
                     "demcz_create: need N>=1, 1<=d<=64, K>=1, Mcap>=2, Gcap>=0, Nblocks>=1 and block/eps tables");
-    if (cfg->lanes_per_chain != 0 && cfg->lanes_per_chain != 1 && cfg->lanes_per_chain != 8 && cfg->lanes_per_chain != 16)
-        return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_create: lanes_per_chain must be 0 (auto), 1, 8 or 16");
+    if (cfg->lanes_per_chain != 0 && cfg->lanes_per_chain != 1 && cfg->lanes_per_chain != 8 && cfg->lanes_per_chain != 16 &&
+        cfg->lanes_per_chain != DEMCZ_LAYOUT_SPLIT)
+        return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_create: lanes_per_chain must be 0 (auto), 1, 8, 16 or DEMCZ_LAYOUT_SPLIT");
     const int d = cfg->d;
     // validate blocks: offsets ascending, indices within range and unique inside a block
     if (cfg->block_offsets[0] != 0) return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT, "block_offsets[0] must be 0");
@@ -242,7 +251,16 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         int maxb = 0;
         for (int ib = 0; ib < cfg->Nblocks; ++ib) maxb = std::max(maxb, h->block_offsets[ib + 1] - h->block_offsets[ib]);
         const int L = ml_lanes_available(cfg->target_kind, d, h->full_block, cfg->nobs, maxb, cfg->Nblocks);
-        if (cfg->lanes_per_chain > 1) {
+        const bool split_ok = pc_available(cfg->target_kind, d, h->full_block);
+        if (cfg->lanes_per_chain == DEMCZ_LAYOUT_SPLIT) {
+            if (!split_ok) {
+                h->err = "demcz_create: the split layout is not built for this target / d / block structure";
+                return bail(DEMCZ_ERR_INVALID_ARGUMENT);
+            }
+            h->lanes = DEMCZ_LAYOUT_SPLIT;
+        } else if (cfg->lanes_per_chain == 0 && split_ok && cfg->N <= 32768) {
+            h->lanes = DEMCZ_LAYOUT_SPLIT;      // idle CUs do the state-independent three quarters of the work
+        } else if (cfg->lanes_per_chain > 1) {
             if (L != cfg->lanes_per_chain) {
                 h->err = "demcz_create: the requested lanes_per_chain layout is not built for this target / d / block structure";
                 return bail(DEMCZ_ERR_INVALID_ARGUMENT);
@@ -380,6 +398,7 @@ extern "C" int32_t demcz_set_state(demcz_handle* h, const double* X, const doubl
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->M = M0;
     h->M_app = M0;
+    h->rec_desc[0].valid = h->rec_desc[1].valid = false;
     for (auto& pe : h->pending) if (pe.ev) (void)hipEventDestroy(pe.ev);
     h->pending.clear();
     h->batch_cnt = 0; h->batch_J = -1;
@@ -490,6 +509,82 @@ static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t n
     return 0;
 }
 
+// split layout (demcz_kernels_pc.h)
+static bool pc_available(int target_kind, int d, bool full_block)
+{
+    if (!full_block) return false;
+    // measured per K-window at N=1024: d=5 9.0 us (8 lanes per chain: 11.4); d=10 22.8 (13.5); d=20 205 (16.8):
+    // the consumer holds 3d+1 doubles per prefetched generation, beyond d~5 that no longer fits registers
+    return target_kind == DEMCZ_TARGET_MVNORMAL && (d == 2 || d == 3 || d == 4 || d == 5);
+}
+
+static int pc_roles(int d) { return ((d == 1) ? 1 : (d + 1) / 2) + 2; }
+
+template <int TARGET, int D>
+static void launch_pc(const demcz_handle* h, const WindowParams& P, int64_t blocks)
+{
+    hipLaunchKernelGGL((window_kernel_pc<TARGET, D>), dim3((unsigned)blocks), dim3(64), 0, h->stream, P);
+}
+
+static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P)
+{
+    const int64_t nbc = (P.N + 63) / 64;
+    const int64_t blocks = P.consumer_blocks + nbc * pc_roles(P.d) * P.next_ngen;
+    if (blocks <= 0) return DEMCZ_OK;
+    if (h->cfg.target_kind == DEMCZ_TARGET_MVNORMAL) {
+        switch (P.d) {
+        case 2: launch_pc<TARGET_MVNORMAL, 2>(h, P, blocks); break;
+        case 3: launch_pc<TARGET_MVNORMAL, 3>(h, P, blocks); break;
+        case 4: launch_pc<TARGET_MVNORMAL, 4>(h, P, blocks); break;
+        case 5: launch_pc<TARGET_MVNORMAL, 5>(h, P, blocks); break;
+        default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
+        }
+    } else {
+        return fail(h, DEMCZ_ERR_STATE, "split layout: target not built");
+    }
+    HIPCHK(h, hipGetLastError());
+    return DEMCZ_OK;
+}
+
+// Records of the launch (g .. g+ngen-1 against M rows) are in d_rec[rec_cur] when this returns: either
+// the previous launch's producer half made them, or a producer-only launch is enqueued now.  Then
+// `P` is completed so that this launch's producer half prepares (next_g, next_ngen, next_M).
+static int32_t pc_prepare(demcz_handle* h, WindowParams& P, int64_t next_g, int64_t next_ngen, int64_t next_M)
+{
+    const int d = h->cfg.d;
+    const int64_t need = std::max<int64_t>(P.ngen, next_ngen);
+    if (need > h->rec_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (int b = 0; b < 2; ++b) {
+            if (h->d_rec[b]) HIPCHK(h, hipFree(h->d_rec[b]));
+            h->d_rec[b] = nullptr;
+            HIPCHK(h, hipMalloc((void**)&h->d_rec[b], (size_t)need * (d + 3) * h->cfg.N * sizeof(double)));
+            HIPCHK(h, hipMemsetAsync(h->d_rec[b], 0, (size_t)need * (d + 3) * h->cfg.N * sizeof(double), h->stream));   // row 0: always a legal index
+            h->rec_desc[b].valid = false;
+        }
+        h->rec_cap = need;
+    }
+    const int cur = h->rec_cur;
+    auto& dc = h->rec_desc[cur];
+    if (!(dc.valid && dc.g_first == P.g_first && dc.M == P.M && dc.ngen >= P.ngen)) {
+        WindowParams Q = P;                 // producer-only launch for THIS window
+        Q.consumer_blocks = 0;
+        Q.rec_out = h->d_rec[cur];
+        Q.next_g_first = P.g_first; Q.next_ngen = P.ngen; Q.next_M = P.M;
+        int32_t rc = launch_window_pc(h, Q);
+        if (rc) return rc;
+        dc.valid = true; dc.g_first = P.g_first; dc.M = P.M; dc.ngen = P.ngen;
+    }
+    P.rec_in = h->d_rec[cur];
+    P.consumer_blocks = (int32_t)((P.N + 63) / 64);
+    P.rec_out = h->d_rec[cur ^ 1];
+    P.next_g_first = next_g; P.next_ngen = (int32_t)std::max<int64_t>(next_ngen, 0); P.next_M = next_M;
+    auto& dn = h->rec_desc[cur ^ 1];
+    dn.valid = next_ngen > 0; dn.g_first = next_g; dn.M = next_M; dn.ngen = (int32_t)std::max<int64_t>(next_ngen, 0);
+    h->rec_cur = cur ^ 1;
+    return DEMCZ_OK;
+}
+
 template <int TARGET, int D, int L>
 static void launch_window_mlb(const demcz_handle* h, const WindowParams& P)
 {
@@ -499,7 +594,7 @@ static void launch_window_mlb(const demcz_handle* h, const WindowParams& P)
 
 static bool try_launch_ml(const demcz_handle* h, const WindowParams& P)
 {
-    if (h->lanes <= 1) return false;
+    if (h->lanes <= 1 || h->lanes == DEMCZ_LAYOUT_SPLIT) return false;
     const int d = P.d;
     if (!h->full_block) {
         if (h->cfg.target_kind != DEMCZ_TARGET_MVNORMAL) return false;
@@ -535,6 +630,12 @@ static int32_t launch_window(demcz_handle* h, const WindowParams& P)
 {
     const dim3 grid((unsigned)((P.N + WINDOW_BS - 1) / WINDOW_BS));
     const int d = P.d;
+    if (h->lanes == DEMCZ_LAYOUT_SPLIT) {
+        int32_t rc = launch_window_pc(h, P);
+        if (rc) return rc;
+        ++h->launches;
+        return DEMCZ_OK;
+    }
     if (try_launch_ml(h, P)) {
         HIPCHK(h, hipGetLastError());
         ++h->launches;
@@ -697,6 +798,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     P.tp = target_params(h);
     P.snap = nullptr;
     P.K = K;
+    P.rec_in = nullptr; P.rec_out = nullptr; P.next_g_first = 0; P.next_M = 0; P.next_ngen = 0; P.consumer_blocks = 0;
     const int E = h->lag;
     int64_t g = g_from;
     while (g <= g_to) {
@@ -728,6 +830,20 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
                 h->batch_base = h->M_app;
             }
             P.snap = h->d_send[h->batch_buf] + (size_t)h->batch_cnt * h->cfg.N * h->cfg.d;
+        }
+        if (h->lanes == DEMCZ_LAYOUT_SPLIT) {
+            // what the launch after this one will be, so that this launch's producer half can prepare
+            // its draws: it starts at w_end + 1, runs to its own boundary / batch end, and sees ...
+            const int64_t ng = w_end + 1;
+            int64_t nend = ((ng - 1) / K + 1) * (int64_t)K;
+            if (E > 0 && !h->external_append) nend = ((nend / K + E - 1) / E) * E * (int64_t)K;
+            int64_t nM = h->M, nn = nend - ng + 1;
+            const int64_t rows_n = h->cfg.N * (sharded ? h->nranks : 1);
+            if (h->external_append) nn = 0;                      // the caller appends: M is not ours to predict
+            else if (E == 0) nM = (nbound > 0) ? h->M_app + rows_n : h->M;       // ... the rows appended now
+            else for (const auto& pe : h->pending) if (pe.visible_from <= ng) nM = pe.M_after;   // ... or admitted by then
+            rc = pc_prepare(h, P, ng + h->rng_offset, nn, nM);
+            if (rc) return rc;
         }
         rc = launch_window(h, P);
         if (rc) return rc;
@@ -1190,6 +1306,7 @@ extern "C" int32_t demcz_set_append_lag(demcz_handle* h, int32_t batches)
         }
     }
     h->lag = batches;
+    h->rec_desc[0].valid = h->rec_desc[1].valid = false;
     h->batch_cnt = 0; h->batch_buf = 0; h->batch_J = -1;
     return DEMCZ_OK;
 }
@@ -1198,6 +1315,7 @@ extern "C" int32_t demcz_set_rng_offset(demcz_handle* h, int64_t generations)
 {
     if (!h || generations < 0) return DEMCZ_ERR_INVALID_ARGUMENT;
     h->rng_offset = generations;
+    h->rec_desc[0].valid = h->rec_desc[1].valid = false;
     return DEMCZ_OK;
 }
 

@@ -120,11 +120,26 @@ __device__ __forceinline__ void normal_pair(uint64_t r1, uint64_t r2, double& z0
     z1 = R * s;
 }
 
+// floor(r * m / 2^64) for m < 2^32: r = h 2^32 + l  =>  floor((h m + floor(l m / 2^32)) / 2^32), exact.
+// Two multiplies instead of the 64x64->128 product (the archive has fewer than 2^32 rows in every
+// configuration of interest; the general form stays for larger ones).
+__device__ __forceinline__ uint64_t mulhi64_u32(uint64_t r, uint32_t m)
+{
+    const uint64_t t = (uint64_t)(uint32_t)(r >> 32) * m + __umulhi((uint32_t)r, m);
+    return t >> 32;
+}
+
 // Two distinct archive rows out of M: i1 ~ U{0..M-1}, i2 ~ U({0..M-1} \ {i1}).
 __device__ __forceinline__ void draw_rows(uint64_t r1, uint64_t r2, uint64_t M, uint64_t& i1, uint64_t& i2)
 {
-    i1 = __umul64hi(r1, M);
-    uint64_t j = __umul64hi(r2, M - 1);
+    uint64_t j;
+    if (M <= 0xffffffffull) {           // wave-uniform
+        i1 = mulhi64_u32(r1, (uint32_t)M);
+        j = mulhi64_u32(r2, (uint32_t)(M - 1));
+    } else {
+        i1 = __umul64hi(r1, M);
+        j = __umul64hi(r2, M - 1);
+    }
     i2 = j + (j >= i1 ? 1ull : 0ull);
 }
 

@@ -67,6 +67,14 @@ struct WindowParams {
     const int32_t* slot_of;  // Nblocks x d: position of parameter p inside block ib, or -1
     const double* eps;
     TargetParams tp;
+    // split layout (demcz_kernels_pc.h): draw records of THIS launch's generations, and what the
+    // producer half of the launch prepares for the NEXT one
+    const double* rec_in;
+    double* rec_out;
+    int64_t next_g_first;    // stream generation index of the next launch's first generation
+    int64_t next_M;          // rows its proposals will draw from
+    int32_t next_ngen;
+    int32_t consumer_blocks; // workgroups [0, consumer_blocks) consume, the rest produce
 };
 
 // One archive row (16-byte aligned) <-> registers, as 16-byte accesses.

@@ -83,11 +83,15 @@ typedef struct demcz_config {
     const double* yobs;           /* LINREG_SSE: nobs                                               */
     int64_t nobs;
     void* stream;                 /* hipStream_t to enqueue on, or NULL: the library makes its own  */
-    int32_t lanes_per_chain;      /* 0 = let the library choose; 1 = one lane per chain
-                                     (throughput layout); 8 = eight lanes per chain (latency layout
-                                     for small N).  Results are bit-identical either way.          */
+    int32_t lanes_per_chain;      /* kernel layout: 0 = let the library choose; 1 = one lane per chain,
+                                     fused (throughput layout, large N); 8 / 16 = that many lanes
+                                     cooperate on a chain; DEMCZ_LAYOUT_SPLIT = producer workgroups
+                                     make the state-independent draws one launch ahead, consumer
+                                     lanes run the chains (small N).  Results are bit-identical.   */
     int32_t reserved0;
 } demcz_config;
+
+#define DEMCZ_LAYOUT_SPLIT 100
 
 /* Version of this header's ABI; demcz_abi_version() must return the same number. */
 #define DEMCZ_ABI_VERSION 1

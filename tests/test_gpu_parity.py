@@ -22,19 +22,23 @@ def test_selftest_draws_bit_exact(demc, oracle):
     assert abs(normals.mean()) < 0.02 and abs(normals.std() - 1.0) < 0.02
 
 
-@pytest.mark.parametrize("lanes", [1, 0])
+@pytest.mark.parametrize("lanes", [1, 0, "ml"])
 @pytest.mark.parametrize("N,d,G", [(4, 5, 200), (100, 5, 57), (1024, 5, 40), (64, 3, 30), (65, 8, 25), (32, 7, 25),
                                    (13, 2, 31), (77, 4, 33), (50, 10, 27), (41, 20, 23)])
 def test_mvnormal_full_block_bit_exact(demc, oracle, N, d, G, lanes):
-    """Both layouts: one lane per chain (lanes=1) and the library's choice (lanes=0: eight / sixteen
-    lanes per chain for the dimensions it is built for)."""
+    """Every layout: one lane per chain fused (lanes=1), the library's choice (lanes=0: the
+    producer/consumer split for the dimensions it is built for), eight / sixteen lanes per chain."""
+    if lanes == "ml":
+        if d == 7:
+            pytest.skip("no multi-lane build for d=7")
+        lanes = 16 if d == 20 else 8
     w = demc.workloads.mvnormal_problem(d, N)
     seed = 99 + N
     mc, Z, runner = demc.demcz_sample(w["target"], w["Zinit"], N, w["K"], G, 1, [range(d)], w["eps_scale"], w["gamma"],
                                       verbose=False, seed=seed, lanes_per_chain=lanes, return_runner=True)
     used = runner.engines[0].info()["lanes_per_chain"]
     runner.close()
-    assert used == (1 if lanes == 1 or d == 7 else (16 if d == 20 else 8))
+    assert used == (1 if d == 7 else ((100 if d <= 5 else (16 if d == 20 else 8)) if lanes == 0 else lanes))
     ref = oracle_sample(oracle, w["target"], w["Zinit"], N, w["K"], G, None, w["eps_scale"], w["gamma"], seed)
     assert np.array_equal(mc.chain, ref["chain"])
     assert np.array_equal(mc.log_obj, ref["log_obj"])
