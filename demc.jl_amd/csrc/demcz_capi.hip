@@ -515,15 +515,25 @@ static bool pc_available(int target_kind, int d, bool full_block)
     if (!full_block) return false;
     // measured per K-window at N=1024: d=5 9.0 us (8 lanes per chain: 11.4); d=10 22.8 (13.5); d=20 205 (16.8):
     // the consumer holds 3d+1 doubles per prefetched generation, beyond d~5 that no longer fits registers
-    return target_kind == DEMCZ_TARGET_MVNORMAL && (d == 2 || d == 3 || d == 4 || d == 5);
+    return target_kind == DEMCZ_TARGET_MVNORMAL && (d == 2 || d == 3 || d == 4 || d == 5 || d == 8);
 }
 
 static int pc_roles(int d) { return ((d == 1) ? 1 : (d + 1) / 2) + 2; }
 
+#ifndef DEMCZ_PC_L1
+constexpr int PC_CONSUMER_CHAINS = 8;       // chains per consumer workgroup: 8 lanes per chain (window_kernel_pc8)
+#else
+constexpr int PC_CONSUMER_CHAINS = 64;      // A/B: one lane per chain (window_kernel_pc)
+#endif
+
 template <int TARGET, int D>
 static void launch_pc(const demcz_handle* h, const WindowParams& P, int64_t blocks)
 {
+#ifndef DEMCZ_PC_L1
+    hipLaunchKernelGGL((window_kernel_pc8<TARGET, D>), dim3((unsigned)blocks), dim3(64), 0, h->stream, P);
+#else
     hipLaunchKernelGGL((window_kernel_pc<TARGET, D>), dim3((unsigned)blocks), dim3(64), 0, h->stream, P);
+#endif
 }
 
 static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P)
@@ -537,6 +547,9 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P)
         case 3: launch_pc<TARGET_MVNORMAL, 3>(h, P, blocks); break;
         case 4: launch_pc<TARGET_MVNORMAL, 4>(h, P, blocks); break;
         case 5: launch_pc<TARGET_MVNORMAL, 5>(h, P, blocks); break;
+#ifndef DEMCZ_PC_L1
+        case 8: launch_pc<TARGET_MVNORMAL, 8>(h, P, blocks); break;
+#endif
         default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
         }
     } else {
@@ -576,7 +589,7 @@ static int32_t pc_prepare(demcz_handle* h, WindowParams& P, int64_t next_g, int6
         dc.valid = true; dc.g_first = P.g_first; dc.M = P.M; dc.ngen = P.ngen;
     }
     P.rec_in = h->d_rec[cur];
-    P.consumer_blocks = (int32_t)((P.N + 63) / 64);
+    P.consumer_blocks = (int32_t)((P.N + PC_CONSUMER_CHAINS - 1) / PC_CONSUMER_CHAINS);
     P.rec_out = h->d_rec[cur ^ 1];
     P.next_g_first = next_g; P.next_ngen = (int32_t)std::max<int64_t>(next_ngen, 0); P.next_M = next_M;
     auto& dn = h->rec_desc[cur ^ 1];

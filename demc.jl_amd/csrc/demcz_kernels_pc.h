@@ -190,4 +190,139 @@ __global__ void __launch_bounds__(64) window_kernel_pc(const WindowParams P)
     P.lpcur[c] = lp;
 }
 
+// ------------------------------------------------------------------------------------------------
+// K1g: the same split with an 8-lanes-per-chain consumer.  Lane p of a chain's group prefetches what
+// concerns parameter p for a whole chunk of generations at once (row elements, normal, 6 loads a
+// generation, so a 10-generation chunk fits in registers and its two dependent memory hops are paid
+// once per chunk instead of once per 5 generations), forms its increments and shares them through
+// LDS; then every lane of the group runs the state-dependent part redundantly from the whole state
+// (no cross-lane traffic there) and stores its own element of the history row.
+// ------------------------------------------------------------------------------------------------
+constexpr int PC8_CHUNK = 10;
+
+template <int TARGET, int D>
+__global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
+{
+    static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "split layout: MvNormal / isotropic targets");
+    static_assert(D <= 8, "one lane per parameter");
+    constexpr int L = 8, G = 64 / L, CH = PC8_CHUNK, DP = ((D + 1) / 2) * 2;
+    if ((int64_t)blockIdx.x >= P.consumer_blocks) {
+        pc_produce<D>(P, (int64_t)blockIdx.x - P.consumer_blocks);
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) double sdelta[G * CH * DP];
+    const int lane = threadIdx.x, r = lane % L, gq = lane / L;
+    const int64_t c = (int64_t)blockIdx.x * G + gq;
+    if (c >= P.N) return;
+    const int pc = (r < D) ? r : 0;
+
+    double x[D], muc[D], Wc[(TARGET == TARGET_MVNORMAL) ? D * (D + 1) / 2 : 1];
+#pragma unroll
+    for (int p = 0; p < D; ++p) { x[p] = P.Xcur[c + P.N * p]; muc[p] = P.tp.mu[p]; }
+    if constexpr (TARGET == TARGET_MVNORMAL) {
+#pragma unroll
+        for (int i = 0; i < D * (D + 1) / 2; ++i) Wc[i] = P.tp.Wp[i];
+    }
+    const double c0c = P.tp.c0, epsv = P.eps[pc];
+    double lp = P.lpcur[c];
+    const double scale = (D == 1) ? P.gamma : P.gamma / sqrt((double)(2 * D));
+    int to_b = P.to_boundary;
+    int64_t nb = 0;
+
+    for (int g0 = 0; g0 < P.ngen; g0 += CH) {
+        double lgu[CH];
+        {
+            int64_t i1[CH], i2[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int g = (g0 + u < P.ngen) ? g0 + u : P.ngen - 1;
+                i1[u] = __double_as_longlong(P.rec_in[rec_index<D>(P.N, g, D + 1, c)]);
+                i2[u] = __double_as_longlong(P.rec_in[rec_index<D>(P.N, g, D + 2, c)]);
+            }
+            double za[CH], zb[CH], zt[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int g = (g0 + u < P.ngen) ? g0 + u : P.ngen - 1;
+                za[u] = P.Z[i1[u] * P.ZS + pc];
+                zb[u] = P.Z[i2[u] * P.ZS + pc];
+                zt[u] = P.rec_in[rec_index<D>(P.N, g, (D == 1) ? 0 : pc, c)];
+                lgu[u] = P.rec_in[rec_index<D>(P.N, g, D, c)];
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const double diff = za[u] - zb[u];
+                const double t1 = scale * diff;
+                const double t2 = epsv * zt[u];
+                if (r < D) sdelta[(gq * CH + u) * DP + r] = t1 + t2;
+            }
+        }
+        wave_lds_handoff();
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            if (g0 + u < P.ngen) {       // wave-uniform
+                const int gi = g0 + u;
+                double dl[DP];
+#pragma unroll
+                for (int j = 0; j < DP / 2; ++j) {
+                    const double2 t = reinterpret_cast<const double2*>(sdelta + (gq * CH + u) * DP)[j];
+                    dl[2 * j] = t.x;
+                    dl[2 * j + 1] = t.y;
+                }
+                double xp[D];
+#pragma unroll
+                for (int p = 0; p < D; ++p) xp[p] = x[p] + dl[p];
+                double lpp;
+                if constexpr (TARGET == TARGET_MVNORMAL) {
+                    double q = 0.0;
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        double acc = Wc[(i * (i + 1)) / 2] * (xp[0] - muc[0]);
+#pragma unroll
+                        for (int j = 1; j <= i; ++j) acc = fma(Wc[(i * (i + 1)) / 2 + j], xp[j] - muc[j], acc);
+                        q = (i == 0) ? acc * acc : fma(acc, acc, q);
+                    }
+                    lpp = fma(-0.5, q, c0c);
+                } else {
+                    double q = 0.0;
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        const double rr = xp[i] - muc[i];
+                        q = (i == 0) ? rr * rr : fma(rr, rr, q);
+                    }
+                    lpp = -q;
+                }
+                double dlt = lpp - lp;
+                if (P.temperature) dlt = dlt / P.temperature[gi];
+                const bool acc = lgu[u] < dlt;
+#pragma unroll
+                for (int p = 0; p < D; ++p) x[p] = acc ? xp[p] : x[p];
+                lp = acc ? lpp : lp;
+                const int64_t slot = P.slot_first + gi;
+                double xs = x[0];
+#pragma unroll
+                for (int p = 1; p < D; ++p) xs = (r == p) ? x[p] : xs;
+                const bool boundary = (--to_b == 0);
+                if (boundary) to_b = P.K;
+                if (r < D) {
+                    if (P.chain) P.chain[c + P.N * (r + (int64_t)D * slot)] = xs;
+                    if (boundary) {      // generation divisible by K: runchain!'s append, demcz.jl:88-91
+                        if (P.do_append) P.Zw[(P.M_append + nb * P.N + c) * P.ZS + r] = xs;
+                        if (P.snap) P.snap[nb * P.N * D + c + P.N * r] = xs;
+                    }
+                }
+                if (P.chain && r == L - 1) P.logobj[c + P.N * slot] = lp;
+                if (boundary) ++nb;
+            }
+        }
+        wave_lds_handoff();      // sdelta is rewritten by the next chunk
+    }
+    if (r < D) {
+        double xs = x[0];
+#pragma unroll
+        for (int p = 1; p < D; ++p) xs = (r == p) ? x[p] : xs;
+        P.Xcur[c + P.N * r] = xs;
+    }
+    if (r == 0) P.lpcur[c] = lp;
+}
+
 }  // namespace demcz
