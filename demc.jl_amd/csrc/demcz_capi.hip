@@ -513,9 +513,12 @@ static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t n
 static bool pc_available(int target_kind, int d, bool full_block)
 {
     if (!full_block) return false;
-    // measured per K-window at N=1024: d=5 9.0 us (8 lanes per chain: 11.4); d=10 22.8 (13.5); d=20 205 (16.8):
-    // the consumer holds 3d+1 doubles per prefetched generation, beyond d~5 that no longer fits registers
-    return target_kind == DEMCZ_TARGET_MVNORMAL && (d == 2 || d == 3 || d == 4 || d == 5 || d == 8);
+    // measured per K-window at N=1024 (split vs 8 lanes per chain, fused): d=5 7.0 vs 11.4 us, d=8 7.8 vs 11.6,
+    // d=10 11.1 vs 13.5
+    if (target_kind == DEMCZ_TARGET_ISO_QUAD) return d == 10;
+    // (d = 20: the replicated 210-coefficient whitening does not fit registers -- 63 us per window against
+    //  16.7 for the 16-lanes-per-chain kernel, which stays the choice there)
+    return target_kind == DEMCZ_TARGET_MVNORMAL && (d == 2 || d == 3 || d == 4 || d == 5 || d == 8 || d == 10);
 }
 
 static int pc_roles(int d) { return ((d == 1) ? 1 : (d + 1) / 2) + 2; }
@@ -549,11 +552,16 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P)
         case 5: launch_pc<TARGET_MVNORMAL, 5>(h, P, blocks); break;
 #ifndef DEMCZ_PC_L1
         case 8: launch_pc<TARGET_MVNORMAL, 8>(h, P, blocks); break;
+        case 10: launch_pc<TARGET_MVNORMAL, 10>(h, P, blocks); break;
 #endif
         default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
         }
     } else {
+#ifndef DEMCZ_PC_L1
+        launch_pc<TARGET_ISO_QUAD, 10>(h, P, blocks);
+#else
         return fail(h, DEMCZ_ERR_STATE, "split layout: target not built");
+#endif
     }
     HIPCHK(h, hipGetLastError());
     return DEMCZ_OK;

@@ -204,8 +204,9 @@ template <int TARGET, int D>
 __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
 {
     static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "split layout: MvNormal / isotropic targets");
-    static_assert(D <= 8, "one lane per parameter");
-    constexpr int L = 8, G = 64 / L, CH = PC8_CHUNK, DP = ((D + 1) / 2) * 2;
+    constexpr int L = 8, G = 64 / L, DP = ((D + 1) / 2) * 2;
+    constexpr int NP = (D + L - 1) / L;                    // parameters a lane prefetches: r, r+8, ...
+    constexpr int CH = (NP == 1) ? PC8_CHUNK : PC8_CHUNK / 2;
     if ((int64_t)blockIdx.x >= P.consumer_blocks) {
         pc_produce<D>(P, (int64_t)blockIdx.x - P.consumer_blocks);
         return;
@@ -214,7 +215,6 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
     const int lane = threadIdx.x, r = lane % L, gq = lane / L;
     const int64_t c = (int64_t)blockIdx.x * G + gq;
     if (c >= P.N) return;
-    const int pc = (r < D) ? r : 0;
 
     double x[D], muc[D], Wc[(TARGET == TARGET_MVNORMAL) ? D * (D + 1) / 2 : 1];
 #pragma unroll
@@ -223,7 +223,11 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
 #pragma unroll
         for (int i = 0; i < D * (D + 1) / 2; ++i) Wc[i] = P.tp.Wp[i];
     }
-    const double c0c = P.tp.c0, epsv = P.eps[pc];
+    int pk[NP];
+    double epsv[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { pk[k] = (r + L * k < D) ? r + L * k : 0; epsv[k] = P.eps[pk[k]]; }
+    const double c0c = P.tp.c0;
     double lp = P.lpcur[c];
     const double scale = (D == 1) ? P.gamma : P.gamma / sqrt((double)(2 * D));
     int to_b = P.to_boundary;
@@ -239,21 +243,27 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
                 i1[u] = __double_as_longlong(P.rec_in[rec_index<D>(P.N, g, D + 1, c)]);
                 i2[u] = __double_as_longlong(P.rec_in[rec_index<D>(P.N, g, D + 2, c)]);
             }
-            double za[CH], zb[CH], zt[CH];
+            double za[CH][NP], zb[CH][NP], zt[CH][NP];
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 const int g = (g0 + u < P.ngen) ? g0 + u : P.ngen - 1;
-                za[u] = P.Z[i1[u] * P.ZS + pc];
-                zb[u] = P.Z[i2[u] * P.ZS + pc];
-                zt[u] = P.rec_in[rec_index<D>(P.N, g, (D == 1) ? 0 : pc, c)];
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    za[u][k] = P.Z[i1[u] * P.ZS + pk[k]];
+                    zb[u][k] = P.Z[i2[u] * P.ZS + pk[k]];
+                    zt[u][k] = P.rec_in[rec_index<D>(P.N, g, (D == 1) ? 0 : pk[k], c)];
+                }
                 lgu[u] = P.rec_in[rec_index<D>(P.N, g, D, c)];
             }
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
-                const double diff = za[u] - zb[u];
-                const double t1 = scale * diff;
-                const double t2 = epsv * zt[u];
-                if (r < D) sdelta[(gq * CH + u) * DP + r] = t1 + t2;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const double diff = za[u][k] - zb[u][k];
+                    const double t1 = scale * diff;
+                    const double t2 = epsv[k] * zt[u][k];
+                    if (r + L * k < D) sdelta[(gq * CH + u) * DP + r + L * k] = t1 + t2;
+                }
             }
         }
         wave_lds_handoff();
@@ -298,16 +308,21 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
                 for (int p = 0; p < D; ++p) x[p] = acc ? xp[p] : x[p];
                 lp = acc ? lpp : lp;
                 const int64_t slot = P.slot_first + gi;
-                double xs = x[0];
-#pragma unroll
-                for (int p = 1; p < D; ++p) xs = (r == p) ? x[p] : xs;
                 const bool boundary = (--to_b == 0);
                 if (boundary) to_b = P.K;
-                if (r < D) {
-                    if (P.chain) P.chain[c + P.N * (r + (int64_t)D * slot)] = xs;
-                    if (boundary) {      // generation divisible by K: runchain!'s append, demcz.jl:88-91
-                        if (P.do_append) P.Zw[(P.M_append + nb * P.N + c) * P.ZS + r] = xs;
-                        if (P.snap) P.snap[nb * P.N * D + c + P.N * r] = xs;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    double xs = x[(L * k < D) ? L * k : 0];
+#pragma unroll
+                    for (int j = 1; j < L; ++j)
+                        if (L * k + j < D) xs = (r == j) ? x[L * k + j] : xs;
+                    const int p = r + L * k;
+                    if (p < D) {
+                        if (P.chain) P.chain[c + P.N * (p + (int64_t)D * slot)] = xs;
+                        if (boundary) {      // generation divisible by K: runchain!'s append, demcz.jl:88-91
+                            if (P.do_append) P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p] = xs;
+                            if (P.snap) P.snap[nb * P.N * D + c + P.N * p] = xs;
+                        }
                     }
                 }
                 if (P.chain && r == L - 1) P.logobj[c + P.N * slot] = lp;
@@ -316,11 +331,14 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
         }
         wave_lds_handoff();      // sdelta is rewritten by the next chunk
     }
-    if (r < D) {
-        double xs = x[0];
 #pragma unroll
-        for (int p = 1; p < D; ++p) xs = (r == p) ? x[p] : xs;
-        P.Xcur[c + P.N * r] = xs;
+    for (int k = 0; k < NP; ++k) {
+        double xs = x[(L * k < D) ? L * k : 0];
+#pragma unroll
+        for (int j = 1; j < L; ++j)
+            if (L * k + j < D) xs = (r == j) ? x[L * k + j] : xs;
+        const int p = r + L * k;
+        if (p < D) P.Xcur[c + P.N * p] = xs;
     }
     if (r == 0) P.lpcur[c] = lp;
 }
