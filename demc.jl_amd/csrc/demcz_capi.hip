@@ -258,8 +258,11 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
                 return bail(DEMCZ_ERR_INVALID_ARGUMENT);
             }
             h->lanes = DEMCZ_LAYOUT_SPLIT;
-        } else if (cfg->lanes_per_chain == 0 && split_ok && cfg->N <= 32768) {
-            h->lanes = DEMCZ_LAYOUT_SPLIT;      // idle CUs do the state-independent three quarters of the work
+        } else if (cfg->lanes_per_chain == 0 && split_ok && cfg->N <= 8192) {
+            // idle CUs do the state-independent three quarters of the work.  Measured at d=5, us per
+            // K-window, split / 8 lanes per chain / 1 lane: N=4096 8.6 / 12.4 / 30.0, N=16384 22.4 / 19.0 /
+            // 32.6, N=32768 41.4 / 29.7 / 35.7, N=65536 77.7 / 54.5 / 40.9
+            h->lanes = DEMCZ_LAYOUT_SPLIT;
         } else if (cfg->lanes_per_chain > 1) {
             if (L != cfg->lanes_per_chain) {
                 h->err = "demcz_create: the requested lanes_per_chain layout is not built for this target / d / block structure";
