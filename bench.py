@@ -43,7 +43,9 @@ def measured_traffic(n_loc, d, lanes):
     f = ROOT / "profiles" / "latest_traffic.json"
     if not f.exists() or (n_loc, d) != (1024, 5):
         return None
-    name = f"window_kernel_ml<0, {d}, {lanes}>" if lanes > 1 else f"window_kernel<0, {d}, true>"
+    if lanes != 100:          # the committed passes were taken with the default (split) layout
+        return None
+    name = f"window_kernel_pc8<0, {d}>"
     for k, v in json.loads(f.read_text())["kernels"].items():
         if name in k:
             return v.get("bytes_per_launch_raw")
