@@ -526,20 +526,12 @@ static bool pc_available(int target_kind, int d, bool full_block)
 
 static int pc_roles(int d) { return ((d == 1) ? 1 : (d + 1) / 2) + 2; }
 
-#ifndef DEMCZ_PC_L1
-constexpr int PC_CONSUMER_CHAINS = 8;       // chains per consumer workgroup: 8 lanes per chain (window_kernel_pc8)
-#else
-constexpr int PC_CONSUMER_CHAINS = 64;      // A/B: one lane per chain (window_kernel_pc)
-#endif
+constexpr int PC_CONSUMER_CHAINS = 8;       // chains per consumer workgroup: 8 lanes per chain
 
 template <int TARGET, int D>
 static void launch_pc(const demcz_handle* h, const WindowParams& P, int64_t blocks)
 {
-#ifndef DEMCZ_PC_L1
     hipLaunchKernelGGL((window_kernel_pc8<TARGET, D>), dim3((unsigned)blocks), dim3(64), 0, h->stream, P);
-#else
-    hipLaunchKernelGGL((window_kernel_pc<TARGET, D>), dim3((unsigned)blocks), dim3(64), 0, h->stream, P);
-#endif
 }
 
 static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P)
@@ -553,18 +545,12 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P)
         case 3: launch_pc<TARGET_MVNORMAL, 3>(h, P, blocks); break;
         case 4: launch_pc<TARGET_MVNORMAL, 4>(h, P, blocks); break;
         case 5: launch_pc<TARGET_MVNORMAL, 5>(h, P, blocks); break;
-#ifndef DEMCZ_PC_L1
         case 8: launch_pc<TARGET_MVNORMAL, 8>(h, P, blocks); break;
         case 10: launch_pc<TARGET_MVNORMAL, 10>(h, P, blocks); break;
-#endif
         default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
         }
     } else {
-#ifndef DEMCZ_PC_L1
         launch_pc<TARGET_ISO_QUAD, 10>(h, P, blocks);
-#else
-        return fail(h, DEMCZ_ERR_STATE, "split layout: target not built");
-#endif
     }
     HIPCHK(h, hipGetLastError());
     return DEMCZ_OK;

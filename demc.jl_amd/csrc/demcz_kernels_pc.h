@@ -29,10 +29,6 @@
 
 namespace demcz {
 
-#ifndef DEMCZ_PC_CHUNK
-#define DEMCZ_PC_CHUNK 5
-#endif
-constexpr int PC_CHUNK = DEMCZ_PC_CHUNK;      // generations whose increments a consumer lane holds in registers
 
 // record layout: rec[(g * (D + 3) + f) * N + c], f = 0..D-1 normals, D log u, D+1 / D+2 row indices (bits)
 template <int D>
@@ -72,131 +68,15 @@ __device__ __forceinline__ void pc_produce(const WindowParams& P, int64_t pb)
     }
 }
 
-template <int TARGET, int D>
-__global__ void __launch_bounds__(64) window_kernel_pc(const WindowParams P)
-{
-    static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "split layout: MvNormal / isotropic targets");
-    if ((int64_t)blockIdx.x >= P.consumer_blocks) {
-        pc_produce<D>(P, (int64_t)blockIdx.x - P.consumer_blocks);
-        return;
-    }
-    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (c >= P.N) return;
-
-    double x[D], muc[D], epsc[D], Wc[(TARGET == TARGET_MVNORMAL) ? D * (D + 1) / 2 : 1];
-#pragma unroll
-    for (int p = 0; p < D; ++p) { x[p] = P.Xcur[c + P.N * p]; muc[p] = P.tp.mu[p]; epsc[p] = P.eps[p]; }
-    if constexpr (TARGET == TARGET_MVNORMAL) {
-#pragma unroll
-        for (int i = 0; i < D * (D + 1) / 2; ++i) Wc[i] = P.tp.Wp[i];
-    }
-    const double c0c = P.tp.c0;
-    double lp = P.lpcur[c];
-    const double scale = (D == 1) ? P.gamma : P.gamma / sqrt((double)(2 * D));
-    int to_b = P.to_boundary;            // countdown to the next K boundary
-    int64_t nb = 0;                      // boundaries passed inside this launch
-
-    // Chunks of PC_CHUNK generations: three branch-free sweeps (row indices; rows, normals, log u;
-    // increments) so that every load of a sweep is in flight before the first one is waited for, then
-    // the state-dependent part from registers.  Generation numbers past the window are clamped (their
-    // values are never applied).  (Measured: prefetching the next chunk's loads under the current
-    // chunk's state-dependent part needs > 256 VGPRs and ran 12.9 vs 9.0 us per window; 10-generation
-    // chunks 10.8 us.)
-    for (int g0 = 0; g0 < P.ngen; g0 += PC_CHUNK) {
-        double delta[PC_CHUNK][D], lgu[PC_CHUNK];
-        {
-            int64_t i1[PC_CHUNK], i2[PC_CHUNK];
-#pragma unroll
-            for (int u = 0; u < PC_CHUNK; ++u) {
-                const int g = (g0 + u < P.ngen) ? g0 + u : P.ngen - 1;
-                i1[u] = __double_as_longlong(P.rec_in[rec_index<D>(P.N, g, D + 1, c)]);
-                i2[u] = __double_as_longlong(P.rec_in[rec_index<D>(P.N, g, D + 2, c)]);
-            }
-            double za[PC_CHUNK][D], zb[PC_CHUNK][D], zt[PC_CHUNK][D];
-#pragma unroll
-            for (int u = 0; u < PC_CHUNK; ++u) {
-                const int g = (g0 + u < P.ngen) ? g0 + u : P.ngen - 1;
-                load_row<D>(P.Z + i1[u] * P.ZS, za[u]);
-                load_row<D>(P.Z + i2[u] * P.ZS, zb[u]);
-                lgu[u] = P.rec_in[rec_index<D>(P.N, g, D, c)];
-#pragma unroll
-                for (int p = 0; p < D; ++p) zt[u][p] = P.rec_in[rec_index<D>(P.N, g, (D == 1) ? 0 : p, c)];
-            }
-#pragma unroll
-            for (int u = 0; u < PC_CHUNK; ++u) {
-#pragma unroll
-                for (int p = 0; p < D; ++p) {
-                    const double diff = za[u][p] - zb[u][p];
-                    const double t1 = scale * diff;
-                    const double t2 = epsc[p] * zt[u][p];
-                    delta[u][p] = t1 + t2;
-                }
-            }
-        }
-        // ---- state-dependent: from registers -------------------------------------------------------------
-#pragma unroll
-        for (int u = 0; u < PC_CHUNK; ++u) {
-            if (g0 + u < P.ngen) {
-                const int gi = g0 + u;
-                double xp[D];
-#pragma unroll
-                for (int p = 0; p < D; ++p) xp[p] = x[p] + delta[u][p];
-                double lpp;
-                if constexpr (TARGET == TARGET_MVNORMAL) {
-                    double q = 0.0;
-#pragma unroll
-                    for (int i = 0; i < D; ++i) {
-                        double acc = Wc[(i * (i + 1)) / 2] * (xp[0] - muc[0]);
-#pragma unroll
-                        for (int j = 1; j <= i; ++j) acc = fma(Wc[(i * (i + 1)) / 2 + j], xp[j] - muc[j], acc);
-                        q = (i == 0) ? acc * acc : fma(acc, acc, q);
-                    }
-                    lpp = fma(-0.5, q, c0c);
-                } else {
-                    double q = 0.0;
-#pragma unroll
-                    for (int i = 0; i < D; ++i) {
-                        const double r = xp[i] - muc[i];
-                        q = (i == 0) ? r * r : fma(r, r, q);
-                    }
-                    lpp = -q;
-                }
-                double dlt = lpp - lp;
-                if (P.temperature) dlt = dlt / P.temperature[gi];
-                const bool acc = lgu[u] < dlt;
-#pragma unroll
-                for (int p = 0; p < D; ++p) x[p] = acc ? xp[p] : x[p];
-                lp = acc ? lpp : lp;
-                const int64_t slot = P.slot_first + gi;
-                if (P.chain) {
-#pragma unroll
-                    for (int p = 0; p < D; ++p) P.chain[c + P.N * (p + (int64_t)D * slot)] = x[p];
-                    P.logobj[c + P.N * slot] = lp;
-                }
-                if (--to_b == 0) {                  // generation divisible by K: runchain!'s append, demcz.jl:88-91
-                    to_b = P.K;
-                    if (P.do_append) store_row<D>(P.Zw + (P.M_append + nb * P.N + c) * P.ZS, x);
-                    if (P.snap) {
-#pragma unroll
-                        for (int p = 0; p < D; ++p) P.snap[nb * P.N * D + c + P.N * p] = x[p];
-                    }
-                    ++nb;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < D; ++p) P.Xcur[c + P.N * p] = x[p];
-    P.lpcur[c] = lp;
-}
-
 // ------------------------------------------------------------------------------------------------
-// K1g: the same split with an 8-lanes-per-chain consumer.  Lane p of a chain's group prefetches what
-// concerns parameter p for a whole chunk of generations at once (row elements, normal, 6 loads a
-// generation, so a 10-generation chunk fits in registers and its two dependent memory hops are paid
-// once per chunk instead of once per 5 generations), forms its increments and shares them through
-// LDS; then every lane of the group runs the state-dependent part redundantly from the whole state
-// (no cross-lane traffic there) and stores its own element of the history row.
+// The consumer: 8 lanes per chain.  Lane p of a chain's group prefetches what concerns parameter p
+// for a whole chunk of generations at once (row elements, normal: 6 loads a generation, so a
+// 10-generation chunk fits in registers and its two dependent memory hops -- record, then archive
+// row -- are paid once per chunk), forms its increments and shares them through LDS; then every lane
+// of the group runs the state-dependent part redundantly from the whole state (no cross-lane traffic
+// there) and stores its own element of the history row.
+// (A one-lane-per-chain consumer has to hold 3d+1 doubles per prefetched generation: 5-generation
+// chunks, 9.0 us per C2 window against 7.0 for this one.)
 // ------------------------------------------------------------------------------------------------
 constexpr int PC8_CHUNK = 10;
 
