@@ -54,7 +54,7 @@ def test_lag_visibility_rule():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("E", [1, 3])
-@pytest.mark.parametrize("lanes", [0, 1])
+@pytest.mark.parametrize("lanes", [0, 1, 8])
 def test_lag_on_gpu_equals_oracle_schedule(E, lanes):
     """Library-applied lag (single handle), RCCL side-stream exchange at nranks=1, host-driven
     in-process shards: all equal the oracle-backed emulation of the same schedule, bit for bit."""

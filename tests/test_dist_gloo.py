@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, local_shards, outdir):
+def _worker(rank, world, port, local_shards, outdir, lag=0):
     for p in (ROOT, ROOT / "oracle", ROOT / "tests"):
         sys.path.insert(0, str(p))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -39,7 +39,7 @@ def _worker(rank, world, port, local_shards, outdir):
     opts = demc.demcopt(d, N=N, K=10, Ngeneration=2000, eps_scale=w["eps_scale"], verbose=False, autostop="Rhat",
                         autostop_every=250, autostop_Rhat=1.15)
     sh = torch_sharding(mode="host", local_shards=local_shards)
-    mc, Z = demc.demcz_sample(w["target"], w["Zinit"], opts, seed=21, engine_factory=OracleEngine, sharding=sh)
+    mc, Z = demc.demcz_sample(w["target"], w["Zinit"], opts, seed=21, engine_factory=OracleEngine, sharding=sh, append_lag=lag)
     np.savez(Path(outdir) / f"rank{rank}.npz", chain=mc.chain, log_obj=mc.log_obj, Z=Z)
     dist.barrier()
     dist.destroy_process_group()
@@ -64,3 +64,23 @@ def test_two_ranks_equal_single_process(tmp_path, local_shards):
         assert np.array_equal(p["Z"], Z)                             # replicated archive identical
         assert np.array_equal(p["chain"], mc.chain[r * N // 2:(r + 1) * N // 2])
         assert np.array_equal(p["log_obj"], mc.log_obj[r * N // 2:(r + 1) * N // 2])
+
+
+def test_two_ranks_deferred_exchange_equal_single_process(tmp_path):
+    """The deferred-visibility schedule (append_lag=2) across two gloo ranks == one process applying the
+    same rule: what a rank may draw from is a function of the generation only."""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), 1, str(tmp_path), 2), nprocs=world, join=True)
+    import demc_jl_amd as demc
+    from oracle_engine import OracleEngine
+    d, N = 5, 16
+    w = demc.workloads.mvnormal_problem(d, N)
+    opts = demc.demcopt(d, N=N, K=10, Ngeneration=2000, eps_scale=w["eps_scale"], verbose=False, autostop="Rhat",
+                        autostop_every=250, autostop_Rhat=1.15)
+    one = demc.Sharding(mode="host", local_shards=1, host_exchange_always=True)
+    mc, Z = demc.demcz_sample(w["target"], w["Zinit"], opts, seed=21, engine_factory=OracleEngine, sharding=one, append_lag=2)
+    G = mc.chain.shape[2]
+    for r in range(world):
+        p = np.load(tmp_path / f"rank{r}.npz")
+        assert p["chain"].shape[2] == G and np.array_equal(p["Z"], Z)
+        assert np.array_equal(p["chain"], mc.chain[r * N // 2:(r + 1) * N // 2])
