@@ -147,20 +147,25 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
             }
         }
         wave_lds_handoff();
+        // the whole chunk's increments into registers first: the LDS latency is paid once, not inside
+        // every generation's dependent chain
+        double dl[CH][DP];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+#pragma unroll
+            for (int j = 0; j < DP / 2; ++j) {
+                const double2 t = reinterpret_cast<const double2*>(sdelta + (gq * CH + u) * DP)[j];
+                dl[u][2 * j] = t.x;
+                dl[u][2 * j + 1] = t.y;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             if (g0 + u < P.ngen) {       // wave-uniform
                 const int gi = g0 + u;
-                double dl[DP];
-#pragma unroll
-                for (int j = 0; j < DP / 2; ++j) {
-                    const double2 t = reinterpret_cast<const double2*>(sdelta + (gq * CH + u) * DP)[j];
-                    dl[2 * j] = t.x;
-                    dl[2 * j + 1] = t.y;
-                }
                 double xp[D];
 #pragma unroll
-                for (int p = 0; p < D; ++p) xp[p] = x[p] + dl[p];
+                for (int p = 0; p < D; ++p) xp[p] = x[p] + dl[u][p];
                 double lpp;
                 if constexpr (TARGET == TARGET_MVNORMAL) {
                     double q = 0.0;
