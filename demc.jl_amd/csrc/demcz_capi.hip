@@ -251,7 +251,7 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         int maxb = 0;
         for (int ib = 0; ib < cfg->Nblocks; ++ib) maxb = std::max(maxb, h->block_offsets[ib + 1] - h->block_offsets[ib]);
         const int L = ml_lanes_available(cfg->target_kind, d, h->full_block, cfg->nobs, maxb, cfg->Nblocks);
-        const bool split_ok = pc_available(cfg->target_kind, d, h->full_block);
+        const bool split_ok = pc_available(cfg->target_kind, d, h->full_block) && cfg->Mcap <= 0xffffffffll;   // 32-bit row indices in the records
         if (cfg->lanes_per_chain == DEMCZ_LAYOUT_SPLIT) {
             if (!split_ok) {
                 h->err = "demcz_create: the split layout is not built for this target / d / block structure";
@@ -568,8 +568,8 @@ static int32_t pc_prepare(demcz_handle* h, WindowParams& P, int64_t next_g, int6
         for (int b = 0; b < 2; ++b) {
             if (h->d_rec[b]) HIPCHK(h, hipFree(h->d_rec[b]));
             h->d_rec[b] = nullptr;
-            HIPCHK(h, hipMalloc((void**)&h->d_rec[b], (size_t)need * (d + 3) * h->cfg.N * sizeof(double)));
-            HIPCHK(h, hipMemsetAsync(h->d_rec[b], 0, (size_t)need * (d + 3) * h->cfg.N * sizeof(double), h->stream));   // row 0: always a legal index
+            HIPCHK(h, hipMalloc((void**)&h->d_rec[b], (size_t)need * (d + 2) * h->cfg.N * sizeof(double)));
+            HIPCHK(h, hipMemsetAsync(h->d_rec[b], 0, (size_t)need * (d + 2) * h->cfg.N * sizeof(double), h->stream));   // row 0: always a legal index
             h->rec_desc[b].valid = false;
         }
         h->rec_cap = need;

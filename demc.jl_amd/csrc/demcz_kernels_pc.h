@@ -30,9 +30,10 @@
 namespace demcz {
 
 
-// record layout: rec[(g * (D + 3) + f) * N + c], f = 0..D-1 normals, D log u, D+1 / D+2 row indices (bits)
+// record layout: rec[(g * (D + 2) + f) * N + c], f = 0..D-1 normals, D log u, D+1 the two row indices
+// packed as 32-bit halves (the split layout is only selected while the archive has < 2^32 rows)
 template <int D>
-__device__ __forceinline__ size_t rec_index(int64_t N, int g, int f, int64_t c) { return ((size_t)g * (D + 3) + f) * (size_t)N + (size_t)c; }
+__device__ __forceinline__ size_t rec_index(int64_t N, int g, int f, int64_t c) { return ((size_t)g * (D + 2) + f) * (size_t)N + (size_t)c; }
 
 template <int D>
 __device__ __forceinline__ void pc_produce(const WindowParams& P, int64_t pb)
@@ -51,8 +52,7 @@ __device__ __forceinline__ void pc_produce(const WindowParams& P, int64_t pb)
     if (role == 0) {
         uint64_t i1, i2;
         draw_rows(r1, r2, (uint64_t)P.next_M, i1, i2);
-        rec[rec_index<D>(P.N, gi, D + 1, c)] = __longlong_as_double((long long)i1);
-        rec[rec_index<D>(P.N, gi, D + 2, c)] = __longlong_as_double((long long)i2);
+        rec[rec_index<D>(P.N, gi, D + 1, c)] = __longlong_as_double((long long)(i1 | (i2 << 32)));
     } else {
         const double lg = dm_log(u_open(r1));
         if (role == S - 1) {
@@ -116,21 +116,23 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
     for (int g0 = 0; g0 < P.ngen; g0 += CH) {
         double lgu[CH];
         {
-            int64_t i1[CH], i2[CH];
+            uint32_t i1[CH], i2[CH];
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 const int g = (g0 + u < P.ngen) ? g0 + u : P.ngen - 1;
-                i1[u] = __double_as_longlong(P.rec_in[rec_index<D>(P.N, g, D + 1, c)]);
-                i2[u] = __double_as_longlong(P.rec_in[rec_index<D>(P.N, g, D + 2, c)]);
+                const uint64_t ii = (uint64_t)__double_as_longlong(P.rec_in[rec_index<D>(P.N, g, D + 1, c)]);
+                i1[u] = (uint32_t)ii;
+                i2[u] = (uint32_t)(ii >> 32);
             }
+            const uint32_t zs = (uint32_t)P.ZS;
             double za[CH][NP], zb[CH][NP], zt[CH][NP];
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 const int g = (g0 + u < P.ngen) ? g0 + u : P.ngen - 1;
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
-                    za[u][k] = P.Z[i1[u] * P.ZS + pk[k]];
-                    zb[u][k] = P.Z[i2[u] * P.ZS + pk[k]];
+                    za[u][k] = P.Z[(uint64_t)i1[u] * zs + (uint32_t)pk[k]];      // one 32x32->64 multiply-add
+                    zb[u][k] = P.Z[(uint64_t)i2[u] * zs + (uint32_t)pk[k]];
                     zt[u][k] = P.rec_in[rec_index<D>(P.N, g, (D == 1) ? 0 : pk[k], c)];
                 }
                 lgu[u] = P.rec_in[rec_index<D>(P.N, g, D, c)];
