@@ -112,6 +112,12 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
     const double scale = (D == 1) ? P.gamma : P.gamma / sqrt((double)(2 * D));
     int to_b = P.to_boundary;
     int64_t nb = 0;
+    // history pointers of this lane's elements, advanced by a uniform stride per generation
+    double* hist[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) hist[k] = P.chain + c + P.N * ((int64_t)pk[k] + (int64_t)D * P.slot_first);
+    double* lobj = P.logobj + c + P.N * P.slot_first;
+    const int64_t hist_stride = P.N * (int64_t)D;
 
     for (int g0 = 0; g0 < P.ngen; g0 += CH) {
         double lgu[CH];
@@ -194,7 +200,6 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
 #pragma unroll
                 for (int p = 0; p < D; ++p) x[p] = acc ? xp[p] : x[p];
                 lp = acc ? lpp : lp;
-                const int64_t slot = P.slot_first + gi;
                 const bool boundary = (--to_b == 0);
                 if (boundary) to_b = P.K;
 #pragma unroll
@@ -205,14 +210,16 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
                         if (L * k + j < D) xs = (r == j) ? x[L * k + j] : xs;
                     const int p = r + L * k;
                     if (p < D) {
-                        if (P.chain) P.chain[c + P.N * (p + (int64_t)D * slot)] = xs;
+                        if (P.chain) *hist[k] = xs;
                         if (boundary) {      // generation divisible by K: runchain!'s append, demcz.jl:88-91
                             if (P.do_append) P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p] = xs;
                             if (P.snap) P.snap[nb * P.N * D + c + P.N * p] = xs;
                         }
                     }
+                    hist[k] += hist_stride;      // next generation's slab: a uniform stride, no per-lane multiply
                 }
-                if (P.chain && r == L - 1) P.logobj[c + P.N * slot] = lp;
+                if (P.chain && r == L - 1) *lobj = lp;
+                lobj += P.N;
                 if (boundary) ++nb;
             }
         }
