@@ -118,6 +118,13 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
     for (int k = 0; k < NP; ++k) hist[k] = P.chain + c + P.N * ((int64_t)pk[k] + (int64_t)D * P.slot_first);
     double* lobj = P.logobj + c + P.N * P.slot_first;
     const int64_t hist_stride = P.N * (int64_t)D;
+    // record pointers of this lane's fields; a generation is a uniform stride further on
+    const double* rec_z[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) rec_z[k] = P.rec_in + (int64_t)((D == 1) ? 0 : pk[k]) * P.N + c;
+    const double* rec_lg = P.rec_in + (int64_t)D * P.N + c;
+    const double* rec_ix = P.rec_in + (int64_t)(D + 1) * P.N + c;
+    const int64_t rec_gs = (int64_t)(D + 2) * P.N;
 
     for (int g0 = 0; g0 < P.ngen; g0 += CH) {
         double lgu[CH];
@@ -126,7 +133,7 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 const int g = (g0 + u < P.ngen) ? g0 + u : P.ngen - 1;
-                const uint64_t ii = (uint64_t)__double_as_longlong(P.rec_in[rec_index<D>(P.N, g, D + 1, c)]);
+                const uint64_t ii = (uint64_t)__double_as_longlong(rec_ix[g * rec_gs]);
                 i1[u] = (uint32_t)ii;
                 i2[u] = (uint32_t)(ii >> 32);
             }
@@ -139,9 +146,9 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
                 for (int k = 0; k < NP; ++k) {
                     za[u][k] = P.Z[(uint64_t)i1[u] * zs + (uint32_t)pk[k]];      // one 32x32->64 multiply-add
                     zb[u][k] = P.Z[(uint64_t)i2[u] * zs + (uint32_t)pk[k]];
-                    zt[u][k] = P.rec_in[rec_index<D>(P.N, g, (D == 1) ? 0 : pk[k], c)];
+                    zt[u][k] = rec_z[k][g * rec_gs];
                 }
-                lgu[u] = P.rec_in[rec_index<D>(P.N, g, D, c)];
+                lgu[u] = rec_lg[g * rec_gs];
             }
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
