@@ -434,6 +434,54 @@ ORACLE_API int oracle_demcz_run(const oracle_problem* p, double* X, double* logp
     return 0;
 }
 
+/* Synchronous schedule with the chains of a generation spread over the host's cores (OpenMP).
+ * Same arithmetic and the same per-chain streams as oracle_demcz_run(..., ORACLE_SCHED_SYNCHRONOUS, ...):
+ * the result is bit-identical for any thread count (tests/test_oracle_sampler.py).  Exists for the
+ * "CPU-omp" baseline row; without -fopenmp it is the serial loop. */
+ORACLE_API int oracle_demcz_run_omp(const oracle_problem* p, double* X, double* logp, double* Z, int64_t* M,
+                                    int64_t g_from, int64_t g_to, double gamma, const double* temperature,
+                                    double* chain_out, double* logobj_out, int64_t* changed_out,
+                                    int do_append, int64_t rng_offset, int nthreads)
+{
+    const int64_t N = p->N;
+    const int d = p->d;
+    if (d > 256 || *M < 2) return 1;
+    const int64_t S = oracle_blocks_per_generation(p);
+    (void)nthreads;
+    for (int64_t g = g_from; g <= g_to; ++g) {
+        const int64_t gi = g - g_from;
+        const double* T = temperature ? &temperature[gi] : NULL;
+        const int64_t Mgen = *M;
+        int64_t changed = 0;
+#pragma omp parallel for schedule(static) reduction(+ : changed) num_threads(nthreads > 0 ? nthreads : 1)
+        for (int64_t c = 0; c < N; ++c) {
+            double x[256];
+            for (int t = 0; t < d; ++t) x[t] = X[c + N * t];
+            double lp = logp[c];
+            const double lp_before = lp;
+            uint64_t blk0 = (uint64_t)(g + rng_offset - 1) * (uint64_t)S;
+            for (int ib = 0; ib < p->Nblocks; ++ib) {
+                block_step(p, Z, Mgen, (uint64_t)(p->chain_id0 + c), blk0, ib, gamma, T, x, &lp, NULL);
+                blk0 += (uint64_t)blockstep_nblk(p->block_offsets[ib + 1] - p->block_offsets[ib]);
+            }
+            for (int t = 0; t < d; ++t) X[c + N * t] = x[t];
+            logp[c] = lp;
+            if (lp != lp_before) ++changed;
+            if (chain_out)
+                for (int t = 0; t < d; ++t) chain_out[c + N * (t + (int64_t)d * gi)] = x[t];
+            if (logobj_out) logobj_out[c + N * gi] = lp;
+        }
+        if (changed_out) changed_out[gi] = changed;
+        if (do_append && (g % p->K) == 0) {
+            if (*M + N > p->Mcap) return 2;
+            for (int64_t c = 0; c < N; ++c)
+                for (int t = 0; t < d; ++t) Z[*M + c + p->Mcap * t] = X[c + N * t];
+            *M += N;
+        }
+    }
+    return 0;
+}
+
 /* Same schedule, but with the reference's O(M) index draw cost emulated
  * (collect(1:M) + deleteat!, demcz.jl:176-178): materialise and shift an M-vector per
  * block-step.  Used only for the "faithful-cost" CPU baseline row; results are identical. */

@@ -182,10 +182,10 @@ def block_step(prob: Problem, Z, M, chain_local, g, ib, gamma, x, lp, temperatur
 
 
 def run(prob: Problem, X, lp, Z, M, g_from, g_to, gamma, temperature=None, schedule=SCHED_SYNCHRONOUS,
-        do_append=True, history=True, native=False, rng_offset=0):
+        do_append=True, history=True, native=False, rng_offset=0, threads=0):
     """Advance generations g_from..g_to (1-based, inclusive) IN PLACE on X (N,d) F-order,
     lp (N,), Z (Mcap,d) F-order.  Returns (M_new, chain (N,d,G) or None, log_obj (N,G) or None,
-    changed (G,))."""
+    changed (G,)).  threads > 0: the OpenMP loop over chains (synchronous schedule only; same bits)."""
     assert X.flags.f_contiguous and X.dtype == np.float64 and X.shape == (prob.N, prob.d)
     assert Z.flags.f_contiguous and Z.dtype == np.float64 and Z.shape == (prob.Mcap, prob.d)
     assert lp.dtype == np.float64 and lp.shape == (prob.N,)
@@ -197,10 +197,18 @@ def run(prob: Problem, X, lp, Z, M, g_from, g_to, gamma, temperature=None, sched
     temp = _f64(temperature) if temperature is not None else None
     if temp is not None:
         assert temp.shape == (G,)
-    rc = lib(native).oracle_demcz_run(C.byref(prob.c), _ptr(X), _ptr(lp), _ptr(Z), C.byref(Mc),
-                                      C.c_int64(g_from), C.c_int64(g_to), C.c_double(gamma), _ptr(temp),
-                                      _ptr(chain), _ptr(lobj), _ptr(changed, _lp),
-                                      C.c_int(schedule), C.c_int(1 if do_append else 0), C.c_int64(rng_offset))
+    if threads > 0:
+        assert schedule == SCHED_SYNCHRONOUS
+        rc = lib(native).oracle_demcz_run_omp(C.byref(prob.c), _ptr(X), _ptr(lp), _ptr(Z), C.byref(Mc),
+                                              C.c_int64(g_from), C.c_int64(g_to), C.c_double(gamma), _ptr(temp),
+                                              _ptr(chain), _ptr(lobj), _ptr(changed, _lp),
+                                              C.c_int(1 if do_append else 0), C.c_int64(rng_offset),
+                                              C.c_int(threads))
+    else:
+        rc = lib(native).oracle_demcz_run(C.byref(prob.c), _ptr(X), _ptr(lp), _ptr(Z), C.byref(Mc),
+                                          C.c_int64(g_from), C.c_int64(g_to), C.c_double(gamma), _ptr(temp),
+                                          _ptr(chain), _ptr(lobj), _ptr(changed, _lp),
+                                          C.c_int(schedule), C.c_int(1 if do_append else 0), C.c_int64(rng_offset))
     if rc != 0:
         raise RuntimeError(f"oracle_demcz_run failed rc={rc}")
     return int(Mc.value), chain, lobj, changed

@@ -1,7 +1,7 @@
 """Chain-updates/s of every BASELINE config that fits one GPU (C2, C3, C4's per-GPU shard, C5) plus
 the CPU rows of BASELINE.md section 2.  Prints one line per row; run on the GPU box.
 usage: python scripts/bench_configs.py [gens]"""
-import sys, time
+import os, sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "oracle"))
@@ -42,6 +42,14 @@ def cpu_rows():
         Z = np.zeros((Mcap, d), order="F"); Z[:M0] = w["Zinit"]
         t0 = time.perf_counter(); O.run(prob, X, lp, Z, M0, 1, Gc, 2.38, schedule=sched, native=True); dt = time.perf_counter() - t0
         print(f"{label:50s} C2 {N*Gc/dt:10.3e} upd/s", flush=True)
+    ncores = os.cpu_count() or 1
+    for thr in sorted({ncores // 2 or 1, ncores}):
+        Mcap = M0 + N * Gc // 10
+        prob = O.Problem(N, d, 10, Mcap, w["eps_scale"], 1, target=w["target"].oracle_spec())
+        X = np.array(w["Zinit"][-N:], order="F"); lp = O.logp(prob, X)
+        Z = np.zeros((Mcap, d), order="F"); Z[:M0] = w["Zinit"]
+        t0 = time.perf_counter(); O.run(prob, X, lp, Z, M0, 1, Gc, 2.38, native=True, threads=thr); dt = time.perf_counter() - t0
+        print(f"{'CPU-omp synchronous, %d threads (of %d cores)' % (thr, ncores):50s} C2 {N*Gc/dt:10.3e} upd/s", flush=True)
     # reference's O(M) index draw (collect(1:M) + deleteat!, demcz.jl:176-178): cost per block-step at archive size M
     L = O.lib(native=True)
     for M in (10**3, 10**5, 10**6):

@@ -336,3 +336,87 @@ def test_no_history_handle_and_closure_anneal(demc, oracle):
     a, Za = demc.demcz_anneal(closure, *args, **kw)
     b, Zb = demc.demcz_anneal(w["target"], *args, **kw)
     assert np.array_equal(a.chain, b.chain) and np.array_equal(Za, Zb)
+
+
+def _engine_run(demc, w, N, d, G, blocks, seed, pieces=None, temperature=None, gamma=None):
+    M0 = w["Zinit"].shape[0]
+    e = demc.HipEngine(N=N, d=d, K=10, Mcap=M0 + N * (G // 10), Gcap=G, blockindex=blocks, eps_scale=w["eps_scale"], seed=seed,
+                       target=w["target"])
+    e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+    g = 1
+    for n in (pieces or [G]):
+        e.run(g, g + n - 1, w["gamma"] if gamma is None else gamma, None if temperature is None else temperature[g - 1:g + n - 1])
+        g += n
+    assert g == G + 1
+    return e
+
+
+def test_full_size_c3_properties(demc, oracle):
+    """BASELINE C3 at full width (d=20 in four blocks of five, N=4096), 4000 generations on the device:
+    first generations against the oracle bit for bit, the run cut into uneven pieces == one call, archive
+    bookkeeping, and the accept band / moments of the reference's predicates (example_normpdf.jl:42-51) once
+    the N(0,1) start has been forgotten (about 2500 generations at d=20: scripts/c3_stats.py)."""
+    d, N, G = 20, 4096, 4000
+    w = demc.workloads.mvnormal_problem(d, N)
+    e = _engine_run(demc, w, N, d, G, BLOCKS_D20, 31953150)
+    ch, lo = e.get_history(1, 12)
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, 10, 12, [list(b) for b in BLOCKS_D20], w["eps_scale"], w["gamma"], 31953150)
+    assert np.array_equal(ch, ref["chain"]) and np.array_equal(lo, ref["log_obj"])
+    X, lp, Z, M = e.get_state()
+    assert M == w["Zinit"].shape[0] + N * (G // 10)
+    last, _ = e.get_history(G, G)
+    assert np.array_equal(Z[-N:], last[:, :, 0]) and np.array_equal(X, last[:, :, 0])
+    acc = e.accept_ratio(G - 999, G)
+    assert np.all(acc > 0.1) and np.all(acc < 0.6), (acc.min(), acc.max())
+    mean, cov = e.mean_cov(G - 999, G)
+    sd = np.sqrt(np.diag(w["Sigma"]))
+    assert np.all(np.abs(mean - w["mu"]) < 0.05 * sd), np.abs((mean - w["mu"]) / sd).max()
+    assert abs(np.trace(cov) / np.trace(w["Sigma"]) - 1) < 0.05
+    rh = e.rhat(G - 999, G)
+    assert np.all(np.isfinite(rh)) and rh.max() < 1.5, rh
+    e.close()
+    e2 = _engine_run(demc, w, N, d, G, BLOCKS_D20, 31953150, pieces=[7, 993, 1, 409, 2590])
+    X2, lp2, Z2, M2 = e2.get_state()
+    e2.close()
+    assert M2 == M and np.array_equal(X2, X) and np.array_equal(lp2, lp) and np.array_equal(Z2, Z)
+
+
+def test_full_size_c4_shards_are_invariant(demc, oracle):
+    """BASELINE C4's shape (d=20, N=8192 as 8 shards of 1024 chains, replicated archive, R-hat autostop
+    statistics reduced across shards): eight handles on the one GPU with the host-driven K-boundary
+    exchange give the bits of one 8192-chain handle, and both start like the oracle."""
+    d, N, G = 20, 8192, 300
+    w = demc.workloads.mvnormal_problem(d, N)
+    opts = demc.demcopt(d, N=N, K=10, Ngeneration=G, eps_scale=w["eps_scale"], verbose=False, autostop="Rhat",
+                        autostop_every=100, autostop_Rhat=1.0)
+    a, Za, ra = demc.demcz_sample(w["target"], w["Zinit"], opts, seed=31953150, return_runner=True)
+    sh = demc.Sharding(rank=0, world_size=1, mode="host", local_shards=8)
+    b, Zb, rb = demc.demcz_sample(w["target"], w["Zinit"], opts, seed=31953150, sharding=sh, return_runner=True)
+    assert np.array_equal(a.chain, b.chain) and np.array_equal(a.log_obj, b.log_obj) and np.array_equal(Za, Zb)
+    assert np.allclose(ra.rhat(101, 300), rb.rhat(101, 300), rtol=1e-11)
+    assert np.array_equal(ra.changed(1, G), rb.changed(1, G))
+    ra.close(); rb.close()
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, 10, 12, None, w["eps_scale"], w["gamma"], 31953150)
+    assert np.array_equal(a.chain[:, :, :12], ref["chain"])
+
+
+def test_full_size_c5_properties(demc, oracle):
+    """BASELINE C5 at full size (regression SSE, d=10, nobs=1000, N=2048, T0=3 -> TN=1e-3 over 10000
+    generations, gamma adaptation on): the first generations against the oracle bit for bit; at the end
+    of the schedule the population sits on the least-squares solution (test/example_linreg.jl:59-66 compares
+    against OLS by eye; here it is asserted) and log_obj never exceeds the optimum."""
+    d, N, G = 10, 2048, 10000
+    w = demc.workloads.linreg_problem(d, N)
+    opts = demc.demcopt(d, N=N, K=10, Ngeneration=G, eps_scale=w["eps_scale"], γ=w["gamma"], verbose=False, T0=3, TN=1e-3,
+                        autostop="no")
+    mc, Z = demc.demcz_anneal(w["target"], w["Zinit"], opts, seed=319531501)
+    beta_ols, *_ = np.linalg.lstsq(w["design"], w["y"], rcond=None)
+    best = -0.5 * np.sum((w["y"] - w["design"] @ beta_ols) ** 2)
+    assert np.all(mc.log_objcurrent <= best * (1 - 1e-12))
+    assert np.all(mc.log_objcurrent > best - 0.05), (best - mc.log_objcurrent).max()
+    assert np.max(np.abs(mc.Xcurrent - beta_ols)) < 0.02
+    assert Z.shape[0] == w["Zinit"].shape[0] + N * (G // 10)
+    G0 = 12
+    temps = np.array([demc.tempbaseline(g, G, 3, 1e-3) for g in range(1, G0 + 1)])
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, 10, G0, None, w["eps_scale"], w["gamma"], 319531501, temperature=temps)
+    assert np.array_equal(mc.chain[:, :, :G0], ref["chain"]) and np.array_equal(mc.log_obj[:, :G0], ref["log_obj"])

@@ -62,3 +62,24 @@ def test_window_split_invariance(oracle):
         chains.append(ch)
         g += step
     assert np.array_equal(np.concatenate(chains, axis=2), a["chain"]) and M == a["M"]
+
+
+def test_openmp_loop_is_bit_identical(oracle):
+    """The CPU-omp baseline row (oracle_demcz_run_omp) is the synchronous schedule spread over threads:
+    same streams, same arithmetic, same bits for any thread count."""
+    from demc_jl_amd import workloads
+    N, d, G, K = 24, 5, 40, 10
+    w = workloads.mvnormal_problem(d, N)
+    M0 = w["Zinit"].shape[0]
+    outs = []
+    for thr in (0, 1, 3):
+        Mcap = M0 + N * G // K
+        prob = oracle.Problem(N, d, K, Mcap, w["eps_scale"], 7, target=w["target"].oracle_spec())
+        X = np.array(w["Zinit"][-N:], order="F"); lp = oracle.logp(prob, X)
+        Z = np.zeros((Mcap, d), order="F"); Z[:M0] = w["Zinit"]
+        M, chain, lobj, changed = oracle.run(prob, X, lp, Z, M0, 1, G, 2.38, threads=thr)
+        outs.append((M, chain, lobj, changed, Z.copy()))
+    for o in outs[1:]:
+        assert o[0] == outs[0][0]
+        for a, b in zip(o[1:], outs[0][1:]):
+            assert np.array_equal(a, b)
