@@ -70,6 +70,10 @@ struct demcz_handle {
     bool gen_open = false;
     // split layout: draw records, double-buffered (this launch reads one, its producer half fills the other)
     double* d_rec[2] = {nullptr, nullptr};
+    unsigned int* d_live_err = nullptr;   // device word a LIVE launch sets when an expected row never appears
+#ifdef DEMCZ_STAMPS
+    unsigned long long* d_stamps = nullptr;
+#endif
     int64_t rec_cap = 0;              // generations each buffer holds
     int rec_cur = 0;
     struct RecDesc { bool valid = false; int64_t g_first = 0; int64_t M = 0; int32_t ngen = 0; } rec_desc[2];
@@ -127,6 +131,7 @@ constexpr size_t ML_MAX_DYNAMIC_LDS = 160 * 1024;      // LDS per CU on gfx950
 static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t nobs, int max_blocklen, int nblocks);
 static bool pc_available(int target_kind, int d, bool full_block);
 static int32_t flush_exchanges(demcz_handle* h);
+static int32_t check_live_err(demcz_handle* h);
 
 extern "C" int32_t demcz_abi_version(void) { return DEMCZ_ABI_VERSION; }
 
@@ -155,6 +160,7 @@ static void free_all(demcz_handle* h)
     h->pending.clear();
     for (int b = 0; b < 2; ++b) {
         if (h->d_rec[b]) (void)hipFree(h->d_rec[b]);
+        if (b == 0 && h->d_live_err) (void)hipFree(h->d_live_err);
         if (h->d_send[b]) (void)hipFree(h->d_send[b]);
         if (h->d_recv[b]) (void)hipFree(h->d_recv[b]);
         if (h->buf_done[b]) (void)hipEventDestroy(h->buf_done[b]);
@@ -280,7 +286,10 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
     const int64_t N = cfg->N;
     h->ZS = (d <= 1) ? 2 : (d <= 2) ? 2 : (d <= 4) ? 4 : ((d + 7) / 8) * 8;     // 16-byte aligned rows; d=5 -> one 64-byte line
     CRCHK(hipMalloc((void**)&h->dZ, (size_t)cfg->Mcap * h->ZS * sizeof(double)));
-    CRCHK(hipMemsetAsync(h->dZ, 0, (size_t)cfg->Mcap * h->ZS * sizeof(double), h->stream));   // zeros(...) demcz.jl:11
+    // (the reference pads with zeros, demcz.jl:11; rows at or beyond M never leave the device, and here they hold
+    //  the sentinel LIVE launches recognise an unpublished row by: fill_unwritten_rows() in demcz_set_state)
+    CRCHK(hipMalloc((void**)&h->d_live_err, sizeof(unsigned int)));
+    CRCHK(hipMemsetAsync(h->d_live_err, 0, sizeof(unsigned int), h->stream));
     CRCHK(hipMalloc((void**)&h->dX, (size_t)N * d * sizeof(double)));
     CRCHK(hipMalloc((void**)&h->dlp, (size_t)N * sizeof(double)));
     if (cfg->Gcap > 0) {
@@ -390,6 +399,13 @@ extern "C" int32_t demcz_set_state(demcz_handle* h, const double* X, const doubl
         hipLaunchKernelGGL(append_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->dZ, h->ZS,
                            (int64_t)0, (const double*)h->d_scratch, M0, M0, d);
         HIPCHK(h, hipGetLastError());
+        const size_t rest = (size_t)(h->cfg.Mcap - M0) * (size_t)h->ZS;
+        if (rest > 0) {
+            hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, h->stream,
+                               reinterpret_cast<unsigned long long*>(h->dZ + (size_t)M0 * h->ZS), rest, LIVE_SENTINEL);
+            HIPCHK(h, hipGetLastError());
+        }
+        HIPCHK(h, hipMemsetAsync(h->d_live_err, 0, sizeof(unsigned int), h->stream));
     }
     if (logp) {
         HIPCHK(h, hipMemcpyAsync(h->dlp, logp, (size_t)N * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -438,7 +454,7 @@ extern "C" int32_t demcz_get_state(demcz_handle* h, double* X, double* logp, dou
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (M) *M = h->M_app;
-    return DEMCZ_OK;
+    return check_live_err(h);
 }
 
 extern "C" int32_t demcz_set_history_origin(demcz_handle* h, int64_t g0)
@@ -524,33 +540,38 @@ static bool pc_available(int target_kind, int d, bool full_block)
     return target_kind == DEMCZ_TARGET_MVNORMAL && (d == 2 || d == 3 || d == 4 || d == 5 || d == 8 || d == 10);
 }
 
-static int pc_roles(int d) { return ((d == 1) ? 1 : (d + 1) / 2) + 2; }
+static int pc_roles(int d) { return ((d == 1) ? 1 : (d + 1) / 2) + 1; }     // producer roles: normal pairs + accept uniform
 
+#ifdef DEMCZ_STAMPS
+constexpr int64_t DEMCZ_STAMP_WGS = 1 << 16;
+#endif
 constexpr int PC_CONSUMER_CHAINS = 8;       // chains per consumer workgroup: 8 lanes per chain
 
 template <int TARGET, int D>
-static void launch_pc(const demcz_handle* h, const WindowParams& P, int64_t blocks)
+static void launch_pc(const demcz_handle* h, const WindowParams& P, int64_t blocks, bool live)
 {
-    hipLaunchKernelGGL((window_kernel_pc8<TARGET, D>), dim3((unsigned)blocks), dim3(64), 0, h->stream, P);
+    if (live) hipLaunchKernelGGL((window_kernel_pc8<TARGET, D, true>), dim3((unsigned)blocks), dim3(64), 0, h->stream, P);
+    else hipLaunchKernelGGL((window_kernel_pc8<TARGET, D, false>), dim3((unsigned)blocks), dim3(64), 0, h->stream, P);
 }
 
-static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P)
+// live: the launch runs through K boundaries whose rows later generations of the SAME launch draw from
+static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool live = false)
 {
     const int64_t nbc = (P.N + 63) / 64;
     const int64_t blocks = P.consumer_blocks + nbc * pc_roles(P.d) * P.next_ngen;
     if (blocks <= 0) return DEMCZ_OK;
     if (h->cfg.target_kind == DEMCZ_TARGET_MVNORMAL) {
         switch (P.d) {
-        case 2: launch_pc<TARGET_MVNORMAL, 2>(h, P, blocks); break;
-        case 3: launch_pc<TARGET_MVNORMAL, 3>(h, P, blocks); break;
-        case 4: launch_pc<TARGET_MVNORMAL, 4>(h, P, blocks); break;
-        case 5: launch_pc<TARGET_MVNORMAL, 5>(h, P, blocks); break;
-        case 8: launch_pc<TARGET_MVNORMAL, 8>(h, P, blocks); break;
-        case 10: launch_pc<TARGET_MVNORMAL, 10>(h, P, blocks); break;
+        case 2: launch_pc<TARGET_MVNORMAL, 2>(h, P, blocks, live); break;
+        case 3: launch_pc<TARGET_MVNORMAL, 3>(h, P, blocks, live); break;
+        case 4: launch_pc<TARGET_MVNORMAL, 4>(h, P, blocks, live); break;
+        case 5: launch_pc<TARGET_MVNORMAL, 5>(h, P, blocks, live); break;
+        case 8: launch_pc<TARGET_MVNORMAL, 8>(h, P, blocks, live); break;
+        case 10: launch_pc<TARGET_MVNORMAL, 10>(h, P, blocks, live); break;
         default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
         }
     } else {
-        launch_pc<TARGET_ISO_QUAD, 10>(h, P, blocks);
+        launch_pc<TARGET_ISO_QUAD, 10>(h, P, blocks, live);
     }
     HIPCHK(h, hipGetLastError());
     return DEMCZ_OK;
@@ -568,15 +589,15 @@ static int32_t pc_prepare(demcz_handle* h, WindowParams& P, int64_t next_g, int6
         for (int b = 0; b < 2; ++b) {
             if (h->d_rec[b]) HIPCHK(h, hipFree(h->d_rec[b]));
             h->d_rec[b] = nullptr;
-            HIPCHK(h, hipMalloc((void**)&h->d_rec[b], (size_t)need * (d + 2) * h->cfg.N * sizeof(double)));
-            HIPCHK(h, hipMemsetAsync(h->d_rec[b], 0, (size_t)need * (d + 2) * h->cfg.N * sizeof(double), h->stream));   // row 0: always a legal index
+            HIPCHK(h, hipMalloc((void**)&h->d_rec[b], (size_t)need * (d + 1) * h->cfg.N * sizeof(double)));
+            HIPCHK(h, hipMemsetAsync(h->d_rec[b], 0, (size_t)need * (d + 1) * h->cfg.N * sizeof(double), h->stream));
             h->rec_desc[b].valid = false;
         }
         h->rec_cap = need;
     }
     const int cur = h->rec_cur;
     auto& dc = h->rec_desc[cur];
-    if (!(dc.valid && dc.g_first == P.g_first && dc.M == P.M && dc.ngen >= P.ngen)) {
+    if (!(dc.valid && dc.g_first == P.g_first && dc.ngen >= P.ngen)) {      // (records do not depend on M: the consumer draws the rows)
         WindowParams Q = P;                 // producer-only launch for THIS window
         Q.consumer_blocks = 0;
         Q.rec_out = h->d_rec[cur];
@@ -636,12 +657,12 @@ static bool try_launch_ml(const demcz_handle* h, const WindowParams& P)
     return false;
 }
 
-static int32_t launch_window(demcz_handle* h, const WindowParams& P)
+static int32_t launch_window(demcz_handle* h, const WindowParams& P, bool live = false)
 {
     const dim3 grid((unsigned)((P.N + WINDOW_BS - 1) / WINDOW_BS));
     const int d = P.d;
     if (h->lanes == DEMCZ_LAYOUT_SPLIT) {
-        int32_t rc = launch_window_pc(h, P);
+        int32_t rc = launch_window_pc(h, P, live);
         if (rc) return rc;
         ++h->launches;
         return DEMCZ_OK;
@@ -760,6 +781,25 @@ static int32_t flush_exchanges(demcz_handle* h)
     return DEMCZ_OK;
 }
 
+// A LIVE launch that gave up waiting for a row leaves a word behind; results after it are void.
+static int32_t check_live_err(demcz_handle* h)
+{
+    unsigned int e = 0;
+    HIPCHK(h, hipMemcpy(&e, h->d_live_err, sizeof(e), hipMemcpyDeviceToHost));
+    if (e) return fail(h, DEMCZ_ERR_HIP, "demcz_run: an archive row appended inside the launch never became visible (LIVE hand-off)");
+    return DEMCZ_OK;
+}
+
+// Generations one LIVE launch of the split layout may span (0: not applicable -- other layouts, sharded
+// runs, deferred visibility, appends owned by the caller).  Bounded by the draw records it needs.
+static int64_t live_span(const demcz_handle* h)
+{
+    if (h->lanes != DEMCZ_LAYOUT_SPLIT || h->comm || h->lag > 0 || h->external_append) return 0;
+    const int64_t per_gen = (int64_t)(h->cfg.d + 1) * h->cfg.N * (int64_t)sizeof(double);
+    const int64_t span = (int64_t)(48ll << 20) / per_gen;
+    return std::max<int64_t>(h->cfg.K, std::min<int64_t>(span, 1 << 20));
+}
+
 extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, double gamma, const double* temperature)
 {
     if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
@@ -809,6 +849,13 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     P.snap = nullptr;
     P.K = K;
     P.rec_in = nullptr; P.rec_out = nullptr; P.next_g_first = 0; P.next_M = 0; P.next_ngen = 0; P.consumer_blocks = 0;
+#ifdef DEMCZ_STAMPS
+    if (!h->d_stamps) {
+        HIPCHK(h, hipMalloc((void**)&h->d_stamps, (size_t)DEMCZ_STAMP_WGS * 8 * sizeof(unsigned long long)));
+        HIPCHK(h, hipMemset(h->d_stamps, 0, (size_t)DEMCZ_STAMP_WGS * 8 * sizeof(unsigned long long)));
+    }
+    P.stamps = h->d_stamps;
+#endif
     const int E = h->lag;
     int64_t g = g_from;
     while (g <= g_to) {
@@ -821,6 +868,10 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
             const int64_t jn = next_boundary / K, J = ((jn + E - 1) / E) * E;
             w_end = std::min(J * (int64_t)K, g_to);
         }
+        // Split layout on one GPU: the launch runs on through the boundaries; waves hand the appended rows
+        // to each other inside it (LIVE, demcz_kernels_pc.h), so the schedule is still the synchronous one.
+        const int64_t live_max = live_span(h);
+        if (live_max > 0) w_end = std::min(g + live_max - 1, g_to);
         int32_t rc = admit_pending(h, g);
         if (rc) return rc;
         const int64_t nbound = w_end / K - (g - 1) / K;           // boundaries inside this launch
@@ -843,24 +894,25 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         }
         if (h->lanes == DEMCZ_LAYOUT_SPLIT) {
             // what the launch after this one will be, so that this launch's producer half can prepare
-            // its draws: it starts at w_end + 1, runs to its own boundary / batch end, and sees ...
+            // its normals and accept uniforms: it starts at w_end + 1 and runs to its own boundary / batch end
+            // (the records do not depend on the archive size; the consumer draws the rows against its own M)
             const int64_t ng = w_end + 1;
             int64_t nend = ((ng - 1) / K + 1) * (int64_t)K;
             if (E > 0 && !h->external_append) nend = ((nend / K + E - 1) / E) * E * (int64_t)K;
-            int64_t nM = h->M, nn = nend - ng + 1;
-            const int64_t rows_n = h->cfg.N * (sharded ? h->nranks : 1);
-            if (h->external_append) nn = 0;                      // the caller appends: M is not ours to predict
-            else if (E == 0) nM = (nbound > 0) ? h->M_app + rows_n : h->M;       // ... the rows appended now
-            else for (const auto& pe : h->pending) if (pe.visible_from <= ng) nM = pe.M_after;   // ... or admitted by then
-            rc = pc_prepare(h, P, ng + h->rng_offset, nn, nM);
+            int64_t nn = nend - ng + 1;
+            if (live_max > 0) nn = std::min(live_max, (w_end < g_to) ? g_to - w_end : G);   // a next call is taken to be as long as this one
+            rc = pc_prepare(h, P, ng + h->rng_offset, nn, 0);
             if (rc) return rc;
         }
-        rc = launch_window(h, P);
+        // boundaries whose rows generations of this same launch draw from
+        const bool live = live_max > 0 && ((w_end - 1) / K - (g - 1) / K) > 0;
+        P.live_err = h->d_live_err;
+        rc = launch_window(h, P, live);
         if (rc) return rc;
         if (nbound > 0 && !h->external_append) {
             const int64_t rows = h->cfg.N * (sharded ? h->nranks : 1);
             if (E == 0) {
-                if (kernel_appends) { h->M_app += rows; h->M = h->M_app; }
+                if (kernel_appends) { h->M_app += nbound * rows; h->M = h->M_app; }
                 else { rc = append_after_window(h); if (rc) return rc; }
             } else {
                 // boundary j belongs to the batch closing at J = ceil(j/E)*E; its rows are drawn from
@@ -897,7 +949,7 @@ extern "C" int32_t demcz_synchronize(demcz_handle* h)
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
-    return DEMCZ_OK;
+    return check_live_err(h);
 }
 
 static int32_t check_hist_range(demcz_handle* h, int64_t g_from, int64_t g_to, const char* who)
@@ -923,7 +975,7 @@ extern "C" int32_t demcz_get_history(demcz_handle* h, int64_t g_from, int64_t g_
         HIPCHK(h, hipMemcpyAsync(log_obj, h->dlogobj + (size_t)N * s0, (size_t)N * G * sizeof(double),
                                  hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return DEMCZ_OK;
+    return check_live_err(h);
 }
 
 extern "C" int32_t demcz_get_changed(demcz_handle* h, int64_t g_from, int64_t g_to, int64_t* changed)
@@ -1428,3 +1480,14 @@ extern "C" int32_t demcz_selftest_draws(int32_t device_id, uint64_t seed, uint64
     if (dl) (void)hipFree(dl);
     return rc;
 }
+
+#ifdef DEMCZ_STAMPS
+// Diagnostic build only: the stamps of the last split-layout launch (8 per workgroup, first `n_wg` workgroups).
+extern "C" int32_t demcz_debug_read_stamps(demcz_handle* h, unsigned long long* out, int64_t n_wg)
+{
+    if (!h || !out || n_wg < 0 || n_wg > DEMCZ_STAMP_WGS || !h->d_stamps) return DEMCZ_ERR_INVALID_ARGUMENT;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, h->d_stamps, (size_t)n_wg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return DEMCZ_OK;
+}
+#endif

@@ -15,6 +15,14 @@
 
 #pragma clang fp contract(off)
 
+// Diagnostic build (-DDEMCZ_STAMPS, never the shipped library): lane 0 of a workgroup records the
+// shader clock at a few points of the split-layout kernel.
+#ifdef DEMCZ_STAMPS
+#define DEMCZ_STAMP(P, i) do { if ((P).stamps && threadIdx.x == 0 && blockIdx.x < 65536u) (P).stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DEMCZ_STAMP(P, i) do { } while (0)
+#endif
+
 namespace demcz {
 
 enum { TARGET_MVNORMAL = 0, TARGET_ISO_QUAD = 1, TARGET_LINREG_SSE = 2, TARGET_HOST_CALLBACK = 3 };
@@ -72,9 +80,13 @@ struct WindowParams {
     const double* rec_in;
     double* rec_out;
     int64_t next_g_first;    // stream generation index of the next launch's first generation
-    int64_t next_M;          // rows its proposals will draw from
+    int64_t next_M;          // (unused since the consumer draws the rows itself)
     int32_t next_ngen;
     int32_t consumer_blocks; // workgroups [0, consumer_blocks) consume, the rest produce
+    unsigned int* live_err;  // LIVE launches: set when a row another wave should have appended never showed up
+#ifdef DEMCZ_STAMPS
+    unsigned long long* stamps;   // diagnostic build only (scripts/stamps.py): 8 s_memtime values per workgroup
+#endif
 };
 
 // One archive row (16-byte aligned) <-> registers, as 16-byte accesses.
@@ -371,6 +383,14 @@ __global__ void logp_kernel(TargetParams tp, int d, const double* X, int64_t ldX
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     out[c] = target_logp<TARGET, 0>(tp, d, [&](int j) { return X[c + ldX * j]; });
+}
+
+// The part of the archive no row has been appended to yet holds `v` (LIVE launches of the split layout,
+// demcz_kernels_pc.h, recognise an unpublished row by it; nothing below row M ever leaves the device).
+__global__ void fill_u64_kernel(unsigned long long* p, size_t n, unsigned long long v)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
 }
 
 // K4: rows (nrows x d column-major, ld ldrows) -> archive rows M .. M+nrows (row-major, stride ZS)

@@ -9,12 +9,15 @@
 // and the chip has 1000 idle SIMDs, so:
 //
 //   producer workgroups (one lane per Philox block of the NEXT launch's generations) write a draw
-//       record per (generation, chain): the D normals, log u of the accept test, the two row indices;
-//   consumer workgroups (one lane per chain) read the records of THIS launch (written by the previous
-//       launch's producers), gather the rows, form the proposal increments for a chunk of generations
-//       up front (all loads in flight together), then run the state-dependent part -- proposal,
-//       log-density, accept, history, K-boundary append -- from registers: ~60 instructions a
-//       generation.
+//       record per (generation, chain): the D normals and log u of the accept test (the expensive
+//       draws: log, sqrt, sincos);
+//   consumer workgroups (eight lanes per chain) read the records of THIS launch (written by the
+//       previous launch's producers) and, while those loads are in flight, draw the two row indices of
+//       a chunk of generations themselves (one Philox block each, no transcendental) so that the
+//       archive gather does not wait for a record: the two memory hops of a chunk overlap instead of
+//       following each other.  They form the proposal increments of the chunk up front, then run the
+//       state-dependent part -- proposal, log-density, accept, history, K-boundary append -- from
+//       registers: ~60 instructions a generation.
 //
 // Both halves are ONE launch (workgroups [0, consumer_blocks) consume, the rest produce), so they
 // overlap on different CUs with no events or second stream; the kernel boundary that already
@@ -30,49 +33,43 @@
 namespace demcz {
 
 
-// record layout: rec[(g * (D + 2) + f) * N + c], f = 0..D-1 normals, D log u, D+1 the two row indices
-// packed as 32-bit halves (the split layout is only selected while the archive has < 2^32 rows)
+// record layout: rec[(g * (D + 1) + f) * N + c], f = 0..D-1 normals, D log u
 template <int D>
-__device__ __forceinline__ size_t rec_index(int64_t N, int g, int f, int64_t c) { return ((size_t)g * (D + 2) + f) * (size_t)N + (size_t)c; }
+__device__ __forceinline__ size_t rec_index(int64_t N, int g, int f, int64_t c) { return ((size_t)g * (D + 1) + f) * (size_t)N + (size_t)c; }
 
 template <int D>
 __device__ __forceinline__ void pc_produce(const WindowParams& P, int64_t pb)
 {
     constexpr int NPAIRS = (D == 1) ? 1 : (D + 1) / 2;
-    constexpr int S = NPAIRS + 2;
+    constexpr int S = NPAIRS + 2;                          // Philox blocks of a generation; block 0 (row indices) is the consumer's
+    constexpr int SP = NPAIRS + 1;                         // producer roles: the normal pairs, then the accept uniform
     const int64_t nbc = (P.N + 63) / 64;                   // workgroups per (generation, role) plane
     const int64_t plane = pb / nbc;                        // wave-uniform
     const int64_t c = (pb % nbc) * 64 + threadIdx.x;
-    const int role = (int)(plane % S), gi = (int)(plane / S);
+    const int role = (int)(plane % SP), gi = (int)(plane / SP);
     if (gi >= P.next_ngen || c >= P.N) return;
     philox_blocks rng;
     uint64_t r1, r2;
-    rng.block(P.seed, (uint64_t)(P.chain_id0 + c), (uint64_t)(P.next_g_first + gi - 1) * (uint64_t)S + (uint64_t)role, r1, r2);
+    rng.block(P.seed, (uint64_t)(P.chain_id0 + c), (uint64_t)(P.next_g_first + gi - 1) * (uint64_t)S + (uint64_t)(role + 1), r1, r2);
     double* rec = P.rec_out;
-    if (role == 0) {
-        uint64_t i1, i2;
-        draw_rows(r1, r2, (uint64_t)P.next_M, i1, i2);
-        rec[rec_index<D>(P.N, gi, D + 1, c)] = __longlong_as_double((long long)(i1 | (i2 << 32)));
+    const double lg = dm_log(u_open(r1));
+    if (role == SP - 1) {
+        rec[rec_index<D>(P.N, gi, D, c)] = lg;
     } else {
-        const double lg = dm_log(u_open(r1));
-        if (role == S - 1) {
-            rec[rec_index<D>(P.N, gi, D, c)] = lg;
-        } else {
-            const double R = sqrt(-2.0 * lg);
-            double cs, sn;
-            dm_sincos2pi(r2 >> 11, cs, sn);
-            const int p0 = (D == 1) ? 0 : 2 * (role - 1);
-            rec[rec_index<D>(P.N, gi, p0, c)] = R * cs;
-            if (p0 + 1 < D) rec[rec_index<D>(P.N, gi, p0 + 1, c)] = R * sn;
-        }
+        const double R = sqrt(-2.0 * lg);
+        double cs, sn;
+        dm_sincos2pi(r2 >> 11, cs, sn);
+        const int p0 = (D == 1) ? 0 : 2 * role;
+        rec[rec_index<D>(P.N, gi, p0, c)] = R * cs;
+        if (p0 + 1 < D) rec[rec_index<D>(P.N, gi, p0 + 1, c)] = R * sn;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // The consumer: 8 lanes per chain.  Lane p of a chain's group prefetches what concerns parameter p
-// for a whole chunk of generations at once (row elements, normal: 6 loads a generation, so a
-// 10-generation chunk fits in registers and its two dependent memory hops -- record, then archive
-// row -- are paid once per chunk), forms its increments and shares them through LDS; then every lane
+// for a whole chunk of generations at once (row elements, normal: 3 loads a generation, so a
+// 10-generation chunk fits in registers and its memory latency -- records beside archive rows --
+// is paid once per chunk), forms its increments and shares them through LDS; then every lane
 // of the group runs the state-dependent part redundantly from the whole state (no cross-lane traffic
 // there) and stores its own element of the history row.
 // (A one-lane-per-chain consumer has to hold 3d+1 doubles per prefetched generation: 5-generation
@@ -80,21 +77,55 @@ __device__ __forceinline__ void pc_produce(const WindowParams& P, int64_t pb)
 // ------------------------------------------------------------------------------------------------
 constexpr int PC8_CHUNK = 10;
 
-template <int TARGET, int D>
+// LIVE launches (single GPU, the reference's immediate visibility): one launch runs through several
+// K boundaries.  The rows a boundary appends are drawn from in the very next generation, by any chain,
+// so waves hand rows to each other INSIDE the launch, and they do it through the data itself:
+//   * the unwritten part of the archive holds a sentinel (a signalling-NaN pattern no arithmetic
+//     produces: results have the quiet bit set);
+//   * a wave appends its chains' rows with write-through (sc1) 8-byte stores;
+//   * every archive gather of such a launch is an sc1 load (served past the CU's L1) and is repeated
+//     while it returns the sentinel -- each double is its own naturally aligned 8-byte granule, so
+//     nothing needs ordering, flags, fences or a grid barrier (MI355X_MICROARCH.md, inter-workgroup
+//     visibility: sc1 stores + sc1 loads, data-tagged granules).
+// A wave only ever waits for rows of an EARLIER boundary than the one it is working towards, so the
+// waits cannot form a cycle; all consumer workgroups are single waves and co-resident (N <= 8192:
+// at most 1024 of them on 256 CUs).  A bounded spin turns a lost row into an error word, not a hang.
+constexpr unsigned long long LIVE_SENTINEL = 0xFFF4DEADC0DE5EEDull;
+constexpr int LIVE_SPIN_LIMIT = 1 << 20;
+
+__device__ __forceinline__ double live_load(const double* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void live_store(double* p, double v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool is_sentinel(double v) { return (unsigned long long)__double_as_longlong(v) == LIVE_SENTINEL; }
+
+template <int TARGET, int D, bool LIVE>
 __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
 {
     static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "split layout: MvNormal / isotropic targets");
     constexpr int L = 8, G = 64 / L, DP = ((D + 1) / 2) * 2;
     constexpr int NP = (D + L - 1) / L;                    // parameters a lane prefetches: r, r+8, ...
     constexpr int CH = (NP == 1) ? PC8_CHUNK : PC8_CHUNK / 2;
+    DEMCZ_STAMP(P, 0);
     if ((int64_t)blockIdx.x >= P.consumer_blocks) {
         pc_produce<D>(P, (int64_t)blockIdx.x - P.consumer_blocks);
+        DEMCZ_STAMP(P, 7);
         return;
     }
+    constexpr int NPAIRS = (D == 1) ? 1 : (D + 1) / 2, S = NPAIRS + 2;
+    constexpr int ITEMS = G * CH, ROUNDS = (ITEMS + 63) / 64;         // (chain, generation) index draws of a chunk, per wave
     __shared__ __attribute__((aligned(16))) double sdelta[G * CH * DP];
+    __shared__ __attribute__((aligned(16))) uint64_t sidx[G * CH];
     const int lane = threadIdx.x, r = lane % L, gq = lane / L;
-    const int64_t c = (int64_t)blockIdx.x * G + gq;
-    if (c >= P.N) return;
+    // every lane of the wave stays: it draws row indices for the whole wave (below).  Groups beyond the
+    // last chain shadow chain N-1 and store nothing.
+    const int64_t c_own = (int64_t)blockIdx.x * G + gq;
+    const bool live = c_own < P.N;
+    const int64_t c = live ? c_own : P.N - 1;
 
     double x[D], muc[D], Wc[(TARGET == TARGET_MVNORMAL) ? D * (D + 1) / 2 : 1];
 #pragma unroll
@@ -123,33 +154,114 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
 #pragma unroll
     for (int k = 0; k < NP; ++k) rec_z[k] = P.rec_in + (int64_t)((D == 1) ? 0 : pk[k]) * P.N + c;
     const double* rec_lg = P.rec_in + (int64_t)D * P.N + c;
-    const double* rec_ix = P.rec_in + (int64_t)(D + 1) * P.N + c;
-    const int64_t rec_gs = (int64_t)(D + 2) * P.N;
+    const int64_t rec_gs = (int64_t)(D + 1) * P.N;
+    // the index draws this lane makes for its wave: item t = (generation of the chunk) * G + (chain of the wave)
+    uint64_t my_chain[ROUNDS];
+    int my_u[ROUNDS];
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int t = (rd * 64 + lane < ITEMS) ? rd * 64 + lane : ITEMS - 1;
+        const int64_t cc = (int64_t)blockIdx.x * G + (t % G);
+        my_chain[rd] = (uint64_t)(P.chain_id0 + ((cc < P.N) ? cc : P.N - 1));
+        my_u[rd] = t / G;
+    }
+    const uint32_t M32 = (uint32_t)P.M;                              // < 2^32 rows: condition of this layout
+    // LIVE: generation gi of the launch (0-based) sees the rows of the boundaries before it:
+    // (gi + K - to_boundary) / K of them, N rows each
+    const uint32_t Ku = (uint32_t)P.K, N32 = (uint32_t)P.N, boff = (uint32_t)(P.K - P.to_boundary);
+    const float rK = 1.0f / (float)P.K;
 
-    for (int g0 = 0; g0 < P.ngen; g0 += CH) {
+    // A chunk is up to CH generations whose draws are fetched together.  In a LIVE launch it also ends at
+    // the next K boundary: the generation after a boundary draws from rows that are only being written
+    // while this chunk computes (K = 1: one generation per chunk).
+    int len = 0;
+    for (int g0 = 0; g0 < P.ngen; g0 += len) {
+        len = (P.ngen - g0 < CH) ? P.ngen - g0 : CH;
+        if constexpr (LIVE) len = (to_b < len) ? to_b : len;
         double lgu[CH];
         {
+            // records first: their latency runs beside the index draws and the archive gather
+            double za[CH][NP], zb[CH][NP], zt[CH][NP];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int g = g0 + ((u < len) ? u : len - 1);
+#pragma unroll
+                for (int k = 0; k < NP; ++k) zt[u][k] = rec_z[k][g * rec_gs];
+                lgu[u] = rec_lg[g * rec_gs];
+            }
+            // the two archive rows of every (chain, generation) of the chunk: block 0 of the generation's
+            // Philox blocks (update_demcz_chain_block, demcz.jl:176-179), one draw per lane and round
+#pragma unroll
+            for (int rd = 0; rd < ROUNDS; ++rd) {
+                const int gu = g0 + ((my_u[rd] < len) ? my_u[rd] : len - 1);
+                philox_blocks rng;
+                uint64_t r1, r2;
+                rng.block(P.seed, my_chain[rd], (uint64_t)(P.g_first + gu - 1) * (uint64_t)S, r1, r2);
+                uint32_t Mv = M32;
+                if constexpr (LIVE) {
+                    const uint32_t a = (uint32_t)gu + boff;              // exact floor(a / K), a < 2^22
+                    uint32_t q = (uint32_t)((float)a * rK);
+                    q -= (q * Ku > a) ? 1u : 0u;
+                    q += ((q + 1u) * Ku <= a) ? 1u : 0u;
+                    Mv = M32 + q * N32;
+                }
+                const uint64_t i1 = mulhi64_u32(r1, Mv);
+                const uint64_t j = mulhi64_u32(r2, Mv - 1u);
+                const uint64_t i2 = j + (j >= i1 ? 1ull : 0ull);
+                if (rd * 64 + lane < ITEMS) sidx[(rd * 64 + lane) % G * CH + (rd * 64 + lane) / G] = i1 | (i2 << 32);
+            }
+            if (g0 == 0) DEMCZ_STAMP(P, 1);
+            wave_lds_handoff();
             uint32_t i1[CH], i2[CH];
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
-                const int g = (g0 + u < P.ngen) ? g0 + u : P.ngen - 1;
-                const uint64_t ii = (uint64_t)__double_as_longlong(rec_ix[g * rec_gs]);
+                const uint64_t ii = sidx[gq * CH + u];
                 i1[u] = (uint32_t)ii;
                 i2[u] = (uint32_t)(ii >> 32);
             }
             const uint32_t zs = (uint32_t)P.ZS;
-            double za[CH][NP], zb[CH][NP], zt[CH][NP];
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
-                const int g = (g0 + u < P.ngen) ? g0 + u : P.ngen - 1;
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
-                    za[u][k] = P.Z[(uint64_t)i1[u] * zs + (uint32_t)pk[k]];      // one 32x32->64 multiply-add
-                    zb[u][k] = P.Z[(uint64_t)i2[u] * zs + (uint32_t)pk[k]];
-                    zt[u][k] = rec_z[k][g * rec_gs];
+                    if constexpr (LIVE) {
+                        za[u][k] = live_load(&P.Z[(uint64_t)i1[u] * zs + (uint32_t)pk[k]]);
+                        zb[u][k] = live_load(&P.Z[(uint64_t)i2[u] * zs + (uint32_t)pk[k]]);
+                    } else {
+                        za[u][k] = P.Z[(uint64_t)i1[u] * zs + (uint32_t)pk[k]];      // one 32x32->64 multiply-add
+                        zb[u][k] = P.Z[(uint64_t)i2[u] * zs + (uint32_t)pk[k]];
+                    }
                 }
-                lgu[u] = rec_lg[g * rec_gs];
             }
+            // nothing that waits for a record may be scheduled in front of the gather's issue
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (LIVE) {
+                // rows another wave has not published yet read as the sentinel: ask again
+                bool bad = false;
+#pragma unroll
+                for (int u = 0; u < CH; ++u)
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) bad |= is_sentinel(za[u][k]) | is_sentinel(zb[u][k]);
+                int spins = 0;
+                while (__builtin_amdgcn_ballot_w64(bad) != 0ull) {           // wave-uniform
+                    if (++spins > LIVE_SPIN_LIMIT) {
+                        if (lane == 0) atomicExch(P.live_err, 1u);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    bad = false;
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) {
+#pragma unroll
+                        for (int k = 0; k < NP; ++k) {
+                            if (is_sentinel(za[u][k])) za[u][k] = live_load(&P.Z[(uint64_t)i1[u] * zs + (uint32_t)pk[k]]);
+                            if (is_sentinel(zb[u][k])) zb[u][k] = live_load(&P.Z[(uint64_t)i2[u] * zs + (uint32_t)pk[k]]);
+                            bad |= is_sentinel(za[u][k]) | is_sentinel(zb[u][k]);
+                        }
+                    }
+                }
+            }
+            if (g0 == 0) DEMCZ_STAMP(P, 2);
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
 #pragma unroll
@@ -161,6 +273,7 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
                 }
             }
         }
+        if (g0 == 0) DEMCZ_STAMP(P, 3);
         wave_lds_handoff();
         // the whole chunk's increments into registers first: the LDS latency is paid once, not inside
         // every generation's dependent chain
@@ -176,7 +289,7 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
         }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-            if (g0 + u < P.ngen) {       // wave-uniform
+            if (u < len) {       // wave-uniform
                 const int gi = g0 + u;
                 double xp[D];
 #pragma unroll
@@ -216,20 +329,24 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
                     for (int j = 1; j < L; ++j)
                         if (L * k + j < D) xs = (r == j) ? x[L * k + j] : xs;
                     const int p = r + L * k;
-                    if (p < D) {
+                    if (p < D && live) {
                         if (P.chain) *hist[k] = xs;
                         if (boundary) {      // generation divisible by K: runchain!'s append, demcz.jl:88-91
-                            if (P.do_append) P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p] = xs;
+                            if (P.do_append) {
+                                if constexpr (LIVE) live_store(&P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p], xs);
+                                else P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p] = xs;
+                            }
                             if (P.snap) P.snap[nb * P.N * D + c + P.N * p] = xs;
                         }
                     }
                     hist[k] += hist_stride;      // next generation's slab: a uniform stride, no per-lane multiply
                 }
-                if (P.chain && r == L - 1) *lobj = lp;
+                if (P.chain && r == L - 1 && live) *lobj = lp;
                 lobj += P.N;
                 if (boundary) ++nb;
             }
         }
+        if (g0 == 0) DEMCZ_STAMP(P, 4);
         wave_lds_handoff();      // sdelta is rewritten by the next chunk
     }
 #pragma unroll
@@ -239,9 +356,10 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
         for (int j = 1; j < L; ++j)
             if (L * k + j < D) xs = (r == j) ? x[L * k + j] : xs;
         const int p = r + L * k;
-        if (p < D) P.Xcur[c + P.N * p] = xs;
+        if (p < D && live) P.Xcur[c + P.N * p] = xs;
     }
-    if (r == 0) P.lpcur[c] = lp;
+    if (r == 0 && live) P.lpcur[c] = lp;
+    DEMCZ_STAMP(P, 7);
 }
 
 }  // namespace demcz

@@ -1,0 +1,56 @@
+"""Where a split-layout launch spends its time: shader-clock stamps written by a diagnostic build
+(-DDEMCZ_STAMPS, build_ab/stamps.so; never the shipped library).
+usage: python scripts/stamps.py [K] [generations] [append_lag]   (run on the GPU box)"""
+import ctypes as C
+import os
+import subprocess
+import sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+so = ROOT / "build_ab" / "stamps.so"
+if not so.exists():
+    so.parent.mkdir(exist_ok=True)
+    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-pass-failed",
+                    "-DDEMCZ_STAMPS", "-o", str(so), str(ROOT / "demc.jl_amd" / "csrc" / "demcz_capi.hip"), "-lrccl"], check=True)
+os.environ["DEMCZ_LIB"] = str(so)
+sys.path.insert(0, str(ROOT))
+import numpy as np
+import demc_jl_amd as demc
+from demc_jl_amd import _lib
+
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+lag = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+N, d = 1024, 5
+w = demc.workloads.mvnormal_problem(d, N)
+M0 = w["Zinit"].shape[0]
+e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K + 1), Gcap=G, blockindex=[range(d)], eps_scale=w["eps_scale"], seed=1,
+                   target=w["target"])
+if lag:
+    e.set_append_lag(lag)
+e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+e.run(1, G, 2.38)
+e.synchronize()
+lib = _lib.load()
+ncons = (N + 7) // 8
+nprod = ((N + 63) // 64) * 3 * (K * max(lag, 1))
+nwg = ncons + nprod
+buf = np.zeros((nwg, 8), dtype=np.uint64)
+lib.demcz_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+rc = lib.demcz_debug_read_stamps(e._h, buf.ctypes.data_as(C.c_void_p), nwg)
+assert rc == 0, rc
+s = buf.astype(np.int64)
+t00 = s[:, 0].min()
+c = s[:ncons]
+print(f"stamps of the last launch (K={K}, lag={lag}); shader-clock ticks; consumer workgroups: {ncons}, producer: {nprod}")
+print(f"entry skew over all workgroups: {s[:,0].max() - t00} ticks; consumers enter at {np.mean(c[:,0]-t00):.0f} (mean) / {np.max(c[:,0]-t00)} (max)")
+names = {1: "row indices drawn (Philox + LDS write)", 2: "records and gathers issued", 3: "all loads back, increments in LDS",
+         4: "first chunk of generations done", 7: "exit"}
+for i in (1, 2, 3, 4, 7):
+    dt = c[:, i] - c[:, 0]
+    print(f"  consumer +{np.mean(dt):8.0f} mean  {np.min(dt):6d} min {np.max(dt):6d} max   {names[i]}")
+p = s[ncons:nwg]
+ok = p[:, 7] > 0
+print(f"  producer: {ok.sum()} workgroups wrote; body {np.mean((p[ok,7]-p[ok,0])):.0f} mean {np.max(p[ok,7]-p[ok,0])} max; last exit at {np.max(p[ok,7])-t00} after the first entry")
+print(f"  last consumer exit at {np.max(c[:,7]) - t00} after the first entry")
+e.close()
