@@ -45,7 +45,7 @@ def measured_traffic(n_loc, d, lanes):
         return None
     if lanes != 100:          # the committed passes were taken with the default (split) layout
         return None
-    name = f"window_kernel_pc8<0, {d}>"
+    name = f"window_kernel_pc8<0, {d},"
     for k, v in json.loads(f.read_text())["kernels"].items():
         if name in k:
             return v.get("bytes_per_launch_raw")

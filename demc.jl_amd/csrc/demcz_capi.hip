@@ -550,8 +550,14 @@ constexpr int PC_CONSUMER_CHAINS = 8;       // chains per consumer workgroup: 8 
 template <int TARGET, int D>
 static void launch_pc(const demcz_handle* h, const WindowParams& P, int64_t blocks, bool live)
 {
-    if (live) hipLaunchKernelGGL((window_kernel_pc8<TARGET, D, true>), dim3((unsigned)blocks), dim3(64), 0, h->stream, P);
-    else hipLaunchKernelGGL((window_kernel_pc8<TARGET, D, false>), dim3((unsigned)blocks), dim3(64), 0, h->stream, P);
+    const dim3 grid((unsigned)blocks), wg(64);
+    if (P.temperature) {      // tempered accept (demcz_anneal.jl:172-178): its own instantiation, no branch per generation
+        if (live) hipLaunchKernelGGL((window_kernel_pc8<TARGET, D, true, true>), grid, wg, 0, h->stream, P);
+        else hipLaunchKernelGGL((window_kernel_pc8<TARGET, D, false, true>), grid, wg, 0, h->stream, P);
+    } else {
+        if (live) hipLaunchKernelGGL((window_kernel_pc8<TARGET, D, true, false>), grid, wg, 0, h->stream, P);
+        else hipLaunchKernelGGL((window_kernel_pc8<TARGET, D, false, false>), grid, wg, 0, h->stream, P);
+    }
 }
 
 // live: the launch runs through K boundaries whose rows later generations of the SAME launch draw from

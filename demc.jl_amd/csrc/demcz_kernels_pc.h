@@ -103,7 +103,7 @@ __device__ __forceinline__ void live_store(double* p, double v)
 }
 __device__ __forceinline__ bool is_sentinel(double v) { return (unsigned long long)__double_as_longlong(v) == LIVE_SENTINEL; }
 
-template <int TARGET, int D, bool LIVE>
+template <int TARGET, int D, bool LIVE, bool TEMPER>
 __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
 {
     static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "split layout: MvNormal / isotropic targets");
@@ -143,12 +143,37 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
     const double scale = (D == 1) ? P.gamma : P.gamma / sqrt((double)(2 * D));
     int to_b = P.to_boundary;
     int64_t nb = 0;
-    // history pointers of this lane's elements, advanced by a uniform stride per generation
-    double* hist[NP];
+    // What a lane stores every generation: its own element(s) of the history row -- tracked beside the
+    // replicated state (own' = own + its increment: the same addition on the same values) -- and, where
+    // the group has a lane to spare (D < 8), lane D stores log_obj in the same instruction.  Pointers
+    // advance by a per-lane stride; lanes with nothing to store are masked off once, here.
+    constexpr bool LP_MERGED = (D < L);
+    double own[NP];
 #pragma unroll
-    for (int k = 0; k < NP; ++k) hist[k] = P.chain + c + P.N * ((int64_t)pk[k] + (int64_t)D * P.slot_first);
-    double* lobj = P.logobj + c + P.N * P.slot_first;
-    const int64_t hist_stride = P.N * (int64_t)D;
+    for (int k = 0; k < NP; ++k) {
+        own[k] = x[(L * k < D) ? L * k : 0];
+#pragma unroll
+        for (int j = 1; j < L; ++j)
+            if (L * k + j < D) own[k] = (r == j) ? x[L * k + j] : own[k];
+    }
+    const bool lp_lane = LP_MERGED ? (r == D) : (r == L - 1);
+    const bool hist_on = (P.chain != nullptr) && live;
+    double* sptr[NP];
+    int64_t sstride[NP];
+    bool son[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const bool xl = (r + L * k < D);
+        sptr[k] = P.chain + c + P.N * ((int64_t)pk[k] + (int64_t)D * P.slot_first);
+        sstride[k] = P.N * (int64_t)D;
+        son[k] = hist_on && xl;
+        if (LP_MERGED && k == 0 && lp_lane) {
+            sptr[k] = P.logobj + c + P.N * P.slot_first;
+            sstride[k] = P.N;
+            son[k] = hist_on;
+        }
+    }
+    double* lobj = P.logobj + c + P.N * P.slot_first;      // D >= 8 only: lane 7 stores log_obj separately
     // record pointers of this lane's fields; a generation is a uniform stride further on
     const double* rec_z[NP];
 #pragma unroll
@@ -165,20 +190,22 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
         my_chain[rd] = (uint64_t)(P.chain_id0 + ((cc < P.N) ? cc : P.N - 1));
         my_u[rd] = t / G;
     }
-    const uint32_t M32 = (uint32_t)P.M;                              // < 2^32 rows: condition of this layout
-    // LIVE: generation gi of the launch (0-based) sees the rows of the boundaries before it:
-    // (gi + K - to_boundary) / K of them, N rows each
-    const uint32_t Ku = (uint32_t)P.K, N32 = (uint32_t)P.N, boff = (uint32_t)(P.K - P.to_boundary);
-    const float rK = 1.0f / (float)P.K;
+    uint32_t Mv = (uint32_t)P.M;       // rows the chunk's proposals draw from (< 2^32: condition of this layout);
+                                       // LIVE: grows by N at every boundary the launch passes
+    const uint32_t N32 = (uint32_t)P.N;
 
-    // A chunk is up to CH generations whose draws are fetched together.  In a LIVE launch it also ends at
-    // the next K boundary: the generation after a boundary draws from rows that are only being written
-    // while this chunk computes (K = 1: one generation per chunk).
+    // A chunk is up to CH generations whose draws are fetched together.  It ends at the next K boundary:
+    // the append then sits between chunks, not inside the generation code, and in a LIVE launch the
+    // generation after a boundary draws from rows that are only being written while this chunk computes
+    // (K = 1: one generation per chunk).
     int len = 0;
+    [[maybe_unused]] const int stamp_g0 = (P.ngen > 5 * CH) ? 5 * CH : 0;      // diagnostic build: the chunk that is timed
     for (int g0 = 0; g0 < P.ngen; g0 += len) {
+        if (g0 == stamp_g0) DEMCZ_STAMP(P, 5);
         len = (P.ngen - g0 < CH) ? P.ngen - g0 : CH;
-        if constexpr (LIVE) len = (to_b < len) ? to_b : len;
-        double lgu[CH];
+        len = (to_b < len) ? to_b : len;
+        double lgu[CH], dmine[CH][NP];
+        [[maybe_unused]] double tmpr[CH];
         {
             // records first: their latency runs beside the index draws and the archive gather
             double za[CH][NP], zb[CH][NP], zt[CH][NP];
@@ -188,6 +215,7 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
 #pragma unroll
                 for (int k = 0; k < NP; ++k) zt[u][k] = rec_z[k][g * rec_gs];
                 lgu[u] = rec_lg[g * rec_gs];
+                if constexpr (TEMPER) tmpr[u] = P.temperature[g];
             }
             // the two archive rows of every (chain, generation) of the chunk: block 0 of the generation's
             // Philox blocks (update_demcz_chain_block, demcz.jl:176-179), one draw per lane and round
@@ -197,20 +225,12 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
                 philox_blocks rng;
                 uint64_t r1, r2;
                 rng.block(P.seed, my_chain[rd], (uint64_t)(P.g_first + gu - 1) * (uint64_t)S, r1, r2);
-                uint32_t Mv = M32;
-                if constexpr (LIVE) {
-                    const uint32_t a = (uint32_t)gu + boff;              // exact floor(a / K), a < 2^22
-                    uint32_t q = (uint32_t)((float)a * rK);
-                    q -= (q * Ku > a) ? 1u : 0u;
-                    q += ((q + 1u) * Ku <= a) ? 1u : 0u;
-                    Mv = M32 + q * N32;
-                }
                 const uint64_t i1 = mulhi64_u32(r1, Mv);
                 const uint64_t j = mulhi64_u32(r2, Mv - 1u);
                 const uint64_t i2 = j + (j >= i1 ? 1ull : 0ull);
                 if (rd * 64 + lane < ITEMS) sidx[(rd * 64 + lane) % G * CH + (rd * 64 + lane) / G] = i1 | (i2 << 32);
             }
-            if (g0 == 0) DEMCZ_STAMP(P, 1);
+            if (g0 == stamp_g0) DEMCZ_STAMP(P, 1);
             wave_lds_handoff();
             uint32_t i1[CH], i2[CH];
 #pragma unroll
@@ -235,6 +255,7 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
             }
             // nothing that waits for a record may be scheduled in front of the gather's issue
             __builtin_amdgcn_sched_barrier(0);
+            if (g0 == stamp_g0) DEMCZ_STAMP(P, 2);
             if constexpr (LIVE) {
                 // rows another wave has not published yet read as the sentinel: ask again
                 bool bad = false;
@@ -261,7 +282,6 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
                     }
                 }
             }
-            if (g0 == 0) DEMCZ_STAMP(P, 2);
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
 #pragma unroll
@@ -269,11 +289,12 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
                     const double diff = za[u][k] - zb[u][k];
                     const double t1 = scale * diff;
                     const double t2 = epsv[k] * zt[u][k];
-                    if (r + L * k < D) sdelta[(gq * CH + u) * DP + r + L * k] = t1 + t2;
+                    dmine[u][k] = t1 + t2;
+                    if (r + L * k < D) sdelta[(gq * CH + u) * DP + r + L * k] = dmine[u][k];
                 }
             }
         }
-        if (g0 == 0) DEMCZ_STAMP(P, 3);
+        if (g0 == stamp_g0) DEMCZ_STAMP(P, 3);
         wave_lds_handoff();
         // the whole chunk's increments into registers first: the LDS latency is paid once, not inside
         // every generation's dependent chain
@@ -290,7 +311,6 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             if (u < len) {       // wave-uniform
-                const int gi = g0 + u;
                 double xp[D];
 #pragma unroll
                 for (int p = 0; p < D; ++p) xp[p] = x[p] + dl[u][p];
@@ -315,48 +335,49 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
                     lpp = -q;
                 }
                 double dlt = lpp - lp;
-                if (P.temperature) dlt = dlt / P.temperature[gi];
+                if constexpr (TEMPER) dlt = dlt / tmpr[u];
                 const bool acc = lgu[u] < dlt;
 #pragma unroll
                 for (int p = 0; p < D; ++p) x[p] = acc ? xp[p] : x[p];
                 lp = acc ? lpp : lp;
-                const bool boundary = (--to_b == 0);
-                if (boundary) to_b = P.K;
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
-                    double xs = x[(L * k < D) ? L * k : 0];
-#pragma unroll
-                    for (int j = 1; j < L; ++j)
-                        if (L * k + j < D) xs = (r == j) ? x[L * k + j] : xs;
-                    const int p = r + L * k;
-                    if (p < D && live) {
-                        if (P.chain) *hist[k] = xs;
-                        if (boundary) {      // generation divisible by K: runchain!'s append, demcz.jl:88-91
-                            if (P.do_append) {
-                                if constexpr (LIVE) live_store(&P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p], xs);
-                                else P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p] = xs;
-                            }
-                            if (P.snap) P.snap[nb * P.N * D + c + P.N * p] = xs;
-                        }
-                    }
-                    hist[k] += hist_stride;      // next generation's slab: a uniform stride, no per-lane multiply
+                    const double ownp = own[k] + dmine[u][k];
+                    own[k] = acc ? ownp : own[k];
+                    const double val = (LP_MERGED && k == 0 && lp_lane) ? lp : own[k];
+                    if (son[k]) *sptr[k] = val;
+                    sptr[k] += sstride[k];       // next generation's slab: a stride, no per-lane multiply
                 }
-                if (P.chain && r == L - 1 && live) *lobj = lp;
-                lobj += P.N;
-                if (boundary) ++nb;
+                if constexpr (!LP_MERGED) {
+                    if (hist_on && lp_lane) *lobj = lp;
+                    lobj += P.N;
+                }
             }
         }
-        if (g0 == 0) DEMCZ_STAMP(P, 4);
+        to_b -= len;
+        if (to_b == 0) {         // the chunk ended on a generation divisible by K: runchain!'s append, demcz.jl:88-91
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int p = r + L * k;
+                if (p < D && live) {
+                    if (P.do_append) {
+                        if constexpr (LIVE) live_store(&P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p], own[k]);
+                        else P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p] = own[k];
+                    }
+                    if (P.snap) P.snap[nb * P.N * D + c + P.N * p] = own[k];
+                }
+            }
+            to_b = P.K;
+            ++nb;
+            if constexpr (LIVE) Mv += N32;
+        }
+        if (g0 == stamp_g0) DEMCZ_STAMP(P, 4);
         wave_lds_handoff();      // sdelta is rewritten by the next chunk
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        double xs = x[(L * k < D) ? L * k : 0];
-#pragma unroll
-        for (int j = 1; j < L; ++j)
-            if (L * k + j < D) xs = (r == j) ? x[L * k + j] : xs;
         const int p = r + L * k;
-        if (p < D && live) P.Xcur[c + P.N * p] = xs;
+        if (p < D && live) P.Xcur[c + P.N * p] = own[k];
     }
     if (r == 0 && live) P.lpcur[c] = lp;
     DEMCZ_STAMP(P, 7);
