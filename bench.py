@@ -45,7 +45,7 @@ def measured_traffic(n_loc, d, lanes):
         return None
     if lanes != 100:          # the committed passes were taken with the default (split) layout
         return None
-    name = f"window_kernel_pc8<0, {d},"
+    name = f"window_kernel_pc8<0, {d}, true, false>"      # the LIVE launches (one per slab between R-hat checks)
     for k, v in json.loads(f.read_text())["kernels"].items():
         if name in k:
             return v.get("bytes_per_launch_raw")
@@ -234,7 +234,8 @@ def main():
                        "parallelism": f"chains sharded x{world}, Z replicated" if world > 1 else "single GPU"},
             "gens_to_rhat_1p05": gens_to_rhat, "rhat_trace": rhat_trace[-12:], "accept_ratio_mean": acc,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": measured_traffic(n_loc, d, eng.info()["lanes_per_chain"]) if K == 10 else None, "kernel": "demcz::window_kernel", "launches": launches,
+                         "traffic": measured_traffic(n_loc, d, eng.info()["lanes_per_chain"]) if K == 10 else None, "kernel": "demcz::window_kernel_pc8<MVNORMAL, 5, LIVE>" if eng.info()["lanes_per_chain"] == 100 else "demcz::window_kernel",
+                         "launches": launches, "generations_per_launch": gens_per_launch,
                          "avg_launch_us": avg_launch_s * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_chain_update": B},
         }

@@ -76,7 +76,7 @@ struct demcz_handle {
 #endif
     int64_t rec_cap = 0;              // generations each buffer holds
     int rec_cur = 0;
-    struct RecDesc { bool valid = false; int64_t g_first = 0; int64_t M = 0; int32_t ngen = 0; } rec_desc[2];
+    struct RecDesc { bool valid = false; int64_t g_first = 0, M = 0, rows = 0; int32_t ngen = 0, boff = 0; } rec_desc[2];
     // multi-GPU
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
@@ -288,8 +288,8 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
     CRCHK(hipMalloc((void**)&h->dZ, (size_t)cfg->Mcap * h->ZS * sizeof(double)));
     // (the reference pads with zeros, demcz.jl:11; rows at or beyond M never leave the device, and here they hold
     //  the sentinel LIVE launches recognise an unpublished row by: fill_unwritten_rows() in demcz_set_state)
-    CRCHK(hipMalloc((void**)&h->d_live_err, sizeof(unsigned int)));
-    CRCHK(hipMemsetAsync(h->d_live_err, 0, sizeof(unsigned int), h->stream));
+    CRCHK(hipMalloc((void**)&h->d_live_err, 4 * sizeof(unsigned int)));
+    CRCHK(hipMemsetAsync(h->d_live_err, 0, 4 * sizeof(unsigned int), h->stream));
     CRCHK(hipMalloc((void**)&h->dX, (size_t)N * d * sizeof(double)));
     CRCHK(hipMalloc((void**)&h->dlp, (size_t)N * sizeof(double)));
     if (cfg->Gcap > 0) {
@@ -405,7 +405,7 @@ extern "C" int32_t demcz_set_state(demcz_handle* h, const double* X, const doubl
                                reinterpret_cast<unsigned long long*>(h->dZ + (size_t)M0 * h->ZS), rest, LIVE_SENTINEL);
             HIPCHK(h, hipGetLastError());
         }
-        HIPCHK(h, hipMemsetAsync(h->d_live_err, 0, sizeof(unsigned int), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_live_err, 0, 4 * sizeof(unsigned int), h->stream));
     }
     if (logp) {
         HIPCHK(h, hipMemcpyAsync(h->dlp, logp, (size_t)N * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -540,7 +540,7 @@ static bool pc_available(int target_kind, int d, bool full_block)
     return target_kind == DEMCZ_TARGET_MVNORMAL && (d == 2 || d == 3 || d == 4 || d == 5 || d == 8 || d == 10);
 }
 
-static int pc_roles(int d) { return ((d == 1) ? 1 : (d + 1) / 2) + 1; }     // producer roles: normal pairs + accept uniform
+static int pc_roles(int d) { return ((d == 1) ? 1 : (d + 1) / 2) + 2; }
 
 #ifdef DEMCZ_STAMPS
 constexpr int64_t DEMCZ_STAMP_WGS = 1 << 16;
@@ -586,7 +586,8 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
 // Records of the launch (g .. g+ngen-1 against M rows) are in d_rec[rec_cur] when this returns: either
 // the previous launch's producer half made them, or a producer-only launch is enqueued now.  Then
 // `P` is completed so that this launch's producer half prepares (next_g, next_ngen, next_M).
-static int32_t pc_prepare(demcz_handle* h, WindowParams& P, int64_t next_g, int64_t next_ngen, int64_t next_M)
+static int32_t pc_prepare(demcz_handle* h, WindowParams& P, int64_t cur_rows, int64_t next_g, int64_t next_ngen, int64_t next_M,
+                          int64_t next_rows, int32_t next_boff)
 {
     const int d = h->cfg.d;
     const int64_t need = std::max<int64_t>(P.ngen, next_ngen);
@@ -595,29 +596,33 @@ static int32_t pc_prepare(demcz_handle* h, WindowParams& P, int64_t next_g, int6
         for (int b = 0; b < 2; ++b) {
             if (h->d_rec[b]) HIPCHK(h, hipFree(h->d_rec[b]));
             h->d_rec[b] = nullptr;
-            HIPCHK(h, hipMalloc((void**)&h->d_rec[b], (size_t)need * (d + 1) * h->cfg.N * sizeof(double)));
-            HIPCHK(h, hipMemsetAsync(h->d_rec[b], 0, (size_t)need * (d + 1) * h->cfg.N * sizeof(double), h->stream));
+            HIPCHK(h, hipMalloc((void**)&h->d_rec[b], (size_t)need * (d + 2) * h->cfg.N * sizeof(double)));
+            HIPCHK(h, hipMemsetAsync(h->d_rec[b], 0, (size_t)need * (d + 2) * h->cfg.N * sizeof(double), h->stream));   // row 0: always a legal index
             h->rec_desc[b].valid = false;
         }
         h->rec_cap = need;
     }
     const int cur = h->rec_cur;
+    const int32_t cur_boff = P.K - P.to_boundary;
     auto& dc = h->rec_desc[cur];
-    if (!(dc.valid && dc.g_first == P.g_first && dc.ngen >= P.ngen)) {      // (records do not depend on M: the consumer draws the rows)
+    // the row indices in a record were drawn against M + (boundaries passed) * rows: all of that must agree
+    if (!(dc.valid && dc.g_first == P.g_first && dc.ngen >= P.ngen && dc.M == P.M && dc.rows == cur_rows && dc.boff == cur_boff)) {
         WindowParams Q = P;                 // producer-only launch for THIS window
         Q.consumer_blocks = 0;
         Q.rec_out = h->d_rec[cur];
-        Q.next_g_first = P.g_first; Q.next_ngen = P.ngen; Q.next_M = P.M;
+        Q.next_g_first = P.g_first; Q.next_ngen = P.ngen; Q.next_M = P.M; Q.next_rows = cur_rows; Q.next_boff = cur_boff;
         int32_t rc = launch_window_pc(h, Q);
         if (rc) return rc;
-        dc.valid = true; dc.g_first = P.g_first; dc.M = P.M; dc.ngen = P.ngen;
+        dc.valid = true; dc.g_first = P.g_first; dc.M = P.M; dc.ngen = P.ngen; dc.rows = cur_rows; dc.boff = cur_boff;
     }
     P.rec_in = h->d_rec[cur];
     P.consumer_blocks = (int32_t)((P.N + PC_CONSUMER_CHAINS - 1) / PC_CONSUMER_CHAINS);
     P.rec_out = h->d_rec[cur ^ 1];
     P.next_g_first = next_g; P.next_ngen = (int32_t)std::max<int64_t>(next_ngen, 0); P.next_M = next_M;
+    P.next_rows = next_rows; P.next_boff = next_boff;
     auto& dn = h->rec_desc[cur ^ 1];
     dn.valid = next_ngen > 0; dn.g_first = next_g; dn.M = next_M; dn.ngen = (int32_t)std::max<int64_t>(next_ngen, 0);
+    dn.rows = next_rows; dn.boff = next_boff;
     h->rec_cur = cur ^ 1;
     return DEMCZ_OK;
 }
@@ -790,9 +795,12 @@ static int32_t flush_exchanges(demcz_handle* h)
 // A LIVE launch that gave up waiting for a row leaves a word behind; results after it are void.
 static int32_t check_live_err(demcz_handle* h)
 {
-    unsigned int e = 0;
-    HIPCHK(h, hipMemcpy(&e, h->d_live_err, sizeof(e), hipMemcpyDeviceToHost));
-    if (e) return fail(h, DEMCZ_ERR_HIP, "demcz_run: an archive row appended inside the launch never became visible (LIVE hand-off)");
+    unsigned int e[4] = {0, 0, 0, 0};
+    HIPCHK(h, hipMemcpy(e, h->d_live_err, sizeof(e), hipMemcpyDeviceToHost));
+    if (e[0])
+        return fail(h, DEMCZ_ERR_HIP, "demcz_run: an archive row appended inside the launch never became visible (LIVE hand-off): "
+                                      "generation " + std::to_string(e[1]) + " of the launch, row " + std::to_string(e[2]) +
+                                      ", workgroup " + std::to_string(e[3]) + ", rows appended " + std::to_string(h->M_app));
     return DEMCZ_OK;
 }
 
@@ -801,8 +809,8 @@ static int32_t check_live_err(demcz_handle* h)
 static int64_t live_span(const demcz_handle* h)
 {
     if (h->lanes != DEMCZ_LAYOUT_SPLIT || h->comm || h->lag > 0 || h->external_append) return 0;
-    const int64_t per_gen = (int64_t)(h->cfg.d + 1) * h->cfg.N * (int64_t)sizeof(double);
-    const int64_t span = (int64_t)(48ll << 20) / per_gen;
+    const int64_t per_gen = (int64_t)(h->cfg.d + 2) * h->cfg.N * (int64_t)sizeof(double);
+    const int64_t span = (int64_t)(64ll << 20) / per_gen;        // 64 MiB of records per buffer (C2: 1170 generations)
     return std::max<int64_t>(h->cfg.K, std::min<int64_t>(span, 1 << 20));
 }
 
@@ -855,6 +863,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     P.snap = nullptr;
     P.K = K;
     P.rec_in = nullptr; P.rec_out = nullptr; P.next_g_first = 0; P.next_M = 0; P.next_ngen = 0; P.consumer_blocks = 0;
+    P.next_rows = 0; P.next_boff = 0;
 #ifdef DEMCZ_STAMPS
     if (!h->d_stamps) {
         HIPCHK(h, hipMalloc((void**)&h->d_stamps, (size_t)DEMCZ_STAMP_WGS * 8 * sizeof(unsigned long long)));
@@ -900,14 +909,20 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         }
         if (h->lanes == DEMCZ_LAYOUT_SPLIT) {
             // what the launch after this one will be, so that this launch's producer half can prepare
-            // its normals and accept uniforms: it starts at w_end + 1 and runs to its own boundary / batch end
-            // (the records do not depend on the archive size; the consumer draws the rows against its own M)
+            // its draws: it starts at w_end + 1, runs to its own boundary / batch end / span, and sees ...
             const int64_t ng = w_end + 1;
-            int64_t nend = ((ng - 1) / K + 1) * (int64_t)K;
+            const int64_t nb1 = ((ng - 1) / K + 1) * (int64_t)K;       // its first boundary
+            int64_t nend = nb1;
             if (E > 0 && !h->external_append) nend = ((nend / K + E - 1) / E) * E * (int64_t)K;
-            int64_t nn = nend - ng + 1;
+            int64_t nM = h->M, nn = nend - ng + 1;
+            const int64_t rows_n = h->cfg.N * (sharded ? h->nranks : 1);
             if (live_max > 0) nn = std::min(live_max, (w_end < g_to) ? g_to - w_end : G);   // a next call is taken to be as long as this one
-            rc = pc_prepare(h, P, ng + h->rng_offset, nn, 0);
+            if (h->external_append) nn = 0;                      // the caller appends: M is not ours to predict
+            else if (E == 0) nM = h->M_app + nbound * rows_n;                    // ... the rows appended now
+            else for (const auto& pe : h->pending) if (pe.visible_from <= ng) nM = pe.M_after;   // ... or admitted by then
+            const int64_t vis_rows = (E == 0) ? rows_n : 0;      // rows that join per boundary passed inside a launch
+            const int32_t nboff = (int32_t)(K - (nb1 - ng + 1));
+            rc = pc_prepare(h, P, vis_rows, ng + h->rng_offset, nn, nM, vis_rows, nboff);
             if (rc) return rc;
         }
         // boundaries whose rows generations of this same launch draw from

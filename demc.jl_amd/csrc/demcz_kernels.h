@@ -80,7 +80,9 @@ struct WindowParams {
     const double* rec_in;
     double* rec_out;
     int64_t next_g_first;    // stream generation index of the next launch's first generation
-    int64_t next_M;          // (unused since the consumer draws the rows itself)
+    int64_t next_M;          // rows its first generation draws from
+    int64_t next_rows;       // ... plus this many per K boundary it has passed (0: appended rows become visible later)
+    int32_t next_boff;       // K - (generations from its first one to the next boundary)
     int32_t next_ngen;
     int32_t consumer_blocks; // workgroups [0, consumer_blocks) consume, the rest produce
     unsigned int* live_err;  // LIVE launches: set when a row another wave should have appended never showed up

@@ -9,15 +9,13 @@
 // and the chip has 1000 idle SIMDs, so:
 //
 //   producer workgroups (one lane per Philox block of the NEXT launch's generations) write a draw
-//       record per (generation, chain): the D normals and log u of the accept test (the expensive
-//       draws: log, sqrt, sincos);
+//       record per (generation, chain): the D normals, log u of the accept test, the two row indices
+//       (against the archive size that generation will see);
 //   consumer workgroups (eight lanes per chain) read the records of THIS launch (written by the
-//       previous launch's producers) and, while those loads are in flight, draw the two row indices of
-//       a chunk of generations themselves (one Philox block each, no transcendental) so that the
-//       archive gather does not wait for a record: the two memory hops of a chunk overlap instead of
-//       following each other.  They form the proposal increments of the chunk up front, then run the
-//       state-dependent part -- proposal, log-density, accept, history, K-boundary append -- from
-//       registers: ~60 instructions a generation.
+//       previous launch's producers) a chunk of generations at a time -- the row indices one chunk
+//       ahead, so that a chunk's archive gather starts at once and runs beside its record loads --
+//       form the proposal increments of the chunk up front, then run the state-dependent part --
+//       proposal, log-density, accept, history -- from registers: ~55 instructions a generation.
 //
 // Both halves are ONE launch (workgroups [0, consumer_blocks) consume, the rest produce), so they
 // overlap on different CUs with no events or second stream; the kernel boundary that already
@@ -33,35 +31,44 @@
 namespace demcz {
 
 
-// record layout: rec[(g * (D + 1) + f) * N + c], f = 0..D-1 normals, D log u
+// record layout: rec[(g * (D + 2) + f) * N + c], f = 0..D-1 normals, D log u, D+1 the two row indices
+// packed as 32-bit halves (the split layout is only selected while the archive has < 2^32 rows)
 template <int D>
-__device__ __forceinline__ size_t rec_index(int64_t N, int g, int f, int64_t c) { return ((size_t)g * (D + 1) + f) * (size_t)N + (size_t)c; }
+__device__ __forceinline__ size_t rec_index(int64_t N, int g, int f, int64_t c) { return ((size_t)g * (D + 2) + f) * (size_t)N + (size_t)c; }
 
 template <int D>
 __device__ __forceinline__ void pc_produce(const WindowParams& P, int64_t pb)
 {
     constexpr int NPAIRS = (D == 1) ? 1 : (D + 1) / 2;
-    constexpr int S = NPAIRS + 2;                          // Philox blocks of a generation; block 0 (row indices) is the consumer's
-    constexpr int SP = NPAIRS + 1;                         // producer roles: the normal pairs, then the accept uniform
+    constexpr int S = NPAIRS + 2;                          // Philox blocks of a generation = producer roles
     const int64_t nbc = (P.N + 63) / 64;                   // workgroups per (generation, role) plane
     const int64_t plane = pb / nbc;                        // wave-uniform
     const int64_t c = (pb % nbc) * 64 + threadIdx.x;
-    const int role = (int)(plane % SP), gi = (int)(plane / SP);
+    const int role = (int)(plane % S), gi = (int)(plane / S);
     if (gi >= P.next_ngen || c >= P.N) return;
     philox_blocks rng;
     uint64_t r1, r2;
-    rng.block(P.seed, (uint64_t)(P.chain_id0 + c), (uint64_t)(P.next_g_first + gi - 1) * (uint64_t)S + (uint64_t)(role + 1), r1, r2);
+    rng.block(P.seed, (uint64_t)(P.chain_id0 + c), (uint64_t)(P.next_g_first + gi - 1) * (uint64_t)S + (uint64_t)role, r1, r2);
     double* rec = P.rec_out;
-    const double lg = dm_log(u_open(r1));
-    if (role == SP - 1) {
-        rec[rec_index<D>(P.N, gi, D, c)] = lg;
+    if (role == 0) {
+        // rows generation gi of the next launch draws from: those it starts with plus, where appended rows
+        // are visible at once, N per K boundary it has passed by then (update_demcz_chain_block, demcz.jl:176-179)
+        const int64_t Mg = P.next_M + (int64_t)((gi + P.next_boff) / P.K) * P.next_rows;
+        uint64_t i1, i2;
+        draw_rows(r1, r2, (uint64_t)Mg, i1, i2);
+        rec[rec_index<D>(P.N, gi, D + 1, c)] = __longlong_as_double((long long)(i1 | (i2 << 32)));
     } else {
-        const double R = sqrt(-2.0 * lg);
-        double cs, sn;
-        dm_sincos2pi(r2 >> 11, cs, sn);
-        const int p0 = (D == 1) ? 0 : 2 * role;
-        rec[rec_index<D>(P.N, gi, p0, c)] = R * cs;
-        if (p0 + 1 < D) rec[rec_index<D>(P.N, gi, p0 + 1, c)] = R * sn;
+        const double lg = dm_log(u_open(r1));
+        if (role == S - 1) {
+            rec[rec_index<D>(P.N, gi, D, c)] = lg;
+        } else {
+            const double R = sqrt(-2.0 * lg);
+            double cs, sn;
+            dm_sincos2pi(r2 >> 11, cs, sn);
+            const int p0 = (D == 1) ? 0 : 2 * (role - 1);
+            rec[rec_index<D>(P.N, gi, p0, c)] = R * cs;
+            if (p0 + 1 < D) rec[rec_index<D>(P.N, gi, p0 + 1, c)] = R * sn;
+        }
     }
 }
 
@@ -91,7 +98,7 @@ constexpr int PC8_CHUNK = 10;
 // waits cannot form a cycle; all consumer workgroups are single waves and co-resident (N <= 8192:
 // at most 1024 of them on 256 CUs).  A bounded spin turns a lost row into an error word, not a hang.
 constexpr unsigned long long LIVE_SENTINEL = 0xFFF4DEADC0DE5EEDull;
-constexpr int LIVE_SPIN_LIMIT = 1 << 20;
+constexpr int LIVE_SPIN_LIMIT = 1 << 18;      // ~0.1-0.3 s of polling
 
 __device__ __forceinline__ double live_load(const double* p)
 {
@@ -116,13 +123,9 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
         DEMCZ_STAMP(P, 7);
         return;
     }
-    constexpr int NPAIRS = (D == 1) ? 1 : (D + 1) / 2, S = NPAIRS + 2;
-    constexpr int ITEMS = G * CH, ROUNDS = (ITEMS + 63) / 64;         // (chain, generation) index draws of a chunk, per wave
     __shared__ __attribute__((aligned(16))) double sdelta[G * CH * DP];
-    __shared__ __attribute__((aligned(16))) uint64_t sidx[G * CH];
     const int lane = threadIdx.x, r = lane % L, gq = lane / L;
-    // every lane of the wave stays: it draws row indices for the whole wave (below).  Groups beyond the
-    // last chain shadow chain N-1 and store nothing.
+    // groups beyond the last chain shadow chain N-1 and store nothing
     const int64_t c_own = (int64_t)blockIdx.x * G + gq;
     const bool live = c_own < P.N;
     const int64_t c = live ? c_own : P.N - 1;
@@ -179,29 +182,40 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
 #pragma unroll
     for (int k = 0; k < NP; ++k) rec_z[k] = P.rec_in + (int64_t)((D == 1) ? 0 : pk[k]) * P.N + c;
     const double* rec_lg = P.rec_in + (int64_t)D * P.N + c;
-    const int64_t rec_gs = (int64_t)(D + 1) * P.N;
-    // the index draws this lane makes for its wave: item t = (generation of the chunk) * G + (chain of the wave)
-    uint64_t my_chain[ROUNDS];
-    int my_u[ROUNDS];
+    const int64_t rec_gs = (int64_t)(D + 2) * P.N;
+    const double* rec_ix = P.rec_in + (int64_t)(D + 1) * P.N + c;
+    // archive addressing: row stride and the whole archive fit 32 bits of byte offset (condition of this
+    // layout), the row stride is a power of two for every dimension built: one shift-add per element
+    constexpr int ZSC = (D <= 2) ? 2 : (D <= 4) ? 4 : ((D + 7) / 8) * 8;
+    static_assert((ZSC & (ZSC - 1)) == 0, "row stride must be a power of two");
+    constexpr int ZSHIFT = (ZSC == 2) ? 4 : (ZSC == 4) ? 5 : (ZSC == 8) ? 6 : 7;
+    const char* Zb = reinterpret_cast<const char*>(P.Z);
+    uint32_t pk8[NP];
 #pragma unroll
-    for (int rd = 0; rd < ROUNDS; ++rd) {
-        const int t = (rd * 64 + lane < ITEMS) ? rd * 64 + lane : ITEMS - 1;
-        const int64_t cc = (int64_t)blockIdx.x * G + (t % G);
-        my_chain[rd] = (uint64_t)(P.chain_id0 + ((cc < P.N) ? cc : P.N - 1));
-        my_u[rd] = t / G;
+    for (int k = 0; k < NP; ++k) pk8[k] = (uint32_t)pk[k] * 8u;
+    // row indices of the first chunk; from then on they are fetched one chunk ahead
+    uint64_t ixn[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+        const int g = (u < P.ngen) ? u : P.ngen - 1;
+        ixn[u] = (uint64_t)__double_as_longlong(rec_ix[g * rec_gs]);
     }
-    uint32_t Mv = (uint32_t)P.M;       // rows the chunk's proposals draw from (< 2^32: condition of this layout);
-                                       // LIVE: grows by N at every boundary the launch passes
-    const uint32_t N32 = (uint32_t)P.N;
 
     // A chunk is up to CH generations whose draws are fetched together.  It ends at the next K boundary:
     // the append then sits between chunks, not inside the generation code, and in a LIVE launch the
     // generation after a boundary draws from rows that are only being written while this chunk computes
     // (K = 1: one generation per chunk).
+    if constexpr (LIVE) {       // an earlier launch of the run already failed: do not wait again
+        if (__hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    }
     int len = 0;
+    [[maybe_unused]] bool gave_up = false;      // LIVE: a row never arrived; the wave stops (results are void, the host reports it)
     [[maybe_unused]] const int stamp_g0 = (P.ngen > 5 * CH) ? 5 * CH : 0;      // diagnostic build: the chunk that is timed
     for (int g0 = 0; g0 < P.ngen; g0 += len) {
         if (g0 == stamp_g0) DEMCZ_STAMP(P, 5);
+#ifdef DEMCZ_STAMPS
+        if (P.stamps && threadIdx.x == 0) P.stamps[(size_t)blockIdx.x * 8 + 6] = 1000000ull + (unsigned long long)g0;   // progress
+#endif
         len = (P.ngen - g0 < CH) ? P.ngen - g0 : CH;
         len = (to_b < len) ? to_b : len;
         double lgu[CH], dmine[CH][NP];
@@ -217,41 +231,29 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
                 lgu[u] = rec_lg[g * rec_gs];
                 if constexpr (TEMPER) tmpr[u] = P.temperature[g];
             }
-            // the two archive rows of every (chain, generation) of the chunk: block 0 of the generation's
-            // Philox blocks (update_demcz_chain_block, demcz.jl:176-179), one draw per lane and round
-#pragma unroll
-            for (int rd = 0; rd < ROUNDS; ++rd) {
-                const int gu = g0 + ((my_u[rd] < len) ? my_u[rd] : len - 1);
-                philox_blocks rng;
-                uint64_t r1, r2;
-                rng.block(P.seed, my_chain[rd], (uint64_t)(P.g_first + gu - 1) * (uint64_t)S, r1, r2);
-                const uint64_t i1 = mulhi64_u32(r1, Mv);
-                const uint64_t j = mulhi64_u32(r2, Mv - 1u);
-                const uint64_t i2 = j + (j >= i1 ? 1ull : 0ull);
-                if (rd * 64 + lane < ITEMS) sidx[(rd * 64 + lane) % G * CH + (rd * 64 + lane) / G] = i1 | (i2 << 32);
-            }
-            if (g0 == stamp_g0) DEMCZ_STAMP(P, 1);
-            wave_lds_handoff();
-            uint32_t i1[CH], i2[CH];
+            // the two archive rows of every generation of the chunk (indices fetched during the previous chunk)
+            uint32_t o1[CH], o2[CH];
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
-                const uint64_t ii = sidx[gq * CH + u];
-                i1[u] = (uint32_t)ii;
-                i2[u] = (uint32_t)(ii >> 32);
+                // slots past the end of the chunk read row 0: their own rows may not exist yet (LIVE: never wait for them)
+                o1[u] = (u < len) ? (uint32_t)ixn[u] << ZSHIFT : 0u;
+                o2[u] = (u < len) ? (uint32_t)(ixn[u] >> 32) << ZSHIFT : 0u;
             }
-            const uint32_t zs = (uint32_t)P.ZS;
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
-                    if constexpr (LIVE) {
-                        za[u][k] = live_load(&P.Z[(uint64_t)i1[u] * zs + (uint32_t)pk[k]]);
-                        zb[u][k] = live_load(&P.Z[(uint64_t)i2[u] * zs + (uint32_t)pk[k]]);
-                    } else {
-                        za[u][k] = P.Z[(uint64_t)i1[u] * zs + (uint32_t)pk[k]];      // one 32x32->64 multiply-add
-                        zb[u][k] = P.Z[(uint64_t)i2[u] * zs + (uint32_t)pk[k]];
-                    }
+                    const double* pa = reinterpret_cast<const double*>(Zb + (o1[u] + pk8[k]));
+                    const double* pb = reinterpret_cast<const double*>(Zb + (o2[u] + pk8[k]));
+                    if constexpr (LIVE) { za[u][k] = live_load(pa); zb[u][k] = live_load(pb); }
+                    else { za[u][k] = *pa; zb[u][k] = *pb; }
                 }
+            }
+            // next chunk's indices (it starts at g0 + len)
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int g = (g0 + len + u < P.ngen) ? g0 + len + u : P.ngen - 1;
+                ixn[u] = (uint64_t)__double_as_longlong(rec_ix[g * rec_gs]);
             }
             // nothing that waits for a record may be scheduled in front of the gather's issue
             __builtin_amdgcn_sched_barrier(0);
@@ -265,8 +267,41 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
                     for (int k = 0; k < NP; ++k) bad |= is_sentinel(za[u][k]) | is_sentinel(zb[u][k]);
                 int spins = 0;
                 while (__builtin_amdgcn_ballot_w64(bad) != 0ull) {           // wave-uniform
-                    if (++spins > LIVE_SPIN_LIMIT) {
-                        if (lane == 0) atomicExch(P.live_err, 1u);
+                    // give up after LIVE_SPIN_LIMIT polls, or as soon as any wave of the launch has given up
+                    // (live_err[0]; checked every 256 polls): the launch then drains within microseconds
+                    const bool timeout = (++spins > LIVE_SPIN_LIMIT);
+                    bool abandon = timeout;
+                    if (!timeout && (spins & 255) == 0)
+                        abandon = __hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                    if (abandon) {
+                        if (timeout && bad) {
+                            // first lane to report leaves what it was waiting for: [1] generation of the launch,
+                            // [2] archive row, [3] workgroup
+                            if (atomicCAS(P.live_err, 0u, 1u) == 0u) {
+                                unsigned row = 0;
+#pragma unroll
+                                for (int u = 0; u < CH; ++u)
+#pragma unroll
+                                    for (int k = 0; k < NP; ++k) {
+                                        if (is_sentinel(za[u][k])) row = o1[u] >> ZSHIFT;
+                                        if (is_sentinel(zb[u][k])) row = o2[u] >> ZSHIFT;
+                                    }
+                                P.live_err[1] = (unsigned)g0; P.live_err[2] = row; P.live_err[3] = blockIdx.x;
+                            }
+                        }
+#ifdef DEMCZ_STAMPS
+                        if (P.stamps) {      // what every stuck lane was waiting for (last writer wins per workgroup)
+#pragma unroll
+                            for (int u = 0; u < CH; ++u)
+#pragma unroll
+                                for (int k = 0; k < NP; ++k) {
+                                    if (is_sentinel(za[u][k])) { P.stamps[(size_t)blockIdx.x * 8 + 4] = 2000000000ull + (o1[u] >> ZSHIFT); P.stamps[(size_t)blockIdx.x * 8 + 3] = 3000000000ull + (unsigned)(u * 100 + pk[k]); }
+                                    if (is_sentinel(zb[u][k])) { P.stamps[(size_t)blockIdx.x * 8 + 4] = 2000000000ull + (o2[u] >> ZSHIFT); P.stamps[(size_t)blockIdx.x * 8 + 3] = 3000000000ull + (unsigned)(u * 100 + pk[k]); }
+                                }
+                            if (lane == 0) P.stamps[(size_t)blockIdx.x * 8 + 2] = 4000000000ull + (unsigned)spins;
+                        }
+#endif
+                        gave_up = true;
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
@@ -275,8 +310,8 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
                     for (int u = 0; u < CH; ++u) {
 #pragma unroll
                         for (int k = 0; k < NP; ++k) {
-                            if (is_sentinel(za[u][k])) za[u][k] = live_load(&P.Z[(uint64_t)i1[u] * zs + (uint32_t)pk[k]]);
-                            if (is_sentinel(zb[u][k])) zb[u][k] = live_load(&P.Z[(uint64_t)i2[u] * zs + (uint32_t)pk[k]]);
+                            if (is_sentinel(za[u][k])) za[u][k] = live_load(reinterpret_cast<const double*>(Zb + (o1[u] + pk8[k])));
+                            if (is_sentinel(zb[u][k])) zb[u][k] = live_load(reinterpret_cast<const double*>(Zb + (o2[u] + pk8[k])));
                             bad |= is_sentinel(za[u][k]) | is_sentinel(zb[u][k]);
                         }
                     }
@@ -294,6 +329,7 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
                 }
             }
         }
+        if constexpr (LIVE) { if (gave_up) return; }       // wave-uniform
         if (g0 == stamp_g0) DEMCZ_STAMP(P, 3);
         wave_lds_handoff();
         // the whole chunk's increments into registers first: the LDS latency is paid once, not inside
@@ -369,7 +405,6 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
             }
             to_b = P.K;
             ++nb;
-            if constexpr (LIVE) Mv += N32;
         }
         if (g0 == stamp_g0) DEMCZ_STAMP(P, 4);
         wave_lds_handoff();      // sdelta is rewritten by the next chunk
