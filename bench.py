@@ -99,10 +99,13 @@ def cpu_baseline(w, N, d, K, seed, budget_updates):
     # the same loop spread over the host's cores (OpenMP over chains): the "CPU-omp" row, reported beside the
     # single-core figure (`value`/`cores` stay the scalar port)
     try:
-        thr = len(os.sched_getaffinity(0))
+        # at most 8 threads: the box's CPU share is smaller than its affinity mask suggests, and spinning OpenMP
+        # barriers on oversubscribed cores take minutes instead of seconds
+        thr = max(1, min(len(os.sched_getaffinity(0)), 8))
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         X = np.array(Z0[M0 - N:], order="F")
         lp = O.logp(prob, X)
-        Gm = G * min(thr, 8)
+        Gm = 2 * G
         Mcap2 = M0 + -(-N * Gm // K)
         prob2 = O.Problem(N, d, K, Mcap2, w["eps_scale"], seed, target=w["target"].oracle_spec())
         Z2 = np.zeros((Mcap2, d), order="F")

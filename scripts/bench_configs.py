@@ -42,8 +42,9 @@ def cpu_rows():
         Z = np.zeros((Mcap, d), order="F"); Z[:M0] = w["Zinit"]
         t0 = time.perf_counter(); O.run(prob, X, lp, Z, M0, 1, Gc, 2.38, schedule=sched, native=True); dt = time.perf_counter() - t0
         print(f"{label:50s} C2 {N*Gc/dt:10.3e} upd/s", flush=True)
-    ncores = os.cpu_count() or 1
-    for thr in sorted({ncores // 2 or 1, ncores}):
+    ncores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    for thr in sorted({min(ncores, 4), min(ncores, 8)}):
         Mcap = M0 + N * Gc // 10
         prob = O.Problem(N, d, 10, Mcap, w["eps_scale"], 1, target=w["target"].oracle_spec())
         X = np.array(w["Zinit"][-N:], order="F"); lp = O.logp(prob, X)
