@@ -232,9 +232,12 @@ def test_full_size_c2_properties(demc, oracle):
     sd = np.sqrt(np.diag(w["Sigma"]))
     assert np.all(np.abs(mean - w["mu"]) < 0.01 * sd), (mean - w["mu"]) / sd
     assert np.allclose(cov, w["Sigma"], rtol=0.02, atol=0.01 * w["Sigma"].max())
-    # first 300 generations against the oracle, bit for bit (the oracle finishes this in a second)
-    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, 10, 300, None, w["eps_scale"], 2.38, 31953150)
-    assert np.array_equal(mc.chain[:, :, :300], ref["chain"])
+    # the whole run against the oracle, bit for bit: 10^7 chain-updates, every history entry and every
+    # archive row (the launches run through 100 K boundaries each, handing rows from wave to wave:
+    # one stale or torn row anywhere would change everything after it)
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, 10, G, None, w["eps_scale"], 2.38, 31953150)
+    assert np.array_equal(mc.chain, ref["chain"]) and np.array_equal(mc.log_obj, ref["log_obj"])
+    assert np.array_equal(Z, ref["Z"]) and np.array_equal(mc.Xcurrent, ref["X"])
     runner.close()
 
 
@@ -420,3 +423,44 @@ def test_full_size_c5_properties(demc, oracle):
     temps = np.array([demc.tempbaseline(g, G, 3, 1e-3) for g in range(1, G0 + 1)])
     ref = oracle_sample(oracle, w["target"], w["Zinit"], N, 10, G0, None, w["eps_scale"], w["gamma"], 319531501, temperature=temps)
     assert np.array_equal(mc.chain[:, :, :G0], ref["chain"]) and np.array_equal(mc.log_obj[:, :G0], ref["log_obj"])
+
+
+def test_live_handoff_under_uneven_load(demc, oracle):
+    """The in-launch row hand-off of the split layout while another stream keeps the
+    chip busy with a 2^18-chain population: consumer waves are dispatched late and unevenly, rows arrive
+    late -- the result must still be the oracle's, bit for bit, for K = 10, 3 and 1."""
+    d, N = 5, 1024
+    w = demc.workloads.mvnormal_problem(d, N)
+    M0 = w["Zinit"].shape[0]
+    Nb = 1 << 18
+    wb = demc.workloads.mvnormal_problem(d, Nb)
+    big = demc.HipEngine(N=Nb, d=d, K=10, Mcap=wb["Zinit"].shape[0] + Nb * 31, Gcap=0, blockindex=[range(d)],
+                         eps_scale=wb["eps_scale"], seed=3, target=wb["target"])
+    big.set_state(wb["Zinit"][-Nb:], None, wb["Zinit"])
+    for K, G in ((10, 600), (3, 200), (1, 60)):
+        e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K), Gcap=G, blockindex=[range(d)], eps_scale=w["eps_scale"],
+                           seed=11, target=w["target"])
+        assert e.info()["lanes_per_chain"] == 100
+        e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+        g = 1
+        for piece in (G // 3, G // 3, G - 2 * (G // 3)):
+            _big_step(big)
+            e.run(g, g + piece - 1, 2.38)         # asynchronous: overlaps the big population's windows on the other stream
+            g += piece
+        ch, lo = e.get_history(1, G)
+        X, lp, Z, M = e.get_state()
+        e.close()
+        ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], 2.38, 11)
+        assert np.array_equal(ch, ref["chain"]) and np.array_equal(lo, ref["log_obj"]) and np.array_equal(Z, ref["Z"]), K
+    big.synchronize()
+    big.close()
+
+
+_BIG_G = [1]
+
+
+def _big_step(big):
+    """30 more generations (3 windows, ~0.1 ms each at 2^18 chains) of the background population, not waited for."""
+    g = _BIG_G[0]
+    big.run(g, g + 29, 2.38)
+    _BIG_G[0] = g + 30
