@@ -69,6 +69,8 @@ struct demcz_handle {
     bool proposal_pending = false;
     bool gen_open = false;
     // split layout: draw records, double-buffered (this launch reads one, its producer half fills the other)
+    int64_t live_wg_cap = -1;         // consumer workgroups a LIVE launch may have (all must be resident at once); -1: not asked yet
+    int split_kind = 0;               // lanes == DEMCZ_LAYOUT_SPLIT: 1 = eight replicated lanes per chain (pc8), 2 = 16 cooperating lanes (ml, REC)
     double* d_rec[2] = {nullptr, nullptr};
     unsigned int* d_live_err = nullptr;   // device word a LIVE launch sets when an expected row never appears
 #ifdef DEMCZ_STAMPS
@@ -130,6 +132,7 @@ static int64_t blockstep_nblk(int b)
 constexpr size_t ML_MAX_DYNAMIC_LDS = 160 * 1024;      // LDS per CU on gfx950
 static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t nobs, int max_blocklen, int nblocks);
 static bool pc_available(int target_kind, int d, bool full_block);
+static bool split_ml_available(int target_kind, int d, bool full_block);
 static int32_t flush_exchanges(demcz_handle* h);
 static int32_t check_live_err(demcz_handle* h);
 
@@ -257,14 +260,22 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         int maxb = 0;
         for (int ib = 0; ib < cfg->Nblocks; ++ib) maxb = std::max(maxb, h->block_offsets[ib + 1] - h->block_offsets[ib]);
         const int L = ml_lanes_available(cfg->target_kind, d, h->full_block, cfg->nobs, maxb, cfg->Nblocks);
-        const bool split_ok = pc_available(cfg->target_kind, d, h->full_block) && cfg->Mcap <= 0xffffffffll;   // 32-bit row indices in the records
+        // 32-bit row indices in the records, 32-bit byte offsets into the archive
+        const bool idx32 = cfg->Mcap <= 0xffffffffll && (double)cfg->Mcap * 8.0 * (((d + 7) / 8) * 8) < 4294967296.0;
+        const int kind = !idx32 ? 0 : pc_available(cfg->target_kind, d, h->full_block) ? 1 : split_ml_available(cfg->target_kind, d, h->full_block) ? 2 : 0;
+        const bool split_ok = kind != 0;
+        h->split_kind = 0;
         if (cfg->lanes_per_chain == DEMCZ_LAYOUT_SPLIT) {
             if (!split_ok) {
                 h->err = "demcz_create: the split layout is not built for this target / d / block structure";
                 return bail(DEMCZ_ERR_INVALID_ARGUMENT);
             }
             h->lanes = DEMCZ_LAYOUT_SPLIT;
-        } else if (cfg->lanes_per_chain == 0 && split_ok && cfg->N <= 8192) {
+            h->split_kind = kind;
+        } else if (cfg->lanes_per_chain == 0 && split_ok && cfg->N <= (kind == 2 ? 4096 : 8192)) {
+            // (16 cooperating lanes, d = 20, us per K-window split / fused: N=1024 9.7 / 16.8, N=4096 16.6 / 21.0,
+            //  N=8192 35.5 / 29.8)
+            h->split_kind = kind;
             // idle CUs do the state-independent three quarters of the work.  Measured at d=5, us per
             // K-window, split / 8 lanes per chain / 1 lane: N=4096 8.6 / 12.4 / 30.0, N=16384 22.4 / 19.0 /
             // 32.6, N=32768 41.4 / 29.7 / 35.7, N=65536 77.7 / 54.5 / 40.9
@@ -540,6 +551,12 @@ static bool pc_available(int target_kind, int d, bool full_block)
     return target_kind == DEMCZ_TARGET_MVNORMAL && (d == 2 || d == 3 || d == 4 || d == 5 || d == 8 || d == 10);
 }
 
+// the split form of the 16-lane layout (window_kernel_ml<.., REC>): where the replicated consumer does not fit
+static bool split_ml_available(int target_kind, int d, bool full_block)
+{
+    return full_block && target_kind == DEMCZ_TARGET_MVNORMAL && d == 20;
+}
+
 static int pc_roles(int d) { return ((d == 1) ? 1 : (d + 1) / 2) + 2; }
 
 #ifdef DEMCZ_STAMPS
@@ -566,7 +583,11 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
     const int64_t nbc = (P.N + 63) / 64;
     const int64_t blocks = P.consumer_blocks + nbc * pc_roles(P.d) * P.next_ngen;
     if (blocks <= 0) return DEMCZ_OK;
-    if (h->cfg.target_kind == DEMCZ_TARGET_MVNORMAL) {
+    if (h->split_kind == 2) {
+        const dim3 grid((unsigned)blocks), wg(64);
+        if (live) hipLaunchKernelGGL((window_kernel_ml<TARGET_MVNORMAL, 20, 16, true, true>), grid, wg, 0, h->stream, P);
+        else hipLaunchKernelGGL((window_kernel_ml<TARGET_MVNORMAL, 20, 16, true, false>), grid, wg, 0, h->stream, P);
+    } else if (h->cfg.target_kind == DEMCZ_TARGET_MVNORMAL) {
         switch (P.d) {
         case 2: launch_pc<TARGET_MVNORMAL, 2>(h, P, blocks, live); break;
         case 3: launch_pc<TARGET_MVNORMAL, 3>(h, P, blocks, live); break;
@@ -616,7 +637,8 @@ static int32_t pc_prepare(demcz_handle* h, WindowParams& P, int64_t cur_rows, in
         dc.valid = true; dc.g_first = P.g_first; dc.M = P.M; dc.ngen = P.ngen; dc.rows = cur_rows; dc.boff = cur_boff;
     }
     P.rec_in = h->d_rec[cur];
-    P.consumer_blocks = (int32_t)((P.N + PC_CONSUMER_CHAINS - 1) / PC_CONSUMER_CHAINS);
+    const int per_wg = (h->split_kind == 2) ? 4 : PC_CONSUMER_CHAINS;       // chains per consumer workgroup
+    P.consumer_blocks = (int32_t)((P.N + per_wg - 1) / per_wg);
     P.rec_out = h->d_rec[cur ^ 1];
     P.next_g_first = next_g; P.next_ngen = (int32_t)std::max<int64_t>(next_ngen, 0); P.next_M = next_M;
     P.next_rows = next_rows; P.next_boff = next_boff;
@@ -804,11 +826,53 @@ static int32_t check_live_err(demcz_handle* h)
     return DEMCZ_OK;
 }
 
+// The consumer workgroups of a LIVE launch wait for each other's rows, so all of them must be resident at
+// once.  Capacity = what the occupancy query gives for the LIVE instantiation of this handle's kernel
+// (both accept variants) x CUs; half of it is used, which leaves room for the producer half, for other
+// streams' kernels and for the query being one block per CU optimistic (MI355X_MICROARCH.md, residency).
+// Beyond that the split layout falls back to one launch per K-window.
+template <int TARGET, int D>
+static int pc_live_blocks_per_cu()
+{
+    int a = 0, b = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&window_kernel_pc8<TARGET, D, true, false>), 64, 0) != hipSuccess) a = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(&window_kernel_pc8<TARGET, D, true, true>), 64, 0) != hipSuccess) b = 0;
+    return std::min(a, b);
+}
+
+static int64_t live_wg_capacity(demcz_handle* h)
+{
+    if (h->live_wg_cap >= 0) return h->live_wg_cap;
+    int per_cu = 0;
+    if (h->split_kind == 2) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&window_kernel_ml<TARGET_MVNORMAL, 20, 16, true, true>), 64, 0) != hipSuccess) per_cu = 0;
+    } else if (h->cfg.target_kind == DEMCZ_TARGET_ISO_QUAD) {
+        per_cu = pc_live_blocks_per_cu<TARGET_ISO_QUAD, 10>();
+    } else {
+        switch (h->cfg.d) {
+        case 2: per_cu = pc_live_blocks_per_cu<TARGET_MVNORMAL, 2>(); break;
+        case 3: per_cu = pc_live_blocks_per_cu<TARGET_MVNORMAL, 3>(); break;
+        case 4: per_cu = pc_live_blocks_per_cu<TARGET_MVNORMAL, 4>(); break;
+        case 5: per_cu = pc_live_blocks_per_cu<TARGET_MVNORMAL, 5>(); break;
+        case 8: per_cu = pc_live_blocks_per_cu<TARGET_MVNORMAL, 8>(); break;
+        case 10: per_cu = pc_live_blocks_per_cu<TARGET_MVNORMAL, 10>(); break;
+        default: per_cu = 0;
+        }
+    }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device_id) != hipSuccess) cus = 0;
+    h->live_wg_cap = (int64_t)per_cu * cus / 2;
+    return h->live_wg_cap;
+}
+
 // Generations one LIVE launch of the split layout may span (0: not applicable -- other layouts, sharded
-// runs, deferred visibility, appends owned by the caller).  Bounded by the draw records it needs.
-static int64_t live_span(const demcz_handle* h)
+// runs, deferred visibility, appends owned by the caller, more consumer workgroups than may wait for each
+// other).  Bounded by the draw records it needs.
+static int64_t live_span(demcz_handle* h)
 {
     if (h->lanes != DEMCZ_LAYOUT_SPLIT || h->comm || h->lag > 0 || h->external_append) return 0;
+    const int per_wg = (h->split_kind == 2) ? 4 : PC_CONSUMER_CHAINS;
+    if ((h->cfg.N + per_wg - 1) / per_wg > live_wg_capacity(h)) return 0;
     const int64_t per_gen = (int64_t)(h->cfg.d + 2) * h->cfg.N * (int64_t)sizeof(double);
     const int64_t span = (int64_t)(64ll << 20) / per_gen;        // 64 MiB of records per buffer (C2: 1170 generations)
     return std::max<int64_t>(h->cfg.K, std::min<int64_t>(span, 1 << 20));

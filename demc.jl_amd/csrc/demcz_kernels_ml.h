@@ -18,36 +18,13 @@
 // Restates the same reference functions as window_kernel (src/demcz.jl:80-93,167-203).
 #pragma once
 
-#include "demcz_kernels.h"
+#include "demcz_kernels_rec.h"
 
 #include <type_traits>
 
 #pragma clang fp contract(off)
 
 namespace demcz {
-
-// rocRAND's Philox4x32-10 round function used as a pure counter -> block map:
-// block(seed, chain, blk) == rocrand_init(seed, chain, 4*blk) followed by rocrand4().
-struct philox_blocks : rocrand_device::philox4x32_10_engine {
-    __device__ __forceinline__ philox_blocks() {}
-    __device__ __forceinline__ void block(uint64_t seed, uint64_t chain, uint64_t blk, uint64_t& r1, uint64_t& r2)
-    {
-        uint4 ctr = {(unsigned)blk, (unsigned)(blk >> 32), (unsigned)chain, (unsigned)(chain >> 32)};
-        uint2 key = {(unsigned)seed, (unsigned)(seed >> 32)};
-        uint4 w = this->ten_rounds(ctr, key);
-        r1 = (uint64_t)w.x | ((uint64_t)w.y << 32);
-        r2 = (uint64_t)w.z | ((uint64_t)w.w << 32);
-    }
-};
-
-// LDS hand-offs between lanes of ONE wave: the hardware keeps a wave's LDS operations in order, so
-// all that is needed is to stop the compiler from moving memory operations across the hand-off.
-__device__ __forceinline__ void wave_lds_handoff()
-{
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
-}
 
 // Workgroup geometry: MvNormal / isotropic targets run one wave per workgroup (small N spreads
 // over as many CUs as there are waves).  The regression target keeps the whole design matrix and
@@ -68,10 +45,23 @@ __host__ __device__ constexpr size_t ml_dynamic_lds(int64_t nobs)
     return (size_t)NG * S * 16 + (size_t)NG * DP * 8 + (size_t)NG * L * 8 + (size_t)(((nobs + 1) / 2) * 2) * 8 + (size_t)nobs * D * 8;
 }
 
-template <int TARGET, int D, int L>
+// REC: the split form of this layout (demcz_kernels_rec.h) -- workgroups beyond consumer_blocks are the
+// producer half (draw records for the next launch), the others read this launch's records instead of
+// drawing: what is left per generation is the state-dependent part.  LIVE: the launch runs through K
+// boundaries and takes appended rows from other waves through the archive itself (sentinel + sc1).
+// Used where the eight-replicated-lanes consumer does not fit (d = 20: 210 whitening coefficients).
+template <int TARGET, int D, int L, bool REC = false, bool LIVE = false>
 __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(const WindowParams P)
 {
     constexpr bool LR = (TARGET == TARGET_LINREG_SSE);
+    static_assert(!REC || !LR, "the split form is for the MvNormal / isotropic targets");
+    static_assert(!LIVE || REC, "LIVE launches are a property of the split form");
+    if constexpr (REC) {
+        if ((int64_t)blockIdx.x >= P.consumer_blocks) {
+            pc_produce<D>(P, (int64_t)blockIdx.x - P.consumer_blocks);
+            return;
+        }
+    }
     constexpr int WAVES = ml_waves<TARGET>();
     constexpr int G = 64 / L;                              // chains per wave
     constexpr int NG = WAVES * G;                          // chains per workgroup
@@ -134,7 +124,29 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
     }
     double lp = P.lpcur[c];
     const double scale = (D == 1) ? P.gamma : P.gamma / sqrt((double)(2 * D));
-    philox_blocks rng;
+    [[maybe_unused]] philox_blocks rng;
+    // REC: this lane's fields of the draw records; a generation is rec_gs doubles further on.  The packed
+    // row indices are fetched one generation ahead of the gather that needs them.
+    [[maybe_unused]] const double* rq_z[NP];
+    [[maybe_unused]] const double* rq_lg = nullptr;
+    [[maybe_unused]] const double* rq_ix = nullptr;
+    [[maybe_unused]] int64_t rec_gs = 0;
+    [[maybe_unused]] uint64_t ix_next = 0;
+    [[maybe_unused]] uint32_t ra = 0, rb = 0, ra_c = 0, rb_c = 0;     // rows of the gather in flight / being consumed
+    if constexpr (REC) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int p = r + L * k;
+            rq_z[k] = P.rec_in + (int64_t)((D == 1) ? 0 : ((p < D) ? p : 0)) * P.N + c;
+        }
+        rq_lg = P.rec_in + (int64_t)D * P.N + c;
+        rq_ix = P.rec_in + (int64_t)(D + 1) * P.N + c;
+        rec_gs = (int64_t)(D + 2) * P.N;
+        ix_next = (uint64_t)__double_as_longlong(rq_ix[0]);
+        if constexpr (LIVE) {       // an earlier launch of the run already failed: do not wait again
+            if (__hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+        }
+    }
 
     // Draws and archive gathers do not depend on the chain state (the row indices come from the
     // counter-based stream), so generation g+1's are issued before generation g's accept resolves:
@@ -144,6 +156,28 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
     int to_b = P.to_boundary;            // countdown to the next K boundary
     int64_t nb = 0;                      // boundaries passed inside this launch
     auto issue_draws = [&](int gi) {
+        if constexpr (REC) {
+            const uint64_t ii = ix_next;
+            const int gn = (gi + 1 < P.ngen) ? gi + 1 : gi;
+            ix_next = (uint64_t)__double_as_longlong(rq_ix[gn * rec_gs]);
+            logu_next = rq_lg[gi * rec_gs];
+            ra = (uint32_t)ii;
+            rb = (uint32_t)(ii >> 32);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int p = r + L * k;
+                const int pc = (p < D) ? p : 0;
+                zt[k] = rq_z[k][gi * rec_gs];
+                if constexpr (LIVE) {
+                    za[k] = live_load(&P.Z[(int64_t)ra * P.ZS + pc]);
+                    zb[k] = live_load(&P.Z[(int64_t)rb * P.ZS + pc]);
+                } else {
+                    za[k] = P.Z[(int64_t)ra * P.ZS + pc];
+                    zb[k] = P.Z[(int64_t)rb * P.ZS + pc];
+                }
+            }
+            return;
+        }
         uint64_t r1, r2, i1, i2;
         rng.block(P.seed, chain, (uint64_t)(P.g_first + gi - 1) * (uint64_t)S + (uint64_t)role, r1, r2);
         const double lg = dm_log(u_open(r1));
@@ -179,11 +213,33 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
 
     // One generation; PREFETCH issues the next generation's draws in the middle of it.  The last
     // generation of the window is a second instantiation without the prefetch (nothing to draw for).
-    auto generation = [&](int gi, auto prefetch) {
+    auto generation = [&](int gi, auto prefetch) -> bool {
 #pragma unroll
         for (int k = 0; k < NP; ++k) { za_c[k] = za[k]; zb_c[k] = zb[k]; zt_c[k] = zt[k]; }
         const double logu = logu_next;
+        ra_c = ra; rb_c = rb;
         if constexpr (decltype(prefetch)::value) issue_draws(gi + 1);
+        if constexpr (LIVE) {
+            // the gather was issued a generation ago; rows appended since then by other waves read as the
+            // sentinel until they are published: ask again (demcz_kernels_rec.h)
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) bad |= is_sentinel(za_c[k]) | is_sentinel(zb_c[k]);
+            int spins = 0;
+            while (__builtin_amdgcn_ballot_w64(bad) != 0ull) {       // wave-uniform
+                if (live_poll_abandon(P, spins, bad, is_sentinel(za_c[0]) ? ra_c : rb_c, gi)) return true;
+                __builtin_amdgcn_s_sleep(1);
+                bad = false;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const int p = r + L * k;
+                    const int pc = (p < D) ? p : 0;
+                    if (is_sentinel(za_c[k])) za_c[k] = live_load(&P.Z[(int64_t)ra_c * P.ZS + pc]);
+                    if (is_sentinel(zb_c[k])) zb_c[k] = live_load(&P.Z[(int64_t)rb_c * P.ZS + pc]);
+                    bad |= is_sentinel(za_c[k]) | is_sentinel(zb_c[k]);
+                }
+            }
+        }
         double delta[NP];
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -316,16 +372,22 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
             for (int k = 0; k < NP; ++k) {
                 const int p = r + L * k;
                 if (p < D && active) {
-                    if (P.do_append) P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p] = x[k];
+                    if (P.do_append) {
+                        if constexpr (LIVE) live_store(&P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p], x[k]);
+                        else P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p] = x[k];
+                    }
                     if (P.snap) P.snap[nb * P.N * D + c + P.N * p] = x[k];
                 }
             }
             ++nb;
         }
         wave_lds_handoff();      // rvec / yvec are rewritten by the next generation
+        return false;
     };
-    for (int gi = 0; gi + 1 < P.ngen; ++gi) generation(gi, std::true_type{});
-    generation(P.ngen - 1, std::false_type{});
+    // (a true return: a LIVE wait was abandoned -- the launch drains, the host reports live_err)
+    for (int gi = 0; gi + 1 < P.ngen; ++gi)
+        if (generation(gi, std::true_type{})) return;
+    if (generation(P.ngen - 1, std::false_type{})) return;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int p = r + L * k;

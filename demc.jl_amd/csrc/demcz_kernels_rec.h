@@ -1,0 +1,123 @@
+// demcz_kernels_rec.h -- what the split layouts share (demcz_kernels_pc.h: eight replicated lanes per
+// chain; demcz_kernels_ml.h, REC variant: L cooperating lanes per chain):
+//   * the draw records and the producer half of a launch that fills them for the NEXT launch;
+//   * the in-launch hand-off of appended archive rows (LIVE launches);
+//   * Philox as a pure counter -> block map, and the one-wave LDS hand-off.
+#pragma once
+
+#include "demcz_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace demcz {
+
+// rocRAND's Philox4x32-10 round function used as a pure counter -> block map:
+// block(seed, chain, blk) == rocrand_init(seed, chain, 4*blk) followed by rocrand4().
+struct philox_blocks : rocrand_device::philox4x32_10_engine {
+    __device__ __forceinline__ philox_blocks() {}
+    __device__ __forceinline__ void block(uint64_t seed, uint64_t chain, uint64_t blk, uint64_t& r1, uint64_t& r2)
+    {
+        uint4 ctr = {(unsigned)blk, (unsigned)(blk >> 32), (unsigned)chain, (unsigned)(chain >> 32)};
+        uint2 key = {(unsigned)seed, (unsigned)(seed >> 32)};
+        uint4 w = this->ten_rounds(ctr, key);
+        r1 = (uint64_t)w.x | ((uint64_t)w.y << 32);
+        r2 = (uint64_t)w.z | ((uint64_t)w.w << 32);
+    }
+};
+
+// LDS hand-offs between lanes of ONE wave: the hardware keeps a wave's LDS operations in order, so
+// all that is needed is to stop the compiler from moving memory operations across the hand-off.
+__device__ __forceinline__ void wave_lds_handoff()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// record layout: rec[(g * (D + 2) + f) * N + c], f = 0..D-1 normals, D log u, D+1 the two row indices
+// packed as 32-bit halves (the split layout is only selected while the archive has < 2^32 rows)
+template <int D>
+__device__ __forceinline__ size_t rec_index(int64_t N, int g, int f, int64_t c) { return ((size_t)g * (D + 2) + f) * (size_t)N + (size_t)c; }
+
+template <int D>
+__device__ __forceinline__ void pc_produce(const WindowParams& P, int64_t pb)
+{
+    constexpr int NPAIRS = (D == 1) ? 1 : (D + 1) / 2;
+    constexpr int S = NPAIRS + 2;                          // Philox blocks of a generation = producer roles
+    const int64_t nbc = (P.N + 63) / 64;                   // workgroups per (generation, role) plane
+    const int64_t plane = pb / nbc;                        // wave-uniform
+    const int64_t c = (pb % nbc) * 64 + threadIdx.x;
+    const int role = (int)(plane % S), gi = (int)(plane / S);
+    if (gi >= P.next_ngen || c >= P.N) return;
+    philox_blocks rng;
+    uint64_t r1, r2;
+    rng.block(P.seed, (uint64_t)(P.chain_id0 + c), (uint64_t)(P.next_g_first + gi - 1) * (uint64_t)S + (uint64_t)role, r1, r2);
+    double* rec = P.rec_out;
+    if (role == 0) {
+        // rows generation gi of the next launch draws from: those it starts with plus, where appended rows
+        // are visible at once, N per K boundary it has passed by then (update_demcz_chain_block, demcz.jl:176-179)
+        const int64_t Mg = P.next_M + (int64_t)((gi + P.next_boff) / P.K) * P.next_rows;
+        uint64_t i1, i2;
+        draw_rows(r1, r2, (uint64_t)Mg, i1, i2);
+        rec[rec_index<D>(P.N, gi, D + 1, c)] = __longlong_as_double((long long)(i1 | (i2 << 32)));
+    } else {
+        const double lg = dm_log(u_open(r1));
+        if (role == S - 1) {
+            rec[rec_index<D>(P.N, gi, D, c)] = lg;
+        } else {
+            const double R = sqrt(-2.0 * lg);
+            double cs, sn;
+            dm_sincos2pi(r2 >> 11, cs, sn);
+            const int p0 = (D == 1) ? 0 : 2 * (role - 1);
+            rec[rec_index<D>(P.N, gi, p0, c)] = R * cs;
+            if (p0 + 1 < D) rec[rec_index<D>(P.N, gi, p0 + 1, c)] = R * sn;
+        }
+    }
+}
+
+// LIVE launches (single GPU, the reference's immediate visibility): one launch runs through several
+// K boundaries.  The rows a boundary appends are drawn from in the very next generation, by any chain,
+// so waves hand rows to each other INSIDE the launch, and they do it through the data itself:
+//   * the unwritten part of the archive holds a sentinel (a signalling-NaN pattern no arithmetic
+//     produces: results have the quiet bit set);
+//   * a wave appends its chains' rows with write-through (sc1) 8-byte stores;
+//   * every archive gather of such a launch is an sc1 load (served past the CU's L1) and is repeated
+//     while it returns the sentinel -- each double is its own naturally aligned 8-byte granule, so
+//     nothing needs ordering, flags, fences or a grid barrier (MI355X_MICROARCH.md, inter-workgroup
+//     visibility: sc1 stores + sc1 loads, data-tagged granules).
+// A wave only ever waits for rows of an EARLIER boundary than the one it is working towards, so the
+// waits cannot form a cycle; all consumer workgroups are single waves and co-resident (N <= 8192:
+// at most 1024 of them on 256 CUs).  A bounded spin turns a lost row into an error word, not a hang.
+constexpr unsigned long long LIVE_SENTINEL = 0xFFF4DEADC0DE5EEDull;
+constexpr int LIVE_SPIN_LIMIT = 1 << 18;      // ~0.1-0.3 s of polling
+
+__device__ __forceinline__ double live_load(const double* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void live_store(double* p, double v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool is_sentinel(double v) { return (unsigned long long)__double_as_longlong(v) == LIVE_SENTINEL; }
+
+
+// One bounded poll step of a LIVE wait, shared by the consumers: returns true when the wave must give
+// up -- its own poll limit, or another wave's (live_err[0]; looked at every 256 polls so that a failed
+// launch drains within microseconds).  The first lane to time out records what it was waiting for:
+// [1] generation of the launch, [2] archive row, [3] workgroup.
+__device__ __forceinline__ bool live_poll_abandon(const WindowParams& P, int& spins, bool lane_waiting, unsigned row, int gi)
+{
+    const bool timeout = (++spins > LIVE_SPIN_LIMIT);
+    bool abandon = timeout;
+    if (!timeout && (spins & 255) == 0)
+        abandon = __hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    if (abandon && timeout && lane_waiting) {
+        if (atomicCAS(P.live_err, 0u, 1u) == 0u) {
+            P.live_err[1] = (unsigned)gi; P.live_err[2] = row; P.live_err[3] = blockIdx.x;
+        }
+    }
+    return abandon;
+}
+
+}  // namespace demcz

@@ -87,7 +87,8 @@ typedef struct demcz_config {
                                      fused (throughput layout, large N); 8 / 16 = that many lanes
                                      cooperate on a chain; DEMCZ_LAYOUT_SPLIT = producer workgroups
                                      make the state-independent draws one launch ahead, consumer
-                                     lanes run the chains (small N).  Results are bit-identical.   */
+                                     lanes run the chains, and on one GPU a launch runs through many
+                                     K boundaries (small N).  Results are bit-identical.           */
     int32_t reserved0;
 } demcz_config;
 

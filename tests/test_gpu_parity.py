@@ -38,7 +38,7 @@ def test_mvnormal_full_block_bit_exact(demc, oracle, N, d, G, lanes):
                                       verbose=False, seed=seed, lanes_per_chain=lanes, return_runner=True)
     used = runner.engines[0].info()["lanes_per_chain"]
     runner.close()
-    assert used == (1 if d == 7 else ((16 if d == 20 else 100) if lanes == 0 else lanes))
+    assert used == (1 if d == 7 else (100 if lanes == 0 else lanes))
     ref = oracle_sample(oracle, w["target"], w["Zinit"], N, w["K"], G, None, w["eps_scale"], w["gamma"], seed)
     assert np.array_equal(mc.chain, ref["chain"])
     assert np.array_equal(mc.log_obj, ref["log_obj"])
