@@ -130,7 +130,7 @@ def main():
     ap.add_argument("--no-sweep", action="store_true", help="skip the chain-count sweep object")
     ap.add_argument("--lanes-per-chain", type=int, default=0)
     ap.add_argument("--append-lag", type=int, default=-1,
-                    help="demcz_set_append_lag batches; default 0 on one GPU (the reference's schedule), 3 when sharded "
+                    help="demcz_set_append_lag batches; default 0 on one GPU (the reference's schedule), 10 when sharded "
                          "(the K-boundary all-gather overlaps the next windows)")
     args = ap.parse_args()
 
@@ -155,7 +155,9 @@ def main():
         from demc_jl_amd.dist import torch_sharding
         sharding = torch_sharding(mode="rccl")
 
-    lag = args.append_lag if args.append_lag >= 0 else (0 if world == 1 else 3)
+    # sharded default: 10 boundaries per all-gather -- a batch (100 generations, ~35 us of compute) then outlasts a
+    # latency-bound 8-rank all-gather, which 3 boundaries (~12 us) would not
+    lag = args.append_lag if args.append_lag >= 0 else (0 if world == 1 else 10)
     d, K, n_loc = args.dim, 10, args.chains_per_gpu
     N = n_loc * world
     W, S = args.warmup, args.steps

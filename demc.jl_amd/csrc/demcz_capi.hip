@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <deque>
 #include <cmath>
 #include <cstdio>
@@ -871,6 +872,8 @@ static int64_t live_wg_capacity(demcz_handle* h)
 static int64_t live_span(demcz_handle* h)
 {
     if (h->lanes != DEMCZ_LAYOUT_SPLIT || h->comm || h->lag > 0 || h->external_append) return 0;
+    static const bool disabled = (getenv("DEMCZ_NO_LIVE") != nullptr);     // safety valve: one launch per K-window
+    if (disabled) return 0;
     const int per_wg = (h->split_kind == 2) ? 4 : PC_CONSUMER_CHAINS;
     if ((h->cfg.N + per_wg - 1) / per_wg > live_wg_capacity(h)) return 0;
     const int64_t per_gen = (int64_t)(h->cfg.d + 2) * h->cfg.N * (int64_t)sizeof(double);
