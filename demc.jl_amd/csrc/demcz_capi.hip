@@ -563,7 +563,8 @@ static int pc_roles(int d) { return ((d == 1) ? 1 : (d + 1) / 2) + 2; }
 #ifdef DEMCZ_STAMPS
 constexpr int64_t DEMCZ_STAMP_WGS = 1 << 16;
 #endif
-constexpr int PC_CONSUMER_CHAINS = 8;       // chains per consumer workgroup: 8 lanes per chain
+constexpr int PC_CONSUMER_CHAINS = 8;
+constexpr size_t REC_PAD = 32;       // chains per consumer workgroup: 8 lanes per chain
 
 template <int TARGET, int D>
 static void launch_pc(const demcz_handle* h, const WindowParams& P, int64_t blocks, bool live)
@@ -618,12 +619,14 @@ static int32_t pc_prepare(demcz_handle* h, WindowParams& P, int64_t cur_rows, in
         for (int b = 0; b < 2; ++b) {
             if (h->d_rec[b]) HIPCHK(h, hipFree(h->d_rec[b]));
             h->d_rec[b] = nullptr;
-            HIPCHK(h, hipMalloc((void**)&h->d_rec[b], (size_t)need * (d + 2) * h->cfg.N * sizeof(double)));
-            HIPCHK(h, hipMemsetAsync(h->d_rec[b], 0, (size_t)need * (d + 2) * h->cfg.N * sizeof(double), h->stream));   // row 0: always a legal index
+            // (+ REC_PAD doubles: a consumer's last 16-byte chunk fetch may run past its row's last generation)
+            HIPCHK(h, hipMalloc((void**)&h->d_rec[b], ((size_t)need * (d + 2) * h->cfg.N + REC_PAD) * sizeof(double)));
+            HIPCHK(h, hipMemsetAsync(h->d_rec[b], 0, ((size_t)need * (d + 2) * h->cfg.N + REC_PAD) * sizeof(double), h->stream));   // row 0: always a legal index
             h->rec_desc[b].valid = false;
         }
         h->rec_cap = need;
     }
+    P.rec_stride = h->rec_cap;
     const int cur = h->rec_cur;
     const int32_t cur_boff = P.K - P.to_boundary;
     auto& dc = h->rec_desc[cur];
@@ -930,7 +933,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     P.snap = nullptr;
     P.K = K;
     P.rec_in = nullptr; P.rec_out = nullptr; P.next_g_first = 0; P.next_M = 0; P.next_ngen = 0; P.consumer_blocks = 0;
-    P.next_rows = 0; P.next_boff = 0;
+    P.next_rows = 0; P.next_boff = 0; P.rec_stride = 0;
 #ifdef DEMCZ_STAMPS
     if (!h->d_stamps) {
         HIPCHK(h, hipMalloc((void**)&h->d_stamps, (size_t)DEMCZ_STAMP_WGS * 8 * sizeof(unsigned long long)));

@@ -79,6 +79,7 @@ struct WindowParams {
     // producer half of the launch prepares for the NEXT one
     const double* rec_in;
     double* rec_out;
+    int64_t rec_stride;      // generations each (field, chain) row of a record buffer holds
     int64_t next_g_first;    // stream generation index of the next launch's first generation
     int64_t next_M;          // rows its first generation draws from
     int64_t next_rows;       // ... plus this many per K boundary it has passed (0: appended rows become visible later)

@@ -125,23 +125,21 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
     double lp = P.lpcur[c];
     const double scale = (D == 1) ? P.gamma : P.gamma / sqrt((double)(2 * D));
     [[maybe_unused]] philox_blocks rng;
-    // REC: this lane's fields of the draw records; a generation is rec_gs doubles further on.  The packed
+    // REC: this lane's fields of the draw records (one double per generation, contiguous).  The packed
     // row indices are fetched one generation ahead of the gather that needs them.
     [[maybe_unused]] const double* rq_z[NP];
     [[maybe_unused]] const double* rq_lg = nullptr;
     [[maybe_unused]] const double* rq_ix = nullptr;
-    [[maybe_unused]] int64_t rec_gs = 0;
     [[maybe_unused]] uint64_t ix_next = 0;
     [[maybe_unused]] uint32_t ra = 0, rb = 0, ra_c = 0, rb_c = 0;     // rows of the gather in flight / being consumed
     if constexpr (REC) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int p = r + L * k;
-            rq_z[k] = P.rec_in + (int64_t)((D == 1) ? 0 : ((p < D) ? p : 0)) * P.N + c;
+            rq_z[k] = P.rec_in + ((int64_t)((D == 1) ? 0 : ((p < D) ? p : 0)) * P.N + c) * P.rec_stride;
         }
-        rq_lg = P.rec_in + (int64_t)D * P.N + c;
-        rq_ix = P.rec_in + (int64_t)(D + 1) * P.N + c;
-        rec_gs = (int64_t)(D + 2) * P.N;
+        rq_lg = P.rec_in + ((int64_t)D * P.N + c) * P.rec_stride;
+        rq_ix = P.rec_in + ((int64_t)(D + 1) * P.N + c) * P.rec_stride;
         ix_next = (uint64_t)__double_as_longlong(rq_ix[0]);
         if constexpr (LIVE) {       // an earlier launch of the run already failed: do not wait again
             if (__hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
@@ -159,15 +157,15 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
         if constexpr (REC) {
             const uint64_t ii = ix_next;
             const int gn = (gi + 1 < P.ngen) ? gi + 1 : gi;
-            ix_next = (uint64_t)__double_as_longlong(rq_ix[gn * rec_gs]);
-            logu_next = rq_lg[gi * rec_gs];
+            ix_next = (uint64_t)__double_as_longlong(rq_ix[gn]);
+            logu_next = rq_lg[gi];
             ra = (uint32_t)ii;
             rb = (uint32_t)(ii >> 32);
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const int p = r + L * k;
                 const int pc = (p < D) ? p : 0;
-                zt[k] = rq_z[k][gi * rec_gs];
+                zt[k] = rq_z[k][gi];
                 if constexpr (LIVE) {
                     za[k] = live_load(&P.Z[(int64_t)ra * P.ZS + pc]);
                     zb[k] = live_load(&P.Z[(int64_t)rb * P.ZS + pc]);

@@ -113,10 +113,22 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
     // record pointers of this lane's fields; a generation is a uniform stride further on
     const double* rec_z[NP];
 #pragma unroll
-    for (int k = 0; k < NP; ++k) rec_z[k] = P.rec_in + (int64_t)((D == 1) ? 0 : pk[k]) * P.N + c;
-    const double* rec_lg = P.rec_in + (int64_t)D * P.N + c;
-    const int64_t rec_gs = (int64_t)(D + 2) * P.N;
-    const double* rec_ix = P.rec_in + (int64_t)(D + 1) * P.N + c;
+    for (int k = 0; k < NP; ++k) rec_z[k] = P.rec_in + ((int64_t)((D == 1) ? 0 : pk[k]) * P.N + c) * P.rec_stride;
+    const double* rec_lg = P.rec_in + ((int64_t)D * P.N + c) * P.rec_stride;
+    const double* rec_ix = P.rec_in + ((int64_t)(D + 1) * P.N + c) * P.rec_stride;
+    // a chunk's CH consecutive generations of one field: CHP/2 16-byte loads off one address (8-byte aligned:
+    // a chunk may start at an odd generation).  Reads up to CHP - 1 generations past the launch's last one:
+    // the buffers are padded; those slots are never used.
+    constexpr int CHP = ((CH + 1) / 2) * 2;
+    typedef double pair8 __attribute__((ext_vector_type(2), aligned(8)));
+    auto fetch_chunk = [](const double* base, double (&out)[CHP]) {
+#pragma unroll
+        for (int j = 0; j < CHP / 2; ++j) {
+            const pair8 t = reinterpret_cast<const pair8*>(base)[j];
+            out[2 * j] = t.x;
+            out[2 * j + 1] = t.y;
+        }
+    };
     // archive addressing: row stride and the whole archive fit 32 bits of byte offset (condition of this
     // layout), the row stride is a power of two for every dimension built: one shift-add per element
     constexpr int ZSC = (D <= 2) ? 2 : (D <= 4) ? 4 : ((D + 7) / 8) * 8;
@@ -127,12 +139,8 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
 #pragma unroll
     for (int k = 0; k < NP; ++k) pk8[k] = (uint32_t)pk[k] * 8u;
     // row indices of the first chunk; from then on they are fetched one chunk ahead
-    uint64_t ixn[CH];
-#pragma unroll
-    for (int u = 0; u < CH; ++u) {
-        const int g = (u < P.ngen) ? u : P.ngen - 1;
-        ixn[u] = (uint64_t)__double_as_longlong(rec_ix[g * rec_gs]);
-    }
+    double ixn[CHP];           // (bit patterns of the packed 32-bit index pairs)
+    fetch_chunk(rec_ix, ixn);
 
     // A chunk is up to CH generations whose draws are fetched together.  It ends at the next K boundary:
     // the append then sits between chunks, not inside the generation code, and in a LIVE launch the
@@ -151,26 +159,26 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
 #endif
         len = (P.ngen - g0 < CH) ? P.ngen - g0 : CH;
         len = (to_b < len) ? to_b : len;
-        double lgu[CH], dmine[CH][NP];
+        double lgu[CHP], dmine[CH][NP];
         [[maybe_unused]] double tmpr[CH];
         {
             // records first: their latency runs beside the index draws and the archive gather
-            double za[CH][NP], zb[CH][NP], zt[CH][NP];
+            double za[CH][NP], zb[CH][NP], zt[NP][CHP];
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const int g = g0 + ((u < len) ? u : len - 1);
+            for (int k = 0; k < NP; ++k) fetch_chunk(rec_z[k] + g0, zt[k]);
+            fetch_chunk(rec_lg + g0, lgu);
+            if constexpr (TEMPER) {
 #pragma unroll
-                for (int k = 0; k < NP; ++k) zt[u][k] = rec_z[k][g * rec_gs];
-                lgu[u] = rec_lg[g * rec_gs];
-                if constexpr (TEMPER) tmpr[u] = P.temperature[g];
+                for (int u = 0; u < CH; ++u) tmpr[u] = P.temperature[g0 + ((u < len) ? u : len - 1)];
             }
             // the two archive rows of every generation of the chunk (indices fetched during the previous chunk)
             uint32_t o1[CH], o2[CH];
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 // slots past the end of the chunk read row 0: their own rows may not exist yet (LIVE: never wait for them)
-                o1[u] = (u < len) ? (uint32_t)ixn[u] << ZSHIFT : 0u;
-                o2[u] = (u < len) ? (uint32_t)(ixn[u] >> 32) << ZSHIFT : 0u;
+                const uint64_t ii = (uint64_t)__double_as_longlong(ixn[u]);
+                o1[u] = (u < len) ? (uint32_t)ii << ZSHIFT : 0u;
+                o2[u] = (u < len) ? (uint32_t)(ii >> 32) << ZSHIFT : 0u;
             }
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
@@ -183,21 +191,30 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
                 }
             }
             // next chunk's indices (it starts at g0 + len)
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const int g = (g0 + len + u < P.ngen) ? g0 + len + u : P.ngen - 1;
-                ixn[u] = (uint64_t)__double_as_longlong(rec_ix[g * rec_gs]);
-            }
+            fetch_chunk(rec_ix + g0 + len, ixn);
             // nothing that waits for a record may be scheduled in front of the gather's issue
             __builtin_amdgcn_sched_barrier(0);
             if (g0 == stamp_g0) DEMCZ_STAMP(P, 2);
             if constexpr (LIVE) {
-                // rows another wave has not published yet read as the sentinel: ask again
-                bool bad = false;
+                // rows another wave has not published yet read as the sentinel: ask again.  Cheap filter first:
+                // the sentinel's high word is that of a negative NaN, above every finite value's, -inf's and
+                // the canonical NaN's -- one max3 per row pair instead of two 64-bit compares
+                uint32_t hmax = 0u;
 #pragma unroll
                 for (int u = 0; u < CH; ++u)
 #pragma unroll
-                    for (int k = 0; k < NP; ++k) bad |= is_sentinel(za[u][k]) | is_sentinel(zb[u][k]);
+                    for (int k = 0; k < NP; ++k) {
+                        const uint32_t ha = (uint32_t)((uint64_t)__double_as_longlong(za[u][k]) >> 32);
+                        const uint32_t hb = (uint32_t)((uint64_t)__double_as_longlong(zb[u][k]) >> 32);
+                        hmax = max(hmax, max(ha, hb));
+                    }
+                bool bad = false;
+                if (__builtin_amdgcn_ballot_w64(hmax >= (uint32_t)(LIVE_SENTINEL >> 32)) != 0ull) {
+#pragma unroll
+                    for (int u = 0; u < CH; ++u)
+#pragma unroll
+                        for (int k = 0; k < NP; ++k) bad |= is_sentinel(za[u][k]) | is_sentinel(zb[u][k]);
+                }
                 int spins = 0;
                 while (__builtin_amdgcn_ballot_w64(bad) != 0ull) {           // wave-uniform
                     // give up after LIVE_SPIN_LIMIT polls, or as soon as any wave of the launch has given up
@@ -256,7 +273,7 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
                 for (int k = 0; k < NP; ++k) {
                     const double diff = za[u][k] - zb[u][k];
                     const double t1 = scale * diff;
-                    const double t2 = epsv[k] * zt[u][k];
+                    const double t2 = epsv[k] * zt[k][u];
                     dmine[u][k] = t1 + t2;
                     if (r + L * k < D) sdelta[(gq * CH + u) * DP + r + L * k] = dmine[u][k];
                 }

@@ -34,10 +34,11 @@ __device__ __forceinline__ void wave_lds_handoff()
     asm volatile("" ::: "memory");
 }
 
-// record layout: rec[(g * (D + 2) + f) * N + c], f = 0..D-1 normals, D log u, D+1 the two row indices
-// packed as 32-bit halves (the split layout is only selected while the archive has < 2^32 rows)
-template <int D>
-__device__ __forceinline__ size_t rec_index(int64_t N, int g, int f, int64_t c) { return ((size_t)g * (D + 2) + f) * (size_t)N + (size_t)c; }
+// record layout: rec[(f * N + c) * GS + g], f = 0..D-1 normals, D log u, D+1 the two row indices packed
+// as 32-bit halves (the split layout is only selected while the archive has < 2^32 rows); GS =
+// WindowParams::rec_stride generations.  The generations of one (field, chain) are contiguous: a
+// consumer lane fetches a chunk of ten with five 16-byte loads off one address.
+__device__ __forceinline__ size_t rec_index(int64_t N, int64_t GS, int g, int f, int64_t c) { return ((size_t)f * (size_t)N + (size_t)c) * (size_t)GS + (size_t)g; }
 
 template <int D>
 __device__ __forceinline__ void pc_produce(const WindowParams& P, int64_t pb)
@@ -59,18 +60,18 @@ __device__ __forceinline__ void pc_produce(const WindowParams& P, int64_t pb)
         const int64_t Mg = P.next_M + (int64_t)((gi + P.next_boff) / P.K) * P.next_rows;
         uint64_t i1, i2;
         draw_rows(r1, r2, (uint64_t)Mg, i1, i2);
-        rec[rec_index<D>(P.N, gi, D + 1, c)] = __longlong_as_double((long long)(i1 | (i2 << 32)));
+        rec[rec_index(P.N, P.rec_stride, gi, D + 1, c)] = __longlong_as_double((long long)(i1 | (i2 << 32)));
     } else {
         const double lg = dm_log(u_open(r1));
         if (role == S - 1) {
-            rec[rec_index<D>(P.N, gi, D, c)] = lg;
+            rec[rec_index(P.N, P.rec_stride, gi, D, c)] = lg;
         } else {
             const double R = sqrt(-2.0 * lg);
             double cs, sn;
             dm_sincos2pi(r2 >> 11, cs, sn);
             const int p0 = (D == 1) ? 0 : 2 * (role - 1);
-            rec[rec_index<D>(P.N, gi, p0, c)] = R * cs;
-            if (p0 + 1 < D) rec[rec_index<D>(P.N, gi, p0 + 1, c)] = R * sn;
+            rec[rec_index(P.N, P.rec_stride, gi, p0, c)] = R * cs;
+            if (p0 + 1 < D) rec[rec_index(P.N, P.rec_stride, gi, p0 + 1, c)] = R * sn;
         }
     }
 }
