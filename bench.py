@@ -174,31 +174,25 @@ def main():
     rhat_trace = []
 
     def advance(g_from, g_to, timed):
-        """Generations g_from..g_to with the R-hat check every `every` generations.
-        Returns (event ms spent in window-kernel slabs, launches)."""
+        """Generations g_from..g_to with the R-hat check every `every` generations: one library call
+        (demcz_run_checked = the driver loop demcz.jl:30-55 without its stop), the window kernels timed by
+        HIP events on their own stream inside the library.  Returns (ms spent in window kernels, launches)."""
         nonlocal gens_to_rhat
-        ev_ms, g = 0.0, g_from
-        pairs = []
-        l0 = eng.info()["window_launches"]
-        while g <= g_to:
-            nxt = min(g_to, ((g - 1) // every + 1) * every)
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-            runner.run(g, nxt, w["gamma"])
-            if timed:
-                e1.record(stream)
-                pairs.append((e0, e1))
-            if nxt % every == 0 and nxt >= every:
-                r = runner.rhat(nxt - every + 1, nxt)
-                rhat_trace.append((nxt, float(np.max(r))))
-                if gens_to_rhat is None and np.max(r) < thr:
-                    gens_to_rhat = nxt
-            g = nxt + 1
+        if timed:
+            eng.set_kernel_timing(True)
+        _, trace, _ = runner.run_checked(g_from, g_to, w["gamma"], every, 0.0)
+        first = ((g_from - 1) // every + 1) * every
+        for i, mx in enumerate(trace):
+            gchk = first + i * every
+            rhat_trace.append((gchk, float(mx)))
+            if gens_to_rhat is None and mx < thr:
+                gens_to_rhat = gchk
         runner.synchronize()
-        for e0, e1 in pairs:
-            ev_ms += e0.elapsed_time(e1)
-        return ev_ms, eng.info()["window_launches"] - l0
+        if not timed:
+            return 0.0, 0
+        n, ms = eng.get_kernel_time()
+        eng.set_kernel_timing(False)
+        return ms, n
 
     def fence():
         runner.synchronize()

@@ -35,7 +35,8 @@ SYMBOLS = [
     "demcz_comm_init", "demcz_export_current_device", "demcz_append_rows_device",
     "demcz_set_external_append", "demcz_get_info", "demcz_selftest_draws", "demcz_append_rows",
     "demcz_rhat_partial", "demcz_set_rng_offset", "demcz_rhat_array", "demcz_accept_ratio_array",
-    "demcz_mean_cov_array", "demcz_set_append_lag",
+    "demcz_mean_cov_array", "demcz_set_append_lag", "demcz_run_checked", "demcz_set_kernel_timing",
+    "demcz_get_kernel_time",
 ]
 
 

@@ -70,6 +70,10 @@ struct demcz_handle {
     bool proposal_pending = false;
     bool gen_open = false;
     // split layout: draw records, double-buffered (this launch reads one, its producer half fills the other)
+    double* pinned_rhat = nullptr;    // demcz_run_checked: pinned host slots the checks' results are copied to
+    int64_t pinned_cap = 0;
+    bool timing = false;              // demcz_set_kernel_timing: events around every window-kernel launch
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
     int64_t live_wg_cap = -1;         // consumer workgroups a LIVE launch may have (all must be resident at once); -1: not asked yet
     int split_kind = 0;               // lanes == DEMCZ_LAYOUT_SPLIT: 1 = eight replicated lanes per chain (pc8), 2 = 16 cooperating lanes (ml, REC)
     double* d_rec[2] = {nullptr, nullptr};
@@ -171,6 +175,8 @@ static void free_all(demcz_handle* h)
     }
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     if (h->d_stage) (void)hipHostFree(h->d_stage);
+    for (auto& pr : h->timed) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (h->pinned_rhat) (void)hipHostFree(h->pinned_rhat);
     if (h->comm) (void)ncclCommDestroy(h->comm);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
 }
@@ -998,8 +1004,19 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         // boundaries whose rows generations of this same launch draw from
         const bool live = live_max > 0 && ((w_end - 1) / K - (g - 1) / K) > 0;
         P.live_err = h->d_live_err;
+        hipEvent_t t0 = nullptr, t1 = nullptr;
+        const bool timed = h->timing && h->timed.size() < 4096;
+        if (timed) {
+            HIPCHK(h, hipEventCreate(&t0));
+            HIPCHK(h, hipEventCreate(&t1));
+            HIPCHK(h, hipEventRecord(t0, h->stream));
+        }
         rc = launch_window(h, P, live);
         if (rc) return rc;
+        if (timed) {
+            HIPCHK(h, hipEventRecord(t1, h->stream));
+            h->timed.emplace_back(t0, t1);
+        }
         if (nbound > 0 && !h->external_append) {
             const int64_t rows = h->cfg.N * (sharded ? h->nranks : 1);
             if (E == 0) {
@@ -1143,9 +1160,10 @@ extern "C" int32_t demcz_rhat_partial(demcz_handle* h, int64_t g_from, int64_t g
     return DEMCZ_OK;
 }
 
-extern "C" int32_t demcz_rhat(demcz_handle* h, int64_t g_from, int64_t g_to, double* rhat)
+// Enqueues the R-hat of generations g_from..g_to and the copy of its d values to `out` (host memory; pinned
+// if the caller wants the copy to be asynchronous); does not wait.
+static int32_t rhat_enqueue(demcz_handle* h, int64_t g_from, int64_t g_to, double* out)
 {
-    if (!h || !rhat) return DEMCZ_ERR_INVALID_ARGUMENT;
     RhatPlan r;
     int32_t rc = rhat_prepare(h, g_from, g_to, r, true);
     if (rc) return rc;
@@ -1154,17 +1172,31 @@ extern "C" int32_t demcz_rhat(demcz_handle* h, int64_t g_from, int64_t g_to, dou
     const int64_t m = 2 * r.N * h->nranks;                   // utils.jl:5
     const bool sharded = (h->comm != nullptr);
     double* sums = r.sums;               // [0,d): sum_j mean_j; [d,3d): stage-1 sums; [3d,4d): R-hat
-    // stage 0 -> (all-reduce) -> stage 1 with the grand mean formed on the device -> (all-reduce) ->
+    if (!sharded) {
+        hipLaunchKernelGGL(rhat_tail_kernel, dim3(d), dim3(256), 0, h->stream, r.mean_j, r.s2_j, r.N, d, (double)n, (double)m, sums + 3 * d);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(out, sums + 3 * d, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        return DEMCZ_OK;
+    }
+    // stage 0 -> all-reduce -> stage 1 with the grand mean formed on the device -> all-reduce ->
     // utils.jl:13-18 on the device: one copy and one synchronisation per check
     hipLaunchKernelGGL(rhat_reduce_kernel, dim3(d), dim3(256), 0, h->stream, r.mean_j, r.s2_j, r.N, d, 0, (const double*)nullptr, 1.0, sums);
     HIPCHK(h, hipGetLastError());
-    if (sharded) NCCLCHK(h, ncclAllReduce(sums, sums, (size_t)d, ncclDouble, ncclSum, h->comm, h->stream));
+    NCCLCHK(h, ncclAllReduce(sums, sums, (size_t)d, ncclDouble, ncclSum, h->comm, h->stream));
     hipLaunchKernelGGL(rhat_reduce_kernel, dim3(d), dim3(256), 0, h->stream, r.mean_j, r.s2_j, r.N, d, 1, (const double*)sums, (double)m, sums + d);
     HIPCHK(h, hipGetLastError());
-    if (sharded) NCCLCHK(h, ncclAllReduce(sums + d, sums + d, (size_t)2 * d, ncclDouble, ncclSum, h->comm, h->stream));
+    NCCLCHK(h, ncclAllReduce(sums + d, sums + d, (size_t)2 * d, ncclDouble, ncclSum, h->comm, h->stream));
     hipLaunchKernelGGL(rhat_final_kernel, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, h->stream, (const double*)(sums + d), d, (double)n, (double)m, sums + 3 * d);
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(rhat, sums + 3 * d, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(out, sums + 3 * d, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_rhat(demcz_handle* h, int64_t g_from, int64_t g_to, double* rhat)
+{
+    if (!h || !rhat) return DEMCZ_ERR_INVALID_ARGUMENT;
+    int32_t rc = rhat_enqueue(h, g_from, g_to, rhat);
+    if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return DEMCZ_OK;
 }
@@ -1582,3 +1614,87 @@ extern "C" int32_t demcz_debug_read_stamps(demcz_handle* h, unsigned long long* 
     return DEMCZ_OK;
 }
 #endif
+
+extern "C" int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_to, double gamma, const double* temperature,
+                                     int64_t every, double threshold, int64_t* g_stop, int32_t* n_checks,
+                                     double* rhat_max, int32_t n_max, double* rhat_last)
+{
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (every < 4 || g_from < 1 || g_to < g_from) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_run_checked: need every >= 4 and 1 <= g_from <= g_to");
+    const int d = h->cfg.d;
+    int32_t checks = 0;
+    int64_t g = g_from;
+    if (g_stop) *g_stop = g_to;
+    // threshold <= 0: nothing is decided on the statistic, so the checks are only enqueued between the slabs
+    // (results land in pinned host memory) and read once at the end: the GPU never waits for the host.
+    const bool monitor = !(threshold > 0.0);
+    const int64_t max_checks = (g_to - g_from + 1) / every + 2;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    if (max_checks * d > h->pinned_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->pinned_rhat) (void)hipHostFree(h->pinned_rhat);
+        h->pinned_rhat = nullptr; h->pinned_cap = 0;
+        HIPCHK(h, hipHostMalloc((void**)&h->pinned_rhat, (size_t)max_checks * d * sizeof(double), hipHostMallocDefault));
+        h->pinned_cap = max_checks * d;
+    }
+    double* pinned = h->pinned_rhat;
+    auto max_of = [d](const double* r) {
+        double mx = r[0];
+        for (int p = 1; p < d; ++p) mx = (r[p] > mx || r[p] != r[p]) ? r[p] : mx;      // a NaN stays
+        return mx;
+    };
+    int32_t rc = DEMCZ_OK;
+    while (g <= g_to && rc == DEMCZ_OK) {
+        const int64_t nxt = std::min(g_to, ((g - 1) / every + 1) * every);
+        rc = demcz_run(h, g, nxt, gamma, temperature ? temperature + (g - g_from) : nullptr);
+        if (rc) break;
+        if (nxt % every == 0 && nxt - every >= h->g0) {          // demcz.jl:39-41
+            double* slot = pinned + (size_t)checks * d;
+            rc = rhat_enqueue(h, nxt - every + 1, nxt, slot);
+            if (rc) break;
+            ++checks;
+            if (!monitor) {
+                if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: synchronise failed"); break; }
+                if (max_of(slot) < threshold) {                  // demcz.jl:43
+                    if (g_stop) *g_stop = nxt;
+                    break;
+                }
+            }
+        }
+        g = nxt + 1;
+    }
+    if (rc == DEMCZ_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: synchronise failed");
+    if (rc == DEMCZ_OK) {
+        for (int32_t i = 0; i < checks; ++i)
+            if (rhat_max && i < n_max) rhat_max[i] = max_of(pinned + (size_t)i * d);
+        if (rhat_last && checks > 0) std::copy(pinned + (size_t)(checks - 1) * d, pinned + (size_t)checks * d, rhat_last);
+        if (n_checks) *n_checks = checks;
+    }
+    return rc;
+}
+
+extern "C" int32_t demcz_set_kernel_timing(demcz_handle* h, int32_t enabled)
+{
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    h->timing = enabled != 0;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_get_kernel_time(demcz_handle* h, int64_t* launches, double* milliseconds)
+{
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double total = 0.0;
+    for (auto& pr : h->timed) {
+        float ms = 0.0f;
+        HIPCHK(h, hipEventElapsedTime(&ms, pr.first, pr.second));
+        total += ms;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    if (launches) *launches = (int64_t)h->timed.size();
+    if (milliseconds) *milliseconds = total;
+    h->timed.clear();
+    return DEMCZ_OK;
+}

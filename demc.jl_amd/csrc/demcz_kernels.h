@@ -527,6 +527,52 @@ __global__ void __launch_bounds__(256) rhat_reduce_kernel(const double* mean_j, 
     }
 }
 
+// Unsharded runs: both reduce stages and utils.jl:13-18 for one parameter in one workgroup -- the same
+// per-thread accumulation and tree order as rhat_reduce_kernel (bit-identical), two launches fewer per check.
+__global__ void __launch_bounds__(256) rhat_tail_kernel(const double* mean_j, const double* s2_j, int64_t N, int d,
+                                                        double n, double m, double* rhat)
+{
+    __shared__ double ra[256], rb[256];
+    const int p = blockIdx.x;
+    const int64_t stride = N * d;
+    double a = 0.0, b = 0.0;
+    for (int64_t k = threadIdx.x; k < 2 * N; k += 256) {
+        const int64_t h = k / N, c = k % N;
+        a += mean_j[c + N * p + stride * h];
+    }
+    ra[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) ra[threadIdx.x] += ra[threadIdx.x + s];
+        __syncthreads();
+    }
+    const double gm = ra[0] / m;
+    __syncthreads();
+    a = 0.0;
+    for (int64_t k = threadIdx.x; k < 2 * N; k += 256) {
+        const int64_t h = k / N, c = k % N;
+        const double dv = mean_j[c + N * p + stride * h] - gm;
+        a = fma(dv, dv, a);
+        b += s2_j[c + N * p + stride * h];
+    }
+    ra[threadIdx.x] = a;
+    rb[threadIdx.x] = b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            ra[threadIdx.x] += ra[threadIdx.x + s];
+            rb[threadIdx.x] += rb[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double B = n / (m - 1.0) * ra[0];                   // utils.jl:13
+        const double W = rb[0] / m;                                // utils.jl:15
+        const double varhat = (n - 1.0) / n * W + B / n;           // utils.jl:16
+        rhat[p] = sqrt(varhat / W);                                // utils.jl:18
+    }
+}
+
 // utils.jl:13-18 from the reduced sums: in[p] = sum_j (mean_j - grand)^2, in[d+p] = sum_j s_j^2
 __global__ void rhat_final_kernel(const double* in, int d, double n, double m, double* rhat)
 {

@@ -132,6 +132,32 @@ class HipEngine:
                 raise ValueError("one temperature per generation")
         self._chk(self._L.demcz_run(self._h, int(g_from), int(g_to), float(gamma), _lib.ptr(t)))
 
+    def run_checked(self, g_from, g_to, gamma, every, threshold=0.0, temperature=None):
+        """demcz_run_checked: the generation loop with its R-hat test every ``every`` generations as one
+        library call (demcz.jl:30-55).  Returns (g_stop, max R-hat of every check made, R-hat vector of the last)."""
+        t = None
+        if temperature is not None:
+            t = _lib.f64(temperature)
+            if t.shape != (g_to - g_from + 1,):
+                raise ValueError("one temperature per generation")
+        n_max = int((g_to - g_from + 1) // every + 2)
+        mx = np.zeros(n_max)
+        last = np.full(self.d, np.nan)
+        g_stop, n = C.c_int64(0), C.c_int32(0)
+        self._chk(self._L.demcz_run_checked(self._h, C.c_int64(int(g_from)), C.c_int64(int(g_to)), C.c_double(float(gamma)),
+                                            _lib.ptr(t), C.c_int64(int(every)), C.c_double(float(threshold)), C.byref(g_stop),
+                                            C.byref(n), _lib.ptr(mx), C.c_int32(n_max), _lib.ptr(last)))
+        return int(g_stop.value), mx[:n.value].copy(), last
+
+    def set_kernel_timing(self, enabled: bool):
+        self._chk(self._L.demcz_set_kernel_timing(self._h, C.c_int32(1 if enabled else 0)))
+
+    def get_kernel_time(self):
+        """(launches, milliseconds) of the window kernels timed since the last call (HIP events on the kernel's stream)."""
+        n, ms = C.c_int64(0), C.c_double(0.0)
+        self._chk(self._L.demcz_get_kernel_time(self._h, C.byref(n), C.byref(ms)))
+        return int(n.value), float(ms.value)
+
     def synchronize(self):
         self._chk(self._L.demcz_synchronize(self._h))
 

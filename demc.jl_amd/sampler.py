@@ -151,6 +151,28 @@ class _Runner:
                 e.set_append_lag(self.lag)      # the library applies the same visibility rule
 
     # generation loop --------------------------------------------------------------------------
+    @property
+    def library_loop(self):
+        """True when the generation loop + its R-hat test can run as one library call (demcz_run_checked):
+        one engine in this process and no host-driven exchange (single GPU, or RCCL inside the library)."""
+        return len(self.engines) == 1 and not self.host_exchange and hasattr(self.engines[0], "run_checked")
+
+    def run_checked(self, g_from, g_to, gamma, every, threshold=0.0, temperature=None):
+        """demcz.jl:30-55 for a slab: returns (g_stop, [max R-hat per check], R-hat vector of the last check)."""
+        if self.library_loop:
+            return self.engines[0].run_checked(g_from, g_to, gamma, every, threshold, temperature)
+        g, trace, last = g_from, [], None
+        while g <= g_to:
+            nxt = min(g_to, ((g - 1) // every + 1) * every)
+            self.run(g, nxt, gamma, None if temperature is None else temperature[g - g_from:nxt - g_from + 1])
+            if nxt % every == 0 and nxt >= every:
+                last = self.rhat(nxt - every + 1, nxt)
+                trace.append(float(np.max(last)))
+                if threshold > 0 and trace[-1] < threshold:
+                    return nxt, np.array(trace), last
+            g = nxt + 1
+        return g_to, np.array(trace), last
+
     def run(self, g_from, g_to, gamma, temperature=None):
         if not self.host_exchange:
             for e in self.engines:
@@ -385,6 +407,16 @@ def demcz_sample(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
         if verbose:
             print("-----------------------\niteration 0\n-----------------------")
         ig = 0
+        if autostop == "Rhat" and not verbose and is_device_target(logobj) and prevrun is None:
+            # the loop and its autostop test as one library call (demcz_run_checked): same decisions, no
+            # host round trip per slab besides the R-hat read-back
+            ig, _, _ = runner.run_checked(1, Ngeneration, γ, autostop_every, autostop_Rhat)
+            if ig < Ngeneration or (ig % autostop_every == 0 and ig >= autostop_every and
+                                    np.max(runner.rhat(ig - autostop_every + 1, ig)) < autostop_Rhat):
+                if runner.accept_ratio_mean(ig - autostop_every + 1, ig) < 0.1:       # demcz.jl:42,44-46
+                    print("Warning: accept ratio below 10% on average")
+                res = _finish(runner, prevrun, ig, padded_Z, Mcap)                  # demcz.jl:47-52
+                return (res + (runner,)) if return_runner else res
         while ig < Ngeneration:                                                     # demcz.jl:30
             stops = [Ngeneration]
             if verbose:

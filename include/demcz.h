@@ -219,6 +219,24 @@ int32_t demcz_mean_cov_array(int32_t device_id, const double* chain, int64_t N, 
 /* Introspection for benchmarks and tests. */
 int32_t demcz_get_info(const demcz_handle* h, int64_t* M, int64_t* launches_window, int32_t* lanes_per_chain);
 
+/* The driver loop with its autostop test as ONE call (demcz.jl:30-55): generations g_from..g_to, and after
+ * every generation g that is a multiple of `every` the split-R-hat of generations (g-every, g]
+ * (Rhat_gelman, utils.jl:2-20; demcz.jl:41).  The maximum over parameters of the i-th check goes to
+ * rhat_max[i] (i < n_max; may be NULL), the whole vector of the last check to rhat_last[d] (may be NULL).
+ * threshold > 0: returns as soon as a check's maximum is below it, with *g_stop = that generation
+ * (demcz.jl:43-52; nothing after it has run); otherwise *g_stop = g_to.  *n_checks = checks made.
+ * Needs a history window (Gcap) that holds the generations of the call.  In a sharded run every rank
+ * makes the same call; the decision is the same on all of them.                                      */
+int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_to, double gamma, const double* temperature,
+                          int64_t every, double threshold, int64_t* g_stop, int32_t* n_checks,
+                          double* rhat_max, int32_t n_max, double* rhat_last);
+
+/* Timing of the window kernels on the stream they are launched on (HIP events around every launch while
+ * enabled; at most 4096 launches are kept).  demcz_get_kernel_time synchronises, returns the number of
+ * timed launches and the sum of their durations, and clears the record.                                */
+int32_t demcz_set_kernel_timing(demcz_handle* h, int32_t enabled);
+int32_t demcz_get_kernel_time(demcz_handle* h, int64_t* launches, double* milliseconds);
+
 /* Device self-test of the draw pipeline: for Philox block blk0+i of the
  * stream of global chain `chain`, words[2i..2i+1] = the two raw 64-bit words,
  * normals[2i..2i+1] = the Box-Muller pair, logu[i] = log(u_open(word 0)).  Lets an integrator

@@ -464,3 +464,44 @@ def _big_step(big):
     g = _BIG_G[0]
     big.run(g, g + 29, 2.38)
     _BIG_G[0] = g + 30
+
+
+def test_run_checked_is_the_driver_loop(demc, oracle):
+    """demcz_run_checked (demcz.jl:30-55 as one call) == the host loop over demcz_run + demcz_rhat: same
+    stop generation, same R-hat values, same chains; the window kernels' event timing counts the launches."""
+    d, N, G, every = 5, 256, 600, 100
+    w = demc.workloads.mvnormal_problem(d, N)
+    M0 = w["Zinit"].shape[0]
+
+    def engine():
+        e = demc.HipEngine(N=N, d=d, K=10, Mcap=M0 + N * (G // 10), Gcap=G, blockindex=[range(d)], eps_scale=w["eps_scale"],
+                           seed=4, target=w["target"])
+        e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+        return e
+
+    a = engine()
+    trace_a, g = [], 1
+    while g <= G:
+        a.run(g, g + every - 1, 2.38)
+        trace_a.append(a.rhat(g, g + every - 1))
+        g += every
+    b = engine()
+    b.set_kernel_timing(True)
+    g_stop, mx, last = b.run_checked(1, G, 2.38, every, 0.0)
+    n, ms = b.get_kernel_time()
+    assert g_stop == G and n >= 1 and ms > 0.0
+    assert np.array_equal(mx, [r.max() for r in trace_a]) and np.array_equal(last, trace_a[-1])
+    assert np.array_equal(a.get_history(1, G)[0], b.get_history(1, G)[0])
+    # with a threshold: stops at the first check below it, nothing after it has run
+    thr = float(np.sort(mx)[len(mx) // 2]) * (1 + 1e-12)
+    c = engine()
+    g_stop, mx_c, _ = c.run_checked(1, G, 2.38, every, thr)
+    k = int(np.argmax(mx < thr))
+    assert g_stop == (k + 1) * every and len(mx_c) == k + 1 and c.M == M0 + N * (g_stop // 10)
+    for e in (a, b, c):
+        e.close()
+    # the sampler's autostop path goes through it and returns what the reference's loop would
+    opts = demc.demcopt(d, N=N, K=10, Ngeneration=G, eps_scale=w["eps_scale"], verbose=False, autostop="Rhat",
+                        autostop_every=every, autostop_Rhat=thr)
+    mc, Z = demc.demcz_sample(w["target"], w["Zinit"], opts, seed=4)
+    assert mc.chain.shape[2] == (k + 1) * every and Z.shape[0] == M0 + N * ((k + 1) * every // 10)
