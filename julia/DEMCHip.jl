@@ -77,6 +77,14 @@ run!(h, g_from, g_to, γ, temperature=nothing) =
     chk(ccall((:demcz_run, libdemcz), Int32, (Ptr{Cvoid}, Int64, Int64, Float64, Ptr{Float64}),
               h, g_from, g_to, γ, temperature === nothing ? C_NULL : temperature), h)
 set_rng_offset(h, g) = chk(ccall((:demcz_set_rng_offset, libdemcz), Int32, (Ptr{Cvoid}, Int64), h, g), h)
+# the loop demcz.jl:30-55 (generations + the R-hat test every `every`) as ONE call; returns the generation it stopped at
+function run_checked!(h, g_from, g_to, γ, every, threshold)
+    g_stop = Ref{Int64}(0); n = Ref{Int32}(0)
+    chk(ccall((:demcz_run_checked, libdemcz), Int32,
+              (Ptr{Cvoid}, Int64, Int64, Float64, Ptr{Float64}, Int64, Float64, Ref{Int64}, Ref{Int32}, Ptr{Float64}, Int32, Ptr{Float64}),
+              h, g_from, g_to, γ, C_NULL, every, threshold, g_stop, n, C_NULL, 0, C_NULL), h)
+    g_stop[]
+end
 function rhat(h, g_from, g_to, d)
     r = zeros(d)
     chk(ccall((:demcz_rhat, libdemcz), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}), h, g_from, g_to, r), h); r
@@ -121,15 +129,13 @@ function demcz_sample(t::DeviceTarget, Zmat, N=4, K=10, Ngeneration=5000, Nblock
         set_state(h, Matrix{Float64}(X), lp, Matrix{Float64}(Zmat))
         prevrun === nothing || set_rng_offset(h, size(prevrun.chain, 3))
         ig = 0
-        while ig < Ngeneration                                                         # demcz.jl:30
-            nxt = autostop == :Rhat ? min(Ngeneration, (ig ÷ autostop_every + 1) * autostop_every) : Ngeneration
-            run!(h, ig + 1, nxt, γ); ig = nxt
-            if autostop == :Rhat && ig % autostop_every == 0                           # demcz.jl:39-53
-                if maximum(rhat(h, ig - autostop_every + 1, ig, d)) < autostop_Rhat
-                    sum(accept_ratio(h, ig - autostop_every + 1, ig, N)) / N < 0.1 && println("Warning: accept ratio below 10% on average")
-                    break
-                end
+        if autostop == :Rhat                                                           # demcz.jl:30-53 in one call
+            ig = run_checked!(h, 1, Ngeneration, γ, autostop_every, autostop_Rhat)
+            if ig % autostop_every == 0 && maximum(rhat(h, ig - autostop_every + 1, ig, d)) < autostop_Rhat
+                sum(accept_ratio(h, ig - autostop_every + 1, ig, N)) / N < 0.1 && println("Warning: accept ratio below 10% on average")
             end
+        else
+            run!(h, 1, Ngeneration, γ); ig = Ngeneration
         end
         chain, log_obj = history(h, N, d, 1, ig)
         Xc, lpc, Z = state(h, N, d)
