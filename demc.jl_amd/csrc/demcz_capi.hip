@@ -74,6 +74,7 @@ struct demcz_handle {
     int64_t pinned_cap = 0;
     bool timing = false;              // demcz_set_kernel_timing: events around every window-kernel launch
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
+    int64_t timed_launches = 0;
     int64_t live_wg_cap = -1;         // consumer workgroups a LIVE launch may have (all must be resident at once); -1: not asked yet
     int split_kind = 0;               // lanes == DEMCZ_LAYOUT_SPLIT: 1 = eight replicated lanes per chain (pc8), 2 = 16 cooperating lanes (ml, REC)
     double* d_rec[2] = {nullptr, nullptr};
@@ -949,6 +950,16 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
 #endif
     const int E = h->lag;
     int64_t g = g_from;
+    // demcz_set_kernel_timing: ONE event pair around the back-to-back window launches of this call (an event
+    // between two launches would put a bubble into the stream it is meant to measure)
+    hipEvent_t tev0 = nullptr, tev1 = nullptr;
+    int64_t timed_launches = 0;
+    const bool timed = h->timing && h->timed.size() < 4096;
+    if (timed) {
+        HIPCHK(h, hipEventCreate(&tev0));
+        HIPCHK(h, hipEventCreate(&tev1));
+        HIPCHK(h, hipEventRecord(tev0, h->stream));
+    }
     while (g <= g_to) {
         const int64_t next_boundary = ((g - 1) / K + 1) * K;      // first multiple of K that is >= g
         // Synchronous schedule: a launch ends at the next K boundary, the kernel boundary is the
@@ -1004,19 +1015,9 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         // boundaries whose rows generations of this same launch draw from
         const bool live = live_max > 0 && ((w_end - 1) / K - (g - 1) / K) > 0;
         P.live_err = h->d_live_err;
-        hipEvent_t t0 = nullptr, t1 = nullptr;
-        const bool timed = h->timing && h->timed.size() < 4096;
-        if (timed) {
-            HIPCHK(h, hipEventCreate(&t0));
-            HIPCHK(h, hipEventCreate(&t1));
-            HIPCHK(h, hipEventRecord(t0, h->stream));
-        }
         rc = launch_window(h, P, live);
         if (rc) return rc;
-        if (timed) {
-            HIPCHK(h, hipEventRecord(t1, h->stream));
-            h->timed.emplace_back(t0, t1);
-        }
+        ++timed_launches;
         if (nbound > 0 && !h->external_append) {
             const int64_t rows = h->cfg.N * (sharded ? h->nranks : 1);
             if (E == 0) {
@@ -1042,6 +1043,11 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
             }
         }
         g = w_end + 1;
+    }
+    if (timed) {
+        HIPCHK(h, hipEventRecord(tev1, h->stream));
+        h->timed.emplace_back(tev0, tev1);
+        h->timed_launches += timed_launches;
     }
     if (sharded && E > 0) {                 // nothing stays un-exchanged across calls
         int32_t rc = exchange_batch(h);
@@ -1693,8 +1699,9 @@ extern "C" int32_t demcz_get_kernel_time(demcz_handle* h, int64_t* launches, dou
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
     }
-    if (launches) *launches = (int64_t)h->timed.size();
+    if (launches) *launches = h->timed_launches;
     if (milliseconds) *milliseconds = total;
     h->timed.clear();
+    h->timed_launches = 0;
     return DEMCZ_OK;
 }

@@ -231,9 +231,10 @@ int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_to, double 
                           int64_t every, double threshold, int64_t* g_stop, int32_t* n_checks,
                           double* rhat_max, int32_t n_max, double* rhat_last);
 
-/* Timing of the window kernels on the stream they are launched on (HIP events around every launch while
- * enabled; at most 4096 launches are kept).  demcz_get_kernel_time synchronises, returns the number of
- * timed launches and the sum of their durations, and clears the record.                                */
+/* Timing of the window kernels on the stream they are launched on: while enabled, every demcz_run call
+ * brackets its back-to-back window launches with one HIP event pair (an event between two launches would
+ * stall the stream being measured).  demcz_get_kernel_time synchronises, returns the number of window
+ * launches covered and the summed duration of the brackets, and clears the record.                     */
 int32_t demcz_set_kernel_timing(demcz_handle* h, int32_t enabled);
 int32_t demcz_get_kernel_time(demcz_handle* h, int64_t* launches, double* milliseconds);
 

@@ -29,8 +29,11 @@ e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K + 1), Gcap=G, blockindex
 if lag:
     e.set_append_lag(lag)
 e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+import time
+t0 = time.perf_counter()
 e.run(1, G, 2.38)
 e.synchronize()
+wall_us = (time.perf_counter() - t0) * 1e6
 lib = _lib.load()
 ncons = (N + 7) // 8
 nprod = ((N + 63) // 64) * 3 * (K * max(lag, 1))
@@ -54,4 +57,5 @@ p = s[ncons:nwg]
 ok = p[:, 7] > 0
 print(f"  producer: {ok.sum()} workgroups wrote; body {np.mean((p[ok,7]-p[ok,0])):.0f} mean {np.max(p[ok,7]-p[ok,0])} max; last exit at {np.max(p[ok,7])-t00} after the first entry")
 print(f"  last consumer exit at {np.max(c[:,7]) - t00} after the first entry")
+print(f"  wall time of the whole call ({G} generations, all launches): {wall_us:.0f} us; ticks of the last launch's consumers: {np.mean(c[:,7]-c[:,0]):.0f}")
 e.close()
