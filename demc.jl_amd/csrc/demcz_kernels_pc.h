@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
     static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "split layout: MvNormal / isotropic targets");
     constexpr int L = 8, G = 64 / L, DP = ((D + 1) / 2) * 2;
     constexpr int NP = (D + L - 1) / L;                    // parameters a lane prefetches: r, r+8, ...
-    constexpr int CH = (NP == 1) ? PC8_CHUNK : PC8_CHUNK / 2;
+    constexpr int CH = (D <= 5) ? PC8_CHUNK : PC8_CHUNK / 2;      // the chunk's increments (CH x D doubles) live in registers
     DEMCZ_STAMP(P, 0);
     if ((int64_t)blockIdx.x >= P.consumer_blocks) {
         pc_produce<D>(P, (int64_t)blockIdx.x - P.consumer_blocks);
@@ -110,10 +110,7 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
         }
     }
     double* lobj = P.logobj + c + P.N * P.slot_first;      // D >= 8 only: lane 7 stores log_obj separately
-    // record pointers of this lane's fields; a generation is a uniform stride further on
-    const double* rec_z[NP];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) rec_z[k] = P.rec_in + ((int64_t)((D == 1) ? 0 : pk[k]) * P.N + c) * P.rec_stride;
+    // record rows of this chain; a generation is the next double
     const double* rec_lg = P.rec_in + ((int64_t)D * P.N + c) * P.rec_stride;
     const double* rec_ix = P.rec_in + ((int64_t)(D + 1) * P.N + c) * P.rec_stride;
     // a chunk's CH consecutive generations of one field: CHP/2 16-byte loads off one address (8-byte aligned:
@@ -134,13 +131,31 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
     constexpr int ZSC = (D <= 2) ? 2 : (D <= 4) ? 4 : ((D + 7) / 8) * 8;
     static_assert((ZSC & (ZSC - 1)) == 0, "row stride must be a power of two");
     constexpr int ZSHIFT = (ZSC == 2) ? 4 : (ZSC == 4) ? 5 : (ZSC == 8) ? 6 : 7;
-    const char* Zb = reinterpret_cast<const char*>(P.Z);
-    uint32_t pk8[NP];
+    // Front-end roles: lane r of a chain's group fetches what generation u = r (and, second round, 8 + r) of
+    // the chunk needs -- the two archive rows whole (16-byte loads), the D normals -- and forms that
+    // generation's D increments.  (Fewer, wider vector-memory instructions than one lane per parameter: a
+    // chunk is 12 + 10 + 7 of them at d = 5 instead of 60; their issue was a third of the chunk's front-end.)
+    constexpr int ROUNDS = (CH + L - 1) / L;
+    constexpr int HW = (D + 1) / 2;                       // 16-byte pieces of a row
+    static_assert(2 * HW <= ZSC, "a row's last 16-byte piece stays inside the row");
+    const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.Z), 0, 0xffffffffu, 0x00020000);
+    constexpr int ZAUX = LIVE ? 16 : 0;                   // sc1: served past the CU's L1 (demcz_kernels_rec.h)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    auto row_piece = [&](uint32_t byte_off, double& lo, double& hi) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, (int)byte_off, 0, ZAUX);
+        lo = __longlong_as_double((long long)(((uint64_t)v.y << 32) | v.x));
+        hi = __longlong_as_double((long long)(((uint64_t)v.w << 32) | v.z));
+    };
+    const double* rec_n[D];                                // normals of this chain, parameter p
 #pragma unroll
-    for (int k = 0; k < NP; ++k) pk8[k] = (uint32_t)pk[k] * 8u;
-    // row indices of the first chunk; from then on they are fetched one chunk ahead
-    double ixn[CHP];           // (bit patterns of the packed 32-bit index pairs)
-    fetch_chunk(rec_ix, ixn);
+    for (int p = 0; p < D; ++p) rec_n[p] = P.rec_in + ((int64_t)((D == 1) ? 0 : p) * P.N + c) * P.rec_stride;
+    double epsall[D];
+#pragma unroll
+    for (int p = 0; p < D; ++p) epsall[p] = P.eps[p];
+    // row indices of this lane's generations of the first chunk; from then on fetched one chunk ahead
+    double ixn[ROUNDS];        // (bit patterns of the packed 32-bit index pairs)
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) ixn[rd] = rec_ix[rd * L + r];
 
     // A chunk is up to CH generations whose draws are fetched together.  It ends at the next K boundary:
     // the append then sits between chunks, not inside the generation code, and in a LIVE launch the
@@ -159,123 +174,109 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
 #endif
         len = (P.ngen - g0 < CH) ? P.ngen - g0 : CH;
         len = (to_b < len) ? to_b : len;
-        double lgu[CHP], dmine[CH][NP];
+        double lgu[CHP];
         [[maybe_unused]] double tmpr[CH];
         {
-            // records first: their latency runs beside the index draws and the archive gather
-            double za[CH][NP], zb[CH][NP], zt[NP][CHP];
-#pragma unroll
-            for (int k = 0; k < NP; ++k) fetch_chunk(rec_z[k] + g0, zt[k]);
             fetch_chunk(rec_lg + g0, lgu);
             if constexpr (TEMPER) {
 #pragma unroll
                 for (int u = 0; u < CH; ++u) tmpr[u] = P.temperature[g0 + ((u < len) ? u : len - 1)];
             }
-            // the two archive rows of every generation of the chunk (indices fetched during the previous chunk)
-            uint32_t o1[CH], o2[CH];
+            double za[ROUNDS][2 * HW], zb[ROUNDS][2 * HW], zt[ROUNDS][D];
+            uint32_t o1[ROUNDS], o2[ROUNDS];
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
+            for (int rd = 0; rd < ROUNDS; ++rd) {
+                const int u = rd * L + r;
                 // slots past the end of the chunk read row 0: their own rows may not exist yet (LIVE: never wait for them)
-                const uint64_t ii = (uint64_t)__double_as_longlong(ixn[u]);
-                o1[u] = (u < len) ? (uint32_t)ii << ZSHIFT : 0u;
-                o2[u] = (u < len) ? (uint32_t)(ii >> 32) << ZSHIFT : 0u;
-            }
+                const uint64_t ii = (uint64_t)__double_as_longlong(ixn[rd]);
+                o1[rd] = (u < len) ? (uint32_t)ii << ZSHIFT : 0u;
+                o2[rd] = (u < len) ? (uint32_t)(ii >> 32) << ZSHIFT : 0u;
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
-#pragma unroll
-                for (int k = 0; k < NP; ++k) {
-                    const double* pa = reinterpret_cast<const double*>(Zb + (o1[u] + pk8[k]));
-                    const double* pb = reinterpret_cast<const double*>(Zb + (o2[u] + pk8[k]));
-                    if constexpr (LIVE) { za[u][k] = live_load(pa); zb[u][k] = live_load(pb); }
-                    else { za[u][k] = *pa; zb[u][k] = *pb; }
+                for (int j = 0; j < HW; ++j) {
+                    row_piece(o1[rd] + 16u * j, za[rd][2 * j], za[rd][2 * j + 1]);
+                    row_piece(o2[rd] + 16u * j, zb[rd][2 * j], zb[rd][2 * j + 1]);
                 }
+                const int gu = g0 + ((u < len) ? u : len - 1);
+#pragma unroll
+                for (int p = 0; p < ((D == 1) ? 1 : D); ++p) zt[rd][p] = rec_n[p][gu];
             }
-            // next chunk's indices (it starts at g0 + len)
-            fetch_chunk(rec_ix + g0 + len, ixn);
+            // next chunk's indices (it starts at g0 + len; the buffers are padded for the overshoot)
+#pragma unroll
+            for (int rd = 0; rd < ROUNDS; ++rd) ixn[rd] = rec_ix[g0 + len + rd * L + r];
             // nothing that waits for a record may be scheduled in front of the gather's issue
             __builtin_amdgcn_sched_barrier(0);
             if (g0 == stamp_g0) DEMCZ_STAMP(P, 2);
             if constexpr (LIVE) {
                 // rows another wave has not published yet read as the sentinel: ask again.  Cheap filter first:
                 // the sentinel's high word is that of a negative NaN, above every finite value's, -inf's and
-                // the canonical NaN's -- one max3 per row pair instead of two 64-bit compares
+                // the canonical NaN's -- a max per value instead of a 64-bit compare
                 uint32_t hmax = 0u;
 #pragma unroll
-                for (int u = 0; u < CH; ++u)
+                for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
-                    for (int k = 0; k < NP; ++k) {
-                        const uint32_t ha = (uint32_t)((uint64_t)__double_as_longlong(za[u][k]) >> 32);
-                        const uint32_t hb = (uint32_t)((uint64_t)__double_as_longlong(zb[u][k]) >> 32);
+                    for (int p = 0; p < D; ++p) {
+                        const uint32_t ha = (uint32_t)((uint64_t)__double_as_longlong(za[rd][p]) >> 32);
+                        const uint32_t hb = (uint32_t)((uint64_t)__double_as_longlong(zb[rd][p]) >> 32);
                         hmax = max(hmax, max(ha, hb));
                     }
                 bool bad = false;
                 if (__builtin_amdgcn_ballot_w64(hmax >= (uint32_t)(LIVE_SENTINEL >> 32)) != 0ull) {
 #pragma unroll
-                    for (int u = 0; u < CH; ++u)
+                    for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
-                        for (int k = 0; k < NP; ++k) bad |= is_sentinel(za[u][k]) | is_sentinel(zb[u][k]);
+                        for (int p = 0; p < D; ++p) bad |= is_sentinel(za[rd][p]) | is_sentinel(zb[rd][p]);
                 }
                 int spins = 0;
                 while (__builtin_amdgcn_ballot_w64(bad) != 0ull) {           // wave-uniform
-                    // give up after LIVE_SPIN_LIMIT polls, or as soon as any wave of the launch has given up
-                    // (live_err[0]; checked every 256 polls): the launch then drains within microseconds
-                    const bool timeout = (++spins > LIVE_SPIN_LIMIT);
-                    bool abandon = timeout;
-                    if (!timeout && (spins & 255) == 0)
-                        abandon = __hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-                    if (abandon) {
-                        if (timeout && bad) {
-                            // first lane to report leaves what it was waiting for: [1] generation of the launch,
-                            // [2] archive row, [3] workgroup
-                            if (atomicCAS(P.live_err, 0u, 1u) == 0u) {
-                                unsigned row = 0;
+                    unsigned waiting_row = 0;
 #pragma unroll
-                                for (int u = 0; u < CH; ++u)
+                    for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
-                                    for (int k = 0; k < NP; ++k) {
-                                        if (is_sentinel(za[u][k])) row = o1[u] >> ZSHIFT;
-                                        if (is_sentinel(zb[u][k])) row = o2[u] >> ZSHIFT;
-                                    }
-                                P.live_err[1] = (unsigned)g0; P.live_err[2] = row; P.live_err[3] = blockIdx.x;
-                            }
+                        for (int p = 0; p < D; ++p) {
+                            if (is_sentinel(za[rd][p])) waiting_row = o1[rd] >> ZSHIFT;
+                            if (is_sentinel(zb[rd][p])) waiting_row = o2[rd] >> ZSHIFT;
                         }
-#ifdef DEMCZ_STAMPS
-                        if (P.stamps) {      // what every stuck lane was waiting for (last writer wins per workgroup)
-#pragma unroll
-                            for (int u = 0; u < CH; ++u)
-#pragma unroll
-                                for (int k = 0; k < NP; ++k) {
-                                    if (is_sentinel(za[u][k])) { P.stamps[(size_t)blockIdx.x * 8 + 4] = 2000000000ull + (o1[u] >> ZSHIFT); P.stamps[(size_t)blockIdx.x * 8 + 3] = 3000000000ull + (unsigned)(u * 100 + pk[k]); }
-                                    if (is_sentinel(zb[u][k])) { P.stamps[(size_t)blockIdx.x * 8 + 4] = 2000000000ull + (o2[u] >> ZSHIFT); P.stamps[(size_t)blockIdx.x * 8 + 3] = 3000000000ull + (unsigned)(u * 100 + pk[k]); }
-                                }
-                            if (lane == 0) P.stamps[(size_t)blockIdx.x * 8 + 2] = 4000000000ull + (unsigned)spins;
-                        }
-#endif
-                        gave_up = true;
-                        break;
-                    }
+                    if (live_poll_abandon(P, spins, bad, waiting_row, g0)) { gave_up = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                     bad = false;
 #pragma unroll
-                    for (int u = 0; u < CH; ++u) {
+                    for (int rd = 0; rd < ROUNDS; ++rd) {
+                        // a row is written by one wave, 8 bytes at a time: re-read whole rows that still hold a sentinel
+                        bool ba = false, bb = false;
 #pragma unroll
-                        for (int k = 0; k < NP; ++k) {
-                            if (is_sentinel(za[u][k])) za[u][k] = live_load(reinterpret_cast<const double*>(Zb + (o1[u] + pk8[k])));
-                            if (is_sentinel(zb[u][k])) zb[u][k] = live_load(reinterpret_cast<const double*>(Zb + (o2[u] + pk8[k])));
-                            bad |= is_sentinel(za[u][k]) | is_sentinel(zb[u][k]);
+                        for (int p = 0; p < D; ++p) { ba |= is_sentinel(za[rd][p]); bb |= is_sentinel(zb[rd][p]); }
+                        if (ba) {
+#pragma unroll
+                            for (int j = 0; j < HW; ++j) row_piece(o1[rd] + 16u * j, za[rd][2 * j], za[rd][2 * j + 1]);
                         }
+                        if (bb) {
+#pragma unroll
+                            for (int j = 0; j < HW; ++j) row_piece(o2[rd] + 16u * j, zb[rd][2 * j], zb[rd][2 * j + 1]);
+                        }
+#pragma unroll
+                        for (int p = 0; p < D; ++p) bad |= is_sentinel(za[rd][p]) | is_sentinel(zb[rd][p]);
                     }
                 }
             }
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
+            for (int rd = 0; rd < ROUNDS; ++rd) {
+                const int u = rd * L + r;
+                double dv[DP];
 #pragma unroll
-                for (int k = 0; k < NP; ++k) {
-                    const double diff = za[u][k] - zb[u][k];
-                    const double t1 = scale * diff;
-                    const double t2 = epsv[k] * zt[k][u];
-                    dmine[u][k] = t1 + t2;
-                    if (r + L * k < D) sdelta[(gq * CH + u) * DP + r + L * k] = dmine[u][k];
+                for (int p = 0; p < DP; ++p) {
+                    if (p < D) {
+                        const double diff = za[rd][p] - zb[rd][p];
+                        const double t1 = scale * diff;
+                        const double t2 = epsall[p] * zt[rd][(D == 1) ? 0 : p];
+                        dv[p] = t1 + t2;
+                    } else {
+                        dv[p] = 0.0;
+                    }
+                }
+                if (u < CH) {
+#pragma unroll
+                    for (int j = 0; j < DP / 2; ++j)
+                        reinterpret_cast<double2*>(sdelta + (gq * CH + u) * DP)[j] = make_double2(dv[2 * j], dv[2 * j + 1]);
                 }
             }
         }
@@ -284,7 +285,7 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
         wave_lds_handoff();
         // the whole chunk's increments into registers first: the LDS latency is paid once, not inside
         // every generation's dependent chain
-        double dl[CH][DP];
+        double dl[CH][DP], dmine[CH][NP];
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
 #pragma unroll
@@ -293,6 +294,8 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
                 dl[u][2 * j] = t.x;
                 dl[u][2 * j + 1] = t.y;
             }
+#pragma unroll
+            for (int k = 0; k < NP; ++k) dmine[u][k] = sdelta[(gq * CH + u) * DP + pk[k]];      // this lane's own element(s)
         }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
