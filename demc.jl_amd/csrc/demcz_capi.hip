@@ -76,7 +76,10 @@ struct demcz_handle {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
     int64_t timed_launches = 0;
     int64_t live_wg_cap = -1;         // consumer workgroups a LIVE launch may have (all must be resident at once); -1: not asked yet
-    int split_kind = 0;               // lanes == DEMCZ_LAYOUT_SPLIT: 1 = eight replicated lanes per chain (pc8), 2 = 16 cooperating lanes (ml, REC)
+    int split_kind = 0;               // lanes == DEMCZ_LAYOUT_SPLIT: 1 = eight replicated lanes per chain (pc8), 2 = 16 cooperating
+                                      // lanes (ml, REC), 3 = cooperating lanes with block updates (mlb, REC)
+    int split_lanes = 0;              // kinds 2, 3: lanes per chain of the consumer
+    int32_t* d_slot_role = nullptr;   // kind 3: role of every Philox block of a generation
     double* d_rec[2] = {nullptr, nullptr};
     unsigned int* d_live_err = nullptr;   // device word a LIVE launch sets when an expected row never appears
 #ifdef DEMCZ_STAMPS
@@ -161,7 +164,7 @@ static hipError_t dev_alloc_copy(T** dst, const T* src, size_t n, hipStream_t s)
 static void free_all(demcz_handle* h)
 {
     void* bufs[] = {h->dZ, h->dX, h->dlp, h->dchain, h->dlogobj, h->dlp_origin, h->dtemp, h->d_block_offsets,
-                    h->d_slot_of, h->d_eps, h->d_mu, h->d_Wp, h->d_design, h->d_y, h->d_scratch, h->dXprop,
+                    h->d_slot_of, h->d_slot_role, h->d_eps, h->d_mu, h->d_Wp, h->d_design, h->d_y, h->d_scratch, h->dXprop,
                     h->dlogu, h->d_gather};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -270,7 +273,10 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         const int L = ml_lanes_available(cfg->target_kind, d, h->full_block, cfg->nobs, maxb, cfg->Nblocks);
         // 32-bit row indices in the records, 32-bit byte offsets into the archive
         const bool idx32 = cfg->Mcap <= 0xffffffffll && (double)cfg->Mcap * 8.0 * (((d + 7) / 8) * 8) < 4294967296.0;
-        const int kind = !idx32 ? 0 : pc_available(cfg->target_kind, d, h->full_block) ? 1 : split_ml_available(cfg->target_kind, d, h->full_block) ? 2 : 0;
+        const int kind = !idx32 ? 0 : pc_available(cfg->target_kind, d, h->full_block) ? 1
+                         : split_ml_available(cfg->target_kind, d, h->full_block) ? 2
+                         : (!h->full_block && cfg->target_kind == DEMCZ_TARGET_MVNORMAL && L > 1) ? 3 : 0;
+        h->split_lanes = (kind == 2) ? 16 : (kind == 3) ? L : 0;
         const bool split_ok = kind != 0;
         h->split_kind = 0;
         if (cfg->lanes_per_chain == DEMCZ_LAYOUT_SPLIT) {
@@ -280,7 +286,7 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
             }
             h->lanes = DEMCZ_LAYOUT_SPLIT;
             h->split_kind = kind;
-        } else if (cfg->lanes_per_chain == 0 && split_ok && cfg->N <= (kind == 2 ? 4096 : 8192)) {
+        } else if (cfg->lanes_per_chain == 0 && split_ok && cfg->N <= (kind == 1 ? 8192 : 4096)) {
             // (16 cooperating lanes, d = 20, us per K-window split / fused: N=1024 9.7 / 16.8, N=4096 16.6 / 21.0,
             //  N=8192 35.5 / 29.8)
             h->split_kind = kind;
@@ -321,6 +327,14 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
     CRCHK(dev_alloc_copy(&h->d_block_offsets, h->block_offsets.data(), h->block_offsets.size(), h->stream));
     CRCHK(dev_alloc_copy(&h->d_slot_of, h->slot_of.data(), h->slot_of.size(), h->stream));
     CRCHK(dev_alloc_copy(&h->d_eps, h->eps.data(), h->eps.size(), h->stream));
+    {   // what every Philox block of a generation is: rows, a normal pair, or the accept uniform (per block, in order)
+        std::vector<int32_t> role;
+        for (int ib = 0; ib < cfg->Nblocks; ++ib) {
+            const int nblk = (int)blockstep_nblk(h->block_offsets[ib + 1] - h->block_offsets[ib]);
+            for (int t = 0; t < nblk; ++t) role.push_back(t == 0 ? 0 : (t == nblk - 1 ? 2 : 1));
+        }
+        CRCHK(dev_alloc_copy(&h->d_slot_role, role.data(), role.size(), h->stream));
+    }
     std::vector<double> wp, design_rm;
     if (cfg->target_kind == DEMCZ_TARGET_MVNORMAL || cfg->target_kind == DEMCZ_TARGET_ISO_QUAD)
         CRCHK(dev_alloc_copy(&h->d_mu, cfg->mu, (size_t)d, h->stream));
@@ -566,6 +580,9 @@ static bool split_ml_available(int target_kind, int d, bool full_block)
 }
 
 static int pc_roles(int d) { return ((d == 1) ? 1 : (d + 1) / 2) + 2; }
+// doubles of draw record per (generation, chain), and producer lanes per (generation, chain)
+static int64_t rec_fields(const demcz_handle* h) { return (h->split_kind == 3) ? 2 * h->S : (int64_t)h->cfg.d + 2; }
+static int64_t rec_roles(const demcz_handle* h) { return (h->split_kind == 3) ? h->S : pc_roles(h->cfg.d); }
 
 #ifdef DEMCZ_STAMPS
 constexpr int64_t DEMCZ_STAMP_WGS = 1 << 16;
@@ -590,9 +607,24 @@ static void launch_pc(const demcz_handle* h, const WindowParams& P, int64_t bloc
 static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool live = false)
 {
     const int64_t nbc = (P.N + 63) / 64;
-    const int64_t blocks = P.consumer_blocks + nbc * pc_roles(P.d) * P.next_ngen;
+    const int64_t blocks = P.consumer_blocks + nbc * rec_roles(h) * P.next_ngen;
     if (blocks <= 0) return DEMCZ_OK;
-    if (h->split_kind == 2) {
+    if (h->split_kind == 3) {
+        const dim3 grid((unsigned)blocks), wg(64);
+#define DEMCZ_LAUNCH_MLB_REC(DD, LL)                                                                                         \
+        do {                                                                                                                 \
+            if (live) hipLaunchKernelGGL((window_kernel_mlb<TARGET_MVNORMAL, DD, LL, true, true>), grid, wg, 0, h->stream, P);   \
+            else hipLaunchKernelGGL((window_kernel_mlb<TARGET_MVNORMAL, DD, LL, true, false>), grid, wg, 0, h->stream, P);       \
+        } while (0)
+        switch (P.d) {
+        case 5: DEMCZ_LAUNCH_MLB_REC(5, 8); break;
+        case 6: DEMCZ_LAUNCH_MLB_REC(6, 8); break;
+        case 10: DEMCZ_LAUNCH_MLB_REC(10, 8); break;
+        case 20: DEMCZ_LAUNCH_MLB_REC(20, 16); break;
+        default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
+        }
+#undef DEMCZ_LAUNCH_MLB_REC
+    } else if (h->split_kind == 2) {
         const dim3 grid((unsigned)blocks), wg(64);
         if (live) hipLaunchKernelGGL((window_kernel_ml<TARGET_MVNORMAL, 20, 16, true, true>), grid, wg, 0, h->stream, P);
         else hipLaunchKernelGGL((window_kernel_ml<TARGET_MVNORMAL, 20, 16, true, false>), grid, wg, 0, h->stream, P);
@@ -627,8 +659,9 @@ static int32_t pc_prepare(demcz_handle* h, WindowParams& P, int64_t cur_rows, in
             if (h->d_rec[b]) HIPCHK(h, hipFree(h->d_rec[b]));
             h->d_rec[b] = nullptr;
             // (+ REC_PAD doubles: a consumer's last 16-byte chunk fetch may run past its row's last generation)
-            HIPCHK(h, hipMalloc((void**)&h->d_rec[b], ((size_t)need * (d + 2) * h->cfg.N + REC_PAD) * sizeof(double)));
-            HIPCHK(h, hipMemsetAsync(h->d_rec[b], 0, ((size_t)need * (d + 2) * h->cfg.N + REC_PAD) * sizeof(double), h->stream));   // row 0: always a legal index
+            const size_t nd = (size_t)need * (size_t)rec_fields(h) * h->cfg.N + REC_PAD;
+            HIPCHK(h, hipMalloc((void**)&h->d_rec[b], nd * sizeof(double)));
+            HIPCHK(h, hipMemsetAsync(h->d_rec[b], 0, nd * sizeof(double), h->stream));   // row 0: always a legal index
             h->rec_desc[b].valid = false;
         }
         h->rec_cap = need;
@@ -648,7 +681,7 @@ static int32_t pc_prepare(demcz_handle* h, WindowParams& P, int64_t cur_rows, in
         dc.valid = true; dc.g_first = P.g_first; dc.M = P.M; dc.ngen = P.ngen; dc.rows = cur_rows; dc.boff = cur_boff;
     }
     P.rec_in = h->d_rec[cur];
-    const int per_wg = (h->split_kind == 2) ? 4 : PC_CONSUMER_CHAINS;       // chains per consumer workgroup
+    const int per_wg = (h->split_kind == 1) ? PC_CONSUMER_CHAINS : 64 / h->split_lanes;       // chains per consumer workgroup
     P.consumer_blocks = (int32_t)((P.N + per_wg - 1) / per_wg);
     P.rec_out = h->d_rec[cur ^ 1];
     P.next_g_first = next_g; P.next_ngen = (int32_t)std::max<int64_t>(next_ngen, 0); P.next_M = next_M;
@@ -855,7 +888,16 @@ static int64_t live_wg_capacity(demcz_handle* h)
 {
     if (h->live_wg_cap >= 0) return h->live_wg_cap;
     int per_cu = 0;
-    if (h->split_kind == 2) {
+    if (h->split_kind == 3) {
+        const void* f = nullptr;
+        switch (h->cfg.d) {
+        case 5: f = reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 5, 8, true, true>); break;
+        case 6: f = reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 6, 8, true, true>); break;
+        case 10: f = reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 10, 8, true, true>); break;
+        case 20: f = reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 20, 16, true, true>); break;
+        }
+        if (!f || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 64, 0) != hipSuccess) per_cu = 0;
+    } else if (h->split_kind == 2) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&window_kernel_ml<TARGET_MVNORMAL, 20, 16, true, true>), 64, 0) != hipSuccess) per_cu = 0;
     } else if (h->cfg.target_kind == DEMCZ_TARGET_ISO_QUAD) {
         per_cu = pc_live_blocks_per_cu<TARGET_ISO_QUAD, 10>();
@@ -884,9 +926,9 @@ static int64_t live_span(demcz_handle* h)
     if (h->lanes != DEMCZ_LAYOUT_SPLIT || h->comm || h->lag > 0 || h->external_append) return 0;
     static const bool disabled = (getenv("DEMCZ_NO_LIVE") != nullptr);     // safety valve: one launch per K-window
     if (disabled) return 0;
-    const int per_wg = (h->split_kind == 2) ? 4 : PC_CONSUMER_CHAINS;
+    const int per_wg = (h->split_kind == 1) ? PC_CONSUMER_CHAINS : 64 / h->split_lanes;
     if ((h->cfg.N + per_wg - 1) / per_wg > live_wg_capacity(h)) return 0;
-    const int64_t per_gen = (int64_t)(h->cfg.d + 2) * h->cfg.N * (int64_t)sizeof(double);
+    const int64_t per_gen = rec_fields(h) * h->cfg.N * (int64_t)sizeof(double);
     const int64_t span = (int64_t)(64ll << 20) / per_gen;        // 64 MiB of records per buffer (C2: 1170 generations)
     return std::max<int64_t>(h->cfg.K, std::min<int64_t>(span, 1 << 20));
 }
@@ -935,7 +977,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     P.chain = hist ? h->dchain : nullptr; P.logobj = hist ? h->dlogobj : nullptr;
     P.N = h->cfg.N; P.chain_id0 = h->cfg.chain_id0; P.d = h->cfg.d;
     P.gamma = gamma; P.seed = h->cfg.seed; P.S = h->S; P.Nblocks = h->cfg.Nblocks;
-    P.block_offsets = h->d_block_offsets; P.slot_of = h->d_slot_of; P.eps = h->d_eps;
+    P.block_offsets = h->d_block_offsets; P.slot_of = h->d_slot_of; P.eps = h->d_eps; P.slot_role = h->d_slot_role;
     P.tp = target_params(h);
     P.snap = nullptr;
     P.K = K;

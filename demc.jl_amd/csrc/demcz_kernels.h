@@ -80,6 +80,7 @@ struct WindowParams {
     const double* rec_in;
     double* rec_out;
     int64_t rec_stride;      // generations each (field, chain) row of a record buffer holds
+    const int32_t* slot_role; // block-structured split runs: what Philox block s of a generation is (0 rows, 1 normal pair, 2 log u)
     int64_t next_g_first;    // stream generation index of the next launch's first generation
     int64_t next_M;          // rows its first generation draws from
     int64_t next_rows;       // ... plus this many per K boundary it has passed (0: appended rows become visible later)

@@ -404,10 +404,19 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
 // ------------------------------------------------------------------------------------------------
 constexpr int MLB_MAX_BLOCKS = 64;
 
-template <int TARGET, int D, int L>
+// REC / LIVE: the split form (demcz_kernels_rec.h, pcb_produce) -- a block-step's draws are read from the
+// records (entries two block-steps ahead, archive rows one ahead) instead of made here.
+template <int TARGET, int D, int L, bool REC = false, bool LIVE = false>
 __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
 {
     static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "block layout: MvNormal / isotropic targets");
+    static_assert(!LIVE || REC, "LIVE launches are a property of the split form");
+    if constexpr (REC) {
+        if ((int64_t)blockIdx.x >= P.consumer_blocks) {
+            pcb_produce(P, (int64_t)blockIdx.x - P.consumer_blocks);
+            return;
+        }
+    }
     constexpr int G = 64 / L;
     constexpr int NP = (D + L - 1) / L;
     constexpr int DP = ((D + 1) / 2) * 2;
@@ -454,7 +463,25 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
         }
     }
     double lp = P.lpcur[c];
-    philox_blocks rng;
+    [[maybe_unused]] philox_blocks rng;
+    // REC: this lane's entry of a block-step's record: slot boff[ib] + role of chain c, generation gi
+    [[maybe_unused]] const double2* rec2 = reinterpret_cast<const double2*>(P.rec_in);
+    [[maybe_unused]] double2 e_pre = make_double2(0.0, 0.0);        // entry of the block-step issue_draws is called for next
+    [[maybe_unused]] int64_t row1_n = 0, row2_n = 0, row1_c = 0, row2_c = 0;
+    auto load_entry = [&](int gi, int ib) {
+        const int b = blen_l[ib];
+        const int nn = (b == 1) ? 1 : b;
+        const int Sb = 2 + (nn + 1) / 2;
+        const int role = (r < Sb) ? r : Sb - 1;
+        const int g = (gi < P.ngen) ? gi : P.ngen - 1;
+        return rec2[((size_t)(boff_l[ib] + role) * (size_t)P.N + (size_t)c) * (size_t)P.rec_stride + (size_t)g];
+    };
+    if constexpr (REC) {
+        if constexpr (LIVE) {       // an earlier launch of the run already failed: do not wait again
+            if (__hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+        }
+        e_pre = load_entry(0, 0);
+    }
 
     // draws of block-step (gi, ib), issued one block-step ahead of their use
     double za[NP], zb[NP], zt[NP], logu_next;
@@ -464,6 +491,38 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
         const int nn = (b == 1) ? 1 : b;
         const int Sb = 2 + (nn + 1) / 2;
         const int role = (r < Sb) ? r : Sb - 1;
+        if constexpr (REC) {
+            const double2 e = e_pre;
+            {   // the entry of the block-step after this one, for the next call
+                const int ib2 = (ib + 1 == NB) ? 0 : ib + 1;
+                const int gi2 = (ib + 1 == NB) ? gi + 1 : gi;
+                e_pre = load_entry(gi2, ib2);
+            }
+            if (r < Sb) rec[gq * L + r] = e;
+            wave_lds_handoff();
+            const double2 ii = rec[gq * L];
+            logu_next = rec[gq * L + Sb - 1].x;
+            row1_n = __double_as_longlong(ii.x);
+            row2_n = __double_as_longlong(ii.y);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int p = r + L * k;
+                const int pc = (p < D) ? p : 0;
+                const int ts = (p < D) ? slot_l[ib * D + pc] : -1;
+                tslot[k] = ts;
+                const int zi = (b == 1 || ts < 0) ? 0 : ts;
+                zt[k] = reinterpret_cast<const double*>(rec)[(gq * L + 1 + zi / 2) * 2 + (zi & 1)];
+                if constexpr (LIVE) {
+                    za[k] = (ts >= 0) ? live_load(&P.Z[row1_n * P.ZS + pc]) : 0.0;
+                    zb[k] = (ts >= 0) ? live_load(&P.Z[row2_n * P.ZS + pc]) : 0.0;
+                } else {
+                    za[k] = (ts >= 0) ? P.Z[row1_n * P.ZS + pc] : 0.0;
+                    zb[k] = (ts >= 0) ? P.Z[row2_n * P.ZS + pc] : 0.0;
+                }
+            }
+            wave_lds_handoff();
+            return;
+        }
         uint64_t r1, r2, i1, i2;
         rng.block(P.seed, chain, (uint64_t)(P.g_first + gi - 1) * (uint64_t)P.S + (uint64_t)(boff_l[ib] + role), r1, r2);
         const double lg = dm_log(u_open(r1));
@@ -504,6 +563,28 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
     int64_t nb = 0;
     for (int gi = 0; gi < P.ngen; ++gi) {
         for (int ib = 0; ib < NB; ++ib) {
+            if constexpr (LIVE) {
+                // the gather was issued a block-step ago; rows appended since then by other waves read as the
+                // sentinel until they are published: ask again (demcz_kernels_rec.h)
+                row1_c = row1_n; row2_c = row2_n;
+                bool bad = false;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) bad |= is_sentinel(za[k]) | is_sentinel(zb[k]);
+                int spins = 0;
+                while (__builtin_amdgcn_ballot_w64(bad) != 0ull) {       // wave-uniform
+                    if (live_poll_abandon(P, spins, bad, (unsigned)(is_sentinel(za[0]) ? row1_c : row2_c), gi)) return;
+                    __builtin_amdgcn_s_sleep(1);
+                    bad = false;
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        const int p = r + L * k;
+                        const int pc = (p < D) ? p : 0;
+                        if (is_sentinel(za[k])) za[k] = live_load(&P.Z[row1_c * P.ZS + pc]);
+                        if (is_sentinel(zb[k])) zb[k] = live_load(&P.Z[row2_c * P.ZS + pc]);
+                        bad |= is_sentinel(za[k]) | is_sentinel(zb[k]);
+                    }
+                }
+            }
             double delta[NP];
             bool inb[NP];
             const double scale = bscale_l[ib];
@@ -584,7 +665,10 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
             for (int k = 0; k < NP; ++k) {
                 const int p = r + L * k;
                 if (p < D) {
-                    if (P.do_append) P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p] = x[k];
+                    if (P.do_append) {
+                        if constexpr (LIVE) live_store(&P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p], x[k]);
+                        else P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p] = x[k];
+                    }
                     if (P.snap) P.snap[nb * P.N * D + c + P.N * p] = x[k];
                 }
             }

@@ -76,6 +76,44 @@ __device__ __forceinline__ void pc_produce(const WindowParams& P, int64_t pb)
     }
 }
 
+// Block-structured runs (DEMCopt.Nblocks > 1, update_blocks demcz.jl:167-172): the record of a generation is
+// one 16-byte entry per Philox block s of its S blocks -- the two row indices (as 64-bit integers), a
+// Box-Muller pair, or log u -- exactly what the cooperating lanes of the fused kernel hand each other
+// through LDS.  rec2[(s * N + c) * GS + g].
+__device__ __forceinline__ void pcb_produce(const WindowParams& P, int64_t pb)
+{
+    const int64_t nbc = (P.N + 63) / 64;
+    const int64_t plane = pb / nbc;                        // wave-uniform
+    const int64_t c = (pb % nbc) * 64 + threadIdx.x;
+    const int s = (int)(plane % P.S), gi = (int)(plane / P.S);
+    if (gi >= P.next_ngen || c >= P.N) return;
+    const int role = P.slot_role[s];
+    philox_blocks rng;
+    uint64_t r1, r2;
+    rng.block(P.seed, (uint64_t)(P.chain_id0 + c), (uint64_t)(P.next_g_first + gi - 1) * (uint64_t)P.S + (uint64_t)s, r1, r2);
+    double2 e;
+    if (role == 0) {
+        const int64_t Mg = P.next_M + (int64_t)((gi + P.next_boff) / P.K) * P.next_rows;
+        uint64_t i1, i2;
+        draw_rows(r1, r2, (uint64_t)Mg, i1, i2);
+        e.x = __longlong_as_double((long long)i1);
+        e.y = __longlong_as_double((long long)i2);
+    } else {
+        const double lg = dm_log(u_open(r1));
+        if (role == 2) {
+            e.x = lg;
+            e.y = 0.0;
+        } else {
+            const double R = sqrt(-2.0 * lg);
+            double cs, sn;
+            dm_sincos2pi(r2 >> 11, cs, sn);
+            e.x = R * cs;
+            e.y = R * sn;
+        }
+    }
+    reinterpret_cast<double2*>(P.rec_out)[((size_t)s * (size_t)P.N + (size_t)c) * (size_t)P.rec_stride + (size_t)gi] = e;
+}
+
 // LIVE launches (single GPU, the reference's immediate visibility): one launch runs through several
 // K boundaries.  The rows a boundary appends are drawn from in the very next generation, by any chain,
 // so waves hand rows to each other INSIDE the launch, and they do it through the data itself:
