@@ -18,9 +18,10 @@
 //       proposal, log-density, accept, history -- from registers: ~55 instructions a generation.
 //
 // Both halves are ONE launch (workgroups [0, consumer_blocks) consume, the rest produce), so they
-// overlap on different CUs with no events or second stream; the kernel boundary that already
-// separates K-windows also orders a window's records before their use.  The next launch's M is known
-// to the host when this one is launched (it is this M plus the rows this launch appends).
+// overlap on different CUs with no events or second stream; a launch boundary orders a launch's
+// records before their use.  The host knows what the next launch will see: this M plus N rows per K
+// boundary passed (demcz_capi.hip, pc_prepare).  On one GPU a launch runs through many K boundaries and
+// the consumers hand the appended rows to each other inside it (LIVE, demcz_kernels_rec.h).
 // Arithmetic and operation order are those of the one-lane kernel: bit-identical results.
 #pragma once
 
@@ -32,14 +33,13 @@ namespace demcz {
 
 
 // ------------------------------------------------------------------------------------------------
-// The consumer: 8 lanes per chain.  Lane p of a chain's group prefetches what concerns parameter p
-// for a whole chunk of generations at once (row elements, normal: 3 loads a generation, so a
-// 10-generation chunk fits in registers and its memory latency -- records beside archive rows --
-// is paid once per chunk), forms its increments and shares them through LDS; then every lane
-// of the group runs the state-dependent part redundantly from the whole state (no cross-lane traffic
-// there) and stores its own element of the history row.
+// The consumer: 8 lanes per chain, two roles.  Front-end of a chunk of <= 10 generations: lane u of a
+// chain's group fetches what generation u needs (the two archive rows whole, its normals), forms that
+// generation's increments and puts them into LDS -- the memory latency is paid once per chunk.  Then
+// every lane of the group runs the state-dependent part of the chunk redundantly from the whole state
+// (no cross-lane traffic there), lane p storing element p of the history row (lane d: log_obj).
 // (A one-lane-per-chain consumer has to hold 3d+1 doubles per prefetched generation: 5-generation
-// chunks, 9.0 us per C2 window against 7.0 for this one.)
+// chunks, 9.0 us per C2 window against 7.0 for the first 8-lane version.)
 // ------------------------------------------------------------------------------------------------
 constexpr int PC8_CHUNK = 10;
 
@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
 {
     static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "split layout: MvNormal / isotropic targets");
     constexpr int L = 8, G = 64 / L, DP = ((D + 1) / 2) * 2;
-    constexpr int NP = (D + L - 1) / L;                    // parameters a lane prefetches: r, r+8, ...
+    constexpr int NP = (D + L - 1) / L;                    // history elements a lane stores: r, r+8, ...
     constexpr int CH = (D <= 5) ? PC8_CHUNK : PC8_CHUNK / 2;      // the chunk's increments (CH x D doubles) live in registers
     DEMCZ_STAMP(P, 0);
     if ((int64_t)blockIdx.x >= P.consumer_blocks) {
