@@ -305,26 +305,53 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
                     sacc = res * res;
                 }
                 o += L;
-                // four observations in flight: their dot products are independent dependency
-                // chains (the order inside each, and of the four additions into sacc, is the spec's)
-                for (; o + 3 * L < P.tp.nobs; o += 4 * L) {
-                    const double* q0 = design_l + o * D;
-                    const double* q1 = q0 + L * D;
-                    const double* q2 = q1 + L * D;
-                    const double* q3 = q2 + L * D;
-                    double a0 = q0[0] * rj[0], a1 = q1[0] * rj[0], a2 = q2[0] * rj[0], a3 = q3[0] * rj[0];
+                // Two observations per stage, two stages in flight: the LDS reads of the next pair are issued
+                // before the current pair's dot products (the wave is alone on its SIMD: nothing else hides
+                // the LDS latency, and 40 of this kernel's 67 us per window were spent waiting for it).  The
+                // order inside each dot product, and of the additions into sacc, is the spec's.
+                constexpr int DH = (D + 1) / 2;
+                auto load2 = [&](int64_t oo, double (&A)[2][2 * DH], double (&Y)[2]) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const double2* row = reinterpret_cast<const double2*>(design_l + (oo + t * L) * D);
+#pragma unroll
+                        for (int j = 0; j < DH; ++j) {
+                            const double2 v = row[j];
+                            A[t][2 * j] = v.x;
+                            A[t][2 * j + 1] = v.y;
+                        }
+                        Y[t] = y_l[oo + t * L];
+                    }
+                };
+                auto comp2 = [&](const double (&A)[2][2 * DH], const double (&Y)[2]) {
+                    double a0 = A[0][0] * rj[0], a1 = A[1][0] * rj[0];
 #pragma unroll
                     for (int j = 1; j < D; ++j) {
-                        a0 = fma(q0[j], rj[j], a0);
-                        a1 = fma(q1[j], rj[j], a1);
-                        a2 = fma(q2[j], rj[j], a2);
-                        a3 = fma(q3[j], rj[j], a3);
+                        a0 = fma(A[0][j], rj[j], a0);
+                        a1 = fma(A[1][j], rj[j], a1);
                     }
-                    const double e0 = y_l[o] - a0, e1 = y_l[o + L] - a1, e2 = y_l[o + 2 * L] - a2, e3 = y_l[o + 3 * L] - a3;
+                    const double e0 = Y[0] - a0, e1 = Y[1] - a1;
                     sacc = fma(e0, e0, sacc);
                     sacc = fma(e1, e1, sacc);
-                    sacc = fma(e2, e2, sacc);
-                    sacc = fma(e3, e3, sacc);
+                };
+                static_assert(D % 2 == 0, "regression layout: 16-byte rows");
+                double A0[2][2 * DH], A1[2][2 * DH], Y0[2], Y1[2];
+                if (o + L < P.tp.nobs) {
+                    load2(o, A0, Y0);
+                    while (true) {
+                        const int64_t o1 = o + 2 * L;
+                        const bool have1 = o1 + L < P.tp.nobs;
+                        if (have1) load2(o1, A1, Y1);
+                        comp2(A0, Y0);
+                        o = o1;
+                        if (!have1) break;
+                        const int64_t o2 = o1 + 2 * L;
+                        const bool have2 = o2 + L < P.tp.nobs;
+                        if (have2) load2(o2, A0, Y0);
+                        comp2(A1, Y1);
+                        o = o2;
+                        if (!have2) break;
+                    }
                 }
 #pragma unroll 1
                 for (; o < P.tp.nobs; o += L) {
