@@ -35,14 +35,16 @@ constexpr int ML_LR_WAVES = 4;
 template <int TARGET>
 constexpr int ml_waves() { return TARGET == TARGET_LINREG_SSE ? ML_LR_WAVES : 1; }
 
-// bytes of dynamic LDS the regression layout needs (0 for the other targets)
+// bytes of dynamic LDS the regression layout needs (0 for the other targets): the per-chain staging rows, y
+// padded to whole 16-observation tiles, and the design in the A-operand order of v_mfma_f64_4x4x4_f64
 template <int TARGET, int D, int L>
 __host__ __device__ constexpr size_t ml_dynamic_lds(int64_t nobs)
 {
     if (TARGET != TARGET_LINREG_SSE) return 0;
     constexpr int G = 64 / L, NPAIRS = (D == 1) ? 1 : (D + 1) / 2, S = NPAIRS + 2, DP = ((D + 1) / 2) * 2;
     constexpr int NG = ML_LR_WAVES * G;
-    return (size_t)NG * S * 16 + (size_t)NG * DP * 8 + (size_t)NG * L * 8 + (size_t)(((nobs + 1) / 2) * 2) * 8 + (size_t)nobs * D * 8;
+    const size_t ntile = (size_t)((nobs + 15) / 16), nm = (size_t)((D + 3) / 4);
+    return (size_t)NG * S * 16 + (size_t)NG * DP * 8 + (size_t)NG * L * 8 + ntile * 16 * 8 + ntile * nm * 64 * 8;
 }
 
 // REC: the split form of this layout (demcz_kernels_rec.h) -- workgroups beyond consumer_blocks are the
@@ -88,18 +90,31 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
         rec = reinterpret_cast<double2*>(q);   q += (size_t)NG * S * 16;
         rvec = reinterpret_cast<double*>(q);   q += (size_t)NG * DP * 8;
         yvec = reinterpret_cast<double*>(q);   q += (size_t)NG * YP * 8;
-        double* yl = reinterpret_cast<double*>(q);   q += (size_t)(((P.tp.nobs + 1) / 2) * 2) * 8;
+        // y padded with zeros to whole tiles, the design in the A-operand order of v_mfma_f64_4x4x4_f64:
+        // Am[(t NM + m) 64 + l] = X[16 t + l % 16][4 m + l / 16], zero outside the data (a padded observation
+        // then adds fma(0, 0, .) to its partial: nothing)
+        const int64_t ntile_f = (P.tp.nobs + 15) / 16;
+        constexpr int NMF = (D + 3) / 4;
+        double* yl = reinterpret_cast<double*>(q);   q += (size_t)ntile_f * 16 * 8;
         double* dl = reinterpret_cast<double*>(q);
-        const int64_t nd = P.tp.nobs * D;
-        for (int64_t i = threadIdx.x; i < nd; i += 64 * WAVES) dl[i] = P.tp.design[i];
-        for (int64_t i = threadIdx.x; i < P.tp.nobs; i += 64 * WAVES) yl[i] = P.tp.yobs[i];
+        for (int64_t i = threadIdx.x; i < ntile_f * NMF * 64; i += 64 * WAVES) {
+            const int ll = (int)(i % 64);
+            const int64_t tm = i / 64;
+            const int64_t o = 16 * (tm / NMF) + ll % 16;
+            const int col = 4 * (int)(tm % NMF) + ll / 16;
+            dl[i] = (o < P.tp.nobs && col < D) ? P.tp.design[o * D + col] : 0.0;
+        }
+        for (int64_t i = threadIdx.x; i < ntile_f * 16; i += 64 * WAVES) yl[i] = (i < P.tp.nobs) ? P.tp.yobs[i] : 0.0;
         __syncthreads();
         y_l = yl;
         design_l = dl;
     }
 
     const int lane = threadIdx.x & 63;
-    const int r = lane % L, gq = (threadIdx.x >> 6) * G + lane / L;
+    // regression: the lane's (partial r, chain of the wave) are those of the matrix instruction's result lane
+    // 16 i + 4 blk + j = D_blk[i][j] (observation 4 blk + i of the tile, chain j): r = 4 blk + i
+    const int r = LR ? 4 * ((lane % 16) / 4) + lane / 16 : lane % L;
+    const int gq = (threadIdx.x >> 6) * G + (LR ? lane % 4 : lane / L);
     const int64_t c_raw = (int64_t)blockIdx.x * NG + gq;
     if (!LR && c_raw >= P.N) return;
     const bool active = c_raw < P.N;                       // regression: idle groups of the last workgroup keep pace
@@ -291,76 +306,54 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
             for (int j = 0; j < D; ++j) q = (j == 0) ? rj[0] * rj[0] : fma(rj[j], rj[j], q);
             lpp = -q;
         } else {
-            // lane r accumulates SSE partial r (observations r, r+16, ...) from the LDS copy of the
-            // design; rows of 16 consecutive observations sit on distinct banks (stride D*8 bytes).
+            // SSE partial r of the chain (observations r, r + 16, ...): the residuals of a tile of 16 observations
+            // for the wave's 4 chains are three v_mfma_f64_4x4x4_f64 (k = 0..3, 4..7, 8..11; four 4x4 blocks =
+            // four observation quads x the same four chains).  The instruction accumulates like the sequential
+            // chain fma(a_k, b_k, .), k ascending, from C (probed: scripts/probes/mfma_f64_4x4x4.hip, bit-identical
+            // on 65536 random results) = the spec's dot product.  A row of the design is fetched once for the four
+            // chains -- the vector form of this loop was bound by the LDS read throughput of its SIMD.
+            constexpr int NMF = (D + 3) / 4;
+            double bop[NMF];                    // B operand: this lane provides b[4 m + lane / 16] of chain lane % 4 (its own)
+#pragma unroll
+            for (int m = 0; m < NMF; ++m) {
+                double v = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    if (4 * m + kk < D) v = ((r & 3) == kk) ? rj[4 * m + kk] : v;
+                bop[m] = (4 * m + (r & 3) < D) ? v : 0.0;
+            }
+            const int ntile = (int)((P.tp.nobs + 15) / 16);
             double sacc = 0.0;
+            auto tile = [&](int t) {
+                double acc = 0.0;
+#pragma unroll
+                for (int m = 0; m < NMF; ++m)
+                    acc = __builtin_amdgcn_mfma_f64_4x4x4f64(design_l[((size_t)t * NMF + m) * 64 + lane], bop[m], acc, 0, 0, 0);
+                return acc;
+            };
             {
-                int64_t o = r;
-                if (o < P.tp.nobs) {
-                    const double* row = design_l + o * D;
-                    double acc = row[0] * rj[0];
+                // TF tiles in flight: a tile's three instructions chain through C, and the matrix pipe wants
+                // several independent chains to stay busy
+                constexpr int TF = 6;
+                int t = 0;
+                for (; t + TF <= ntile; t += TF) {
+                    double a[TF];
 #pragma unroll
-                    for (int j = 1; j < D; ++j) acc = fma(row[j], rj[j], acc);
-                    const double res = y_l[o] - acc;
-                    sacc = res * res;
+                    for (int i = 0; i < TF; ++i) a[i] = 0.0;
+#pragma unroll
+                    for (int m = 0; m < NMF; ++m)
+#pragma unroll
+                        for (int i = 0; i < TF; ++i)
+                            a[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(design_l[((size_t)(t + i) * NMF + m) * 64 + lane], bop[m], a[i], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < TF; ++i) {
+                        const double e = y_l[16 * (t + i) + r] - a[i];
+                        sacc = fma(e, e, sacc);
+                    }
                 }
-                o += L;
-                // Two observations per stage, two stages in flight: the LDS reads of the next pair are issued
-                // before the current pair's dot products (the wave is alone on its SIMD: nothing else hides
-                // the LDS latency, and 40 of this kernel's 67 us per window were spent waiting for it).  The
-                // order inside each dot product, and of the additions into sacc, is the spec's.
-                constexpr int DH = (D + 1) / 2;
-                auto load2 = [&](int64_t oo, double (&A)[2][2 * DH], double (&Y)[2]) {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const double2* row = reinterpret_cast<const double2*>(design_l + (oo + t * L) * D);
-#pragma unroll
-                        for (int j = 0; j < DH; ++j) {
-                            const double2 v = row[j];
-                            A[t][2 * j] = v.x;
-                            A[t][2 * j + 1] = v.y;
-                        }
-                        Y[t] = y_l[oo + t * L];
-                    }
-                };
-                auto comp2 = [&](const double (&A)[2][2 * DH], const double (&Y)[2]) {
-                    double a0 = A[0][0] * rj[0], a1 = A[1][0] * rj[0];
-#pragma unroll
-                    for (int j = 1; j < D; ++j) {
-                        a0 = fma(A[0][j], rj[j], a0);
-                        a1 = fma(A[1][j], rj[j], a1);
-                    }
-                    const double e0 = Y[0] - a0, e1 = Y[1] - a1;
+                for (; t < ntile; ++t) {
+                    const double e0 = y_l[16 * t + r] - tile(t);
                     sacc = fma(e0, e0, sacc);
-                    sacc = fma(e1, e1, sacc);
-                };
-                static_assert(D % 2 == 0, "regression layout: 16-byte rows");
-                double A0[2][2 * DH], A1[2][2 * DH], Y0[2], Y1[2];
-                if (o + L < P.tp.nobs) {
-                    load2(o, A0, Y0);
-                    while (true) {
-                        const int64_t o1 = o + 2 * L;
-                        const bool have1 = o1 + L < P.tp.nobs;
-                        if (have1) load2(o1, A1, Y1);
-                        comp2(A0, Y0);
-                        o = o1;
-                        if (!have1) break;
-                        const int64_t o2 = o1 + 2 * L;
-                        const bool have2 = o2 + L < P.tp.nobs;
-                        if (have2) load2(o2, A0, Y0);
-                        comp2(A1, Y1);
-                        o = o2;
-                        if (!have2) break;
-                    }
-                }
-#pragma unroll 1
-                for (; o < P.tp.nobs; o += L) {
-                    const double* row = design_l + o * D;
-                    double acc = row[0] * rj[0];
-#pragma unroll
-                    for (int j = 1; j < D; ++j) acc = fma(row[j], rj[j], acc);
-                    const double res = y_l[o] - acc;
-                    sacc = fma(res, res, sacc);
                 }
             }
             yvec[gq * YP + r] = sacc;
