@@ -79,6 +79,7 @@ struct demcz_handle {
     int split_kind = 0;               // lanes == DEMCZ_LAYOUT_SPLIT: 1 = eight replicated lanes per chain (pc8), 2 = 16 cooperating
                                       // lanes (ml, REC), 3 = cooperating lanes with block updates (mlb, REC)
     int split_lanes = 0;              // kinds 2, 3: lanes per chain of the consumer
+    int split_per_wg = 1;             // chains per consumer workgroup
     int32_t* d_slot_role = nullptr;   // kind 3: role of every Philox block of a generation
     double* d_rec[2] = {nullptr, nullptr};
     unsigned int* d_live_err = nullptr;   // device word a LIVE launch sets when an expected row never appears
@@ -139,9 +140,10 @@ static int64_t blockstep_nblk(int b)
 }
 
 constexpr size_t ML_MAX_DYNAMIC_LDS = 160 * 1024;      // LDS per CU on gfx950
+constexpr int PC_CONSUMER_CHAINS = 8;       // chains per consumer workgroup of the replicated split layout: 8 lanes per chain
 static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t nobs, int max_blocklen, int nblocks);
 static bool pc_available(int target_kind, int d, bool full_block);
-static bool split_ml_available(int target_kind, int d, bool full_block);
+static bool split_ml_available(int target_kind, int d, bool full_block, int64_t nobs);
 static int32_t flush_exchanges(demcz_handle* h);
 static int32_t check_live_err(demcz_handle* h);
 
@@ -274,9 +276,12 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         // 32-bit row indices in the records, 32-bit byte offsets into the archive
         const bool idx32 = cfg->Mcap <= 0xffffffffll && (double)cfg->Mcap * 8.0 * (((d + 7) / 8) * 8) < 4294967296.0;
         const int kind = !idx32 ? 0 : pc_available(cfg->target_kind, d, h->full_block) ? 1
-                         : split_ml_available(cfg->target_kind, d, h->full_block) ? 2
+                         : split_ml_available(cfg->target_kind, d, h->full_block, cfg->nobs) ? 2
                          : (!h->full_block && cfg->target_kind == DEMCZ_TARGET_MVNORMAL && L > 1) ? 3 : 0;
         h->split_lanes = (kind == 2) ? 16 : (kind == 3) ? L : 0;
+        // chains per consumer workgroup
+        h->split_per_wg = (kind == 1) ? PC_CONSUMER_CHAINS : (kind == 2) ? ((cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? ML_LR_WAVES * 4 : 4)
+                          : (kind == 3) ? 64 / L : 1;
         const bool split_ok = kind != 0;
         h->split_kind = 0;
         if (cfg->lanes_per_chain == DEMCZ_LAYOUT_SPLIT) {
@@ -574,9 +579,11 @@ static bool pc_available(int target_kind, int d, bool full_block)
 }
 
 // the split form of the 16-lane layout (window_kernel_ml<.., REC>): where the replicated consumer does not fit
-static bool split_ml_available(int target_kind, int d, bool full_block)
+static bool split_ml_available(int target_kind, int d, bool full_block, int64_t nobs)
 {
-    return full_block && target_kind == DEMCZ_TARGET_MVNORMAL && d == 20;
+    if (!full_block) return false;
+    if (target_kind == DEMCZ_TARGET_MVNORMAL) return d == 20;
+    return target_kind == DEMCZ_TARGET_LINREG_SSE && d == 10 && ml_dynamic_lds<TARGET_LINREG_SSE, 10, 16>(nobs) <= ML_MAX_DYNAMIC_LDS;
 }
 
 static int pc_roles(int d) { return ((d == 1) ? 1 : (d + 1) / 2) + 2; }
@@ -587,7 +594,6 @@ static int64_t rec_roles(const demcz_handle* h) { return (h->split_kind == 3) ? 
 #ifdef DEMCZ_STAMPS
 constexpr int64_t DEMCZ_STAMP_WGS = 1 << 16;
 #endif
-constexpr int PC_CONSUMER_CHAINS = 8;
 constexpr size_t REC_PAD = 32;       // chains per consumer workgroup: 8 lanes per chain
 
 template <int TARGET, int D>
@@ -607,7 +613,9 @@ static void launch_pc(const demcz_handle* h, const WindowParams& P, int64_t bloc
 static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool live = false)
 {
     const int64_t nbc = (P.N + 63) / 64;
-    const int64_t blocks = P.consumer_blocks + nbc * rec_roles(h) * P.next_ngen;
+    const bool lr_split = h->split_kind == 2 && h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE;
+    const int64_t units = nbc * rec_roles(h) * P.next_ngen;               // 64-lane producer units
+    const int64_t blocks = P.consumer_blocks + (lr_split ? (units + ML_LR_WAVES - 1) / ML_LR_WAVES : units);
     if (blocks <= 0) return DEMCZ_OK;
     if (h->split_kind == 3) {
         const dim3 grid((unsigned)blocks), wg(64);
@@ -624,6 +632,17 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
         default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
         }
 #undef DEMCZ_LAUNCH_MLB_REC
+    } else if (lr_split) {
+        const dim3 grid((unsigned)blocks), wg(64 * ML_LR_WAVES);
+        const size_t dyn = ml_dynamic_lds<TARGET_LINREG_SSE, 10, 16>(P.tp.nobs);
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_ml<TARGET_LINREG_SSE, 10, 16, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_ml<TARGET_LINREG_SSE, 10, 16, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
+            raised = true;
+        }
+        if (live) hipLaunchKernelGGL((window_kernel_ml<TARGET_LINREG_SSE, 10, 16, true, true>), grid, wg, dyn, h->stream, P);
+        else hipLaunchKernelGGL((window_kernel_ml<TARGET_LINREG_SSE, 10, 16, true, false>), grid, wg, dyn, h->stream, P);
     } else if (h->split_kind == 2) {
         const dim3 grid((unsigned)blocks), wg(64);
         if (live) hipLaunchKernelGGL((window_kernel_ml<TARGET_MVNORMAL, 20, 16, true, true>), grid, wg, 0, h->stream, P);
@@ -681,7 +700,7 @@ static int32_t pc_prepare(demcz_handle* h, WindowParams& P, int64_t cur_rows, in
         dc.valid = true; dc.g_first = P.g_first; dc.M = P.M; dc.ngen = P.ngen; dc.rows = cur_rows; dc.boff = cur_boff;
     }
     P.rec_in = h->d_rec[cur];
-    const int per_wg = (h->split_kind == 1) ? PC_CONSUMER_CHAINS : 64 / h->split_lanes;       // chains per consumer workgroup
+    const int per_wg = h->split_per_wg;
     P.consumer_blocks = (int32_t)((P.N + per_wg - 1) / per_wg);
     P.rec_out = h->d_rec[cur ^ 1];
     P.next_g_first = next_g; P.next_ngen = (int32_t)std::max<int64_t>(next_ngen, 0); P.next_M = next_M;
@@ -897,6 +916,10 @@ static int64_t live_wg_capacity(demcz_handle* h)
         case 20: f = reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 20, 16, true, true>); break;
         }
         if (!f || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 64, 0) != hipSuccess) per_cu = 0;
+    } else if (h->split_kind == 2 && h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE) {
+        const size_t dyn = ml_dynamic_lds<TARGET_LINREG_SSE, 10, 16>(h->cfg.nobs);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_ml<TARGET_LINREG_SSE, 10, 16, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&window_kernel_ml<TARGET_LINREG_SSE, 10, 16, true, true>), 64 * ML_LR_WAVES, dyn) != hipSuccess) per_cu = 0;
     } else if (h->split_kind == 2) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&window_kernel_ml<TARGET_MVNORMAL, 20, 16, true, true>), 64, 0) != hipSuccess) per_cu = 0;
     } else if (h->cfg.target_kind == DEMCZ_TARGET_ISO_QUAD) {
@@ -926,7 +949,7 @@ static int64_t live_span(demcz_handle* h)
     if (h->lanes != DEMCZ_LAYOUT_SPLIT || h->comm || h->lag > 0 || h->external_append) return 0;
     static const bool disabled = (getenv("DEMCZ_NO_LIVE") != nullptr);     // safety valve: one launch per K-window
     if (disabled) return 0;
-    const int per_wg = (h->split_kind == 1) ? PC_CONSUMER_CHAINS : 64 / h->split_lanes;
+    const int per_wg = h->split_per_wg;
     if ((h->cfg.N + per_wg - 1) / per_wg > live_wg_capacity(h)) return 0;
     const int64_t per_gen = rec_fields(h) * h->cfg.N * (int64_t)sizeof(double);
     const int64_t span = (int64_t)(64ll << 20) / per_gen;        // 64 MiB of records per buffer (C2: 1170 generations)

@@ -51,16 +51,17 @@ __host__ __device__ constexpr size_t ml_dynamic_lds(int64_t nobs)
 // producer half (draw records for the next launch), the others read this launch's records instead of
 // drawing: what is left per generation is the state-dependent part.  LIVE: the launch runs through K
 // boundaries and takes appended rows from other waves through the archive itself (sentinel + sc1).
-// Used where the eight-replicated-lanes consumer does not fit (d = 20: 210 whitening coefficients).
+// Used where the eight-replicated-lanes consumer does not fit (d = 20: 210 whitening coefficients) and for the
+// regression target.
 template <int TARGET, int D, int L, bool REC = false, bool LIVE = false>
 __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(const WindowParams P)
 {
     constexpr bool LR = (TARGET == TARGET_LINREG_SSE);
-    static_assert(!REC || !LR, "the split form is for the MvNormal / isotropic targets");
     static_assert(!LIVE || REC, "LIVE launches are a property of the split form");
     if constexpr (REC) {
-        if ((int64_t)blockIdx.x >= P.consumer_blocks) {
-            pc_produce<D>(P, (int64_t)blockIdx.x - P.consumer_blocks);
+        if ((int64_t)blockIdx.x >= P.consumer_blocks) {       // every wave of a producer workgroup is one 64-lane producer unit
+            pc_produce<D>(P, ((int64_t)blockIdx.x - P.consumer_blocks) * ml_waves<TARGET>() + (int64_t)(threadIdx.x >> 6),
+                          (int)(threadIdx.x & 63));
             return;
         }
     }

@@ -40,14 +40,16 @@ __device__ __forceinline__ void wave_lds_handoff()
 // consumer lane fetches a chunk of ten with five 16-byte loads off one address.
 __device__ __forceinline__ size_t rec_index(int64_t N, int64_t GS, int g, int f, int64_t c) { return ((size_t)f * (size_t)N + (size_t)c) * (size_t)GS + (size_t)g; }
 
+// (`lane`: position in the 64-wide producer unit -- a workgroup of one wave, or one wave of a larger workgroup)
 template <int D>
-__device__ __forceinline__ void pc_produce(const WindowParams& P, int64_t pb)
+__device__ __forceinline__ void pc_produce(const WindowParams& P, int64_t pb, int lane = -1)
 {
+    if (lane < 0) lane = (int)threadIdx.x;
     constexpr int NPAIRS = (D == 1) ? 1 : (D + 1) / 2;
     constexpr int S = NPAIRS + 2;                          // Philox blocks of a generation = producer roles
     const int64_t nbc = (P.N + 63) / 64;                   // workgroups per (generation, role) plane
     const int64_t plane = pb / nbc;                        // wave-uniform
-    const int64_t c = (pb % nbc) * 64 + threadIdx.x;
+    const int64_t c = (pb % nbc) * 64 + lane;
     const int role = (int)(plane % S), gi = (int)(plane / S);
     if (gi >= P.next_ngen || c >= P.N) return;
     philox_blocks rng;
