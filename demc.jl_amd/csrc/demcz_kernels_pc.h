@@ -56,7 +56,8 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
         DEMCZ_STAMP(P, 7);
         return;
     }
-    __shared__ __attribute__((aligned(16))) double sdelta[G * CH * DP];
+    constexpr int DPL = DP + 2;                            // LDS row of a (chain, generation): DP increments, log u, pad
+    __shared__ __attribute__((aligned(16))) double sdelta[G * CH * DPL];
     const int lane = threadIdx.x, r = lane % L, gq = lane / L;
     // groups beyond the last chain shadow chain N-1 and store nothing
     const int64_t c_own = (int64_t)blockIdx.x * G + gq;
@@ -161,185 +162,225 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
     // the append then sits between chunks, not inside the generation code, and in a LIVE launch the
     // generation after a boundary draws from rows that are only being written while this chunk computes
     // (K = 1: one generation per chunk).
+    //
+    // Software pipeline over chunks: the loads of chunk k+1 (archive rows, normals, log u; its row indices
+    // were fetched a chunk before) are issued right after chunk k's increments have gone to LDS and fly
+    // during chunk k's generations; chunk k+1 begins with the data already in registers.  The generation code
+    // reads its increments from LDS one generation ahead instead of holding the whole chunk in registers --
+    // that is what frees the registers the prefetch lives in.
     if constexpr (LIVE) {       // an earlier launch of the run already failed: do not wait again
         if (__hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     }
-    int len = 0;
-    [[maybe_unused]] bool gave_up = false;      // LIVE: a row never arrived; the wave stops (results are void, the host reports it)
     [[maybe_unused]] const int stamp_g0 = (P.ngen > 5 * CH) ? 5 * CH : 0;      // diagnostic build: the chunk that is timed
+    // in flight for the chunk to come: this lane's generations u = rd * 8 + r
+    double za[ROUNDS][2 * HW], zb[ROUNDS][2 * HW], zt[ROUNDS][D], lgv[ROUNDS];
+    uint32_t o1[ROUNDS], o2[ROUNDS];
+    auto chunk_len = [&](int g0, int tb) {
+        int n = (P.ngen - g0 < CH) ? P.ngen - g0 : CH;
+        return (tb < n) ? tb : n;
+    };
+    auto issue = [&](int g0, int len) {          // loads of the chunk [g0, g0 + len); consumes ixn, refills it for the chunk after
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            const int u = rd * L + r;
+            // slots past the end of the chunk read row 0: their own rows may not exist yet (LIVE: never wait for them)
+            const uint64_t ii = (uint64_t)__double_as_longlong(ixn[rd]);
+            o1[rd] = (u < len) ? (uint32_t)ii << ZSHIFT : 0u;
+            o2[rd] = (u < len) ? (uint32_t)(ii >> 32) << ZSHIFT : 0u;
+#pragma unroll
+            for (int j = 0; j < HW; ++j) {
+                row_piece(o1[rd] + 16u * j, za[rd][2 * j], za[rd][2 * j + 1]);
+                row_piece(o2[rd] + 16u * j, zb[rd][2 * j], zb[rd][2 * j + 1]);
+            }
+            const int gu = g0 + ((u < len) ? u : len - 1);
+#pragma unroll
+            for (int p = 0; p < ((D == 1) ? 1 : D); ++p) zt[rd][p] = rec_n[p][gu];
+            lgv[rd] = rec_lg[gu];
+        }
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) ixn[rd] = rec_ix[g0 + len + rd * L + r];      // (the buffers are padded for the overshoot)
+    };
+    // PIPE: the prefetch across chunks.  Not in LIVE launches: a K-window's time there is set by the hand-off of the
+    // appended rows (which an early read cannot see), and they keep the chunk's LDS rows in registers instead.
+    constexpr bool PIPE = !LIVE;
+    int len = chunk_len(0, to_b);
+    if constexpr (PIPE) issue(0, len);
     for (int g0 = 0; g0 < P.ngen; g0 += len) {
         if (g0 == stamp_g0) DEMCZ_STAMP(P, 5);
 #ifdef DEMCZ_STAMPS
         if (P.stamps && threadIdx.x == 0) P.stamps[(size_t)blockIdx.x * 8 + 6] = 1000000ull + (unsigned long long)g0;   // progress
 #endif
-        len = (P.ngen - g0 < CH) ? P.ngen - g0 : CH;
-        len = (to_b < len) ? to_b : len;
-        double lgu[CHP];
-        [[maybe_unused]] double tmpr[CH];
-        {
-            fetch_chunk(rec_lg + g0, lgu);
-            if constexpr (TEMPER) {
+        if (g0 > 0) len = chunk_len(g0, to_b);
+        if constexpr (!PIPE) {
+            issue(g0, len);
+            __builtin_amdgcn_sched_barrier(0);      // nothing that waits for a record in front of the gather's issue
+        }
+        if constexpr (LIVE) {
+            // rows another wave has not published yet read as the sentinel: ask again.  Cheap filter first:
+            // the sentinel's high word is that of a negative NaN, above every finite value's, -inf's and
+            // the canonical NaN's -- a max per value instead of a 64-bit compare
+            uint32_t hmax = 0u;
 #pragma unroll
-                for (int u = 0; u < CH; ++u) tmpr[u] = P.temperature[g0 + ((u < len) ? u : len - 1)];
-            }
-            double za[ROUNDS][2 * HW], zb[ROUNDS][2 * HW], zt[ROUNDS][D];
-            uint32_t o1[ROUNDS], o2[ROUNDS];
+            for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
-            for (int rd = 0; rd < ROUNDS; ++rd) {
-                const int u = rd * L + r;
-                // slots past the end of the chunk read row 0: their own rows may not exist yet (LIVE: never wait for them)
-                const uint64_t ii = (uint64_t)__double_as_longlong(ixn[rd]);
-                o1[rd] = (u < len) ? (uint32_t)ii << ZSHIFT : 0u;
-                o2[rd] = (u < len) ? (uint32_t)(ii >> 32) << ZSHIFT : 0u;
-#pragma unroll
-                for (int j = 0; j < HW; ++j) {
-                    row_piece(o1[rd] + 16u * j, za[rd][2 * j], za[rd][2 * j + 1]);
-                    row_piece(o2[rd] + 16u * j, zb[rd][2 * j], zb[rd][2 * j + 1]);
+                for (int p = 0; p < D; ++p) {
+                    const uint32_t ha = (uint32_t)((uint64_t)__double_as_longlong(za[rd][p]) >> 32);
+                    const uint32_t hb = (uint32_t)((uint64_t)__double_as_longlong(zb[rd][p]) >> 32);
+                    hmax = max(hmax, max(ha, hb));
                 }
-                const int gu = g0 + ((u < len) ? u : len - 1);
+            bool bad = false;
+            if (__builtin_amdgcn_ballot_w64(hmax >= (uint32_t)(LIVE_SENTINEL >> 32)) != 0ull) {
 #pragma unroll
-                for (int p = 0; p < ((D == 1) ? 1 : D); ++p) zt[rd][p] = rec_n[p][gu];
+                for (int rd = 0; rd < ROUNDS; ++rd)
+#pragma unroll
+                    for (int p = 0; p < D; ++p) bad |= is_sentinel(za[rd][p]) | is_sentinel(zb[rd][p]);
             }
-            // next chunk's indices (it starts at g0 + len; the buffers are padded for the overshoot)
-#pragma unroll
-            for (int rd = 0; rd < ROUNDS; ++rd) ixn[rd] = rec_ix[g0 + len + rd * L + r];
-            // nothing that waits for a record may be scheduled in front of the gather's issue
-            __builtin_amdgcn_sched_barrier(0);
-            if (g0 == stamp_g0) DEMCZ_STAMP(P, 2);
-            if constexpr (LIVE) {
-                // rows another wave has not published yet read as the sentinel: ask again.  Cheap filter first:
-                // the sentinel's high word is that of a negative NaN, above every finite value's, -inf's and
-                // the canonical NaN's -- a max per value instead of a 64-bit compare
-                uint32_t hmax = 0u;
+            int spins = 0;
+            while (__builtin_amdgcn_ballot_w64(bad) != 0ull) {           // wave-uniform
+                unsigned waiting_row = 0;
 #pragma unroll
                 for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
                     for (int p = 0; p < D; ++p) {
-                        const uint32_t ha = (uint32_t)((uint64_t)__double_as_longlong(za[rd][p]) >> 32);
-                        const uint32_t hb = (uint32_t)((uint64_t)__double_as_longlong(zb[rd][p]) >> 32);
-                        hmax = max(hmax, max(ha, hb));
+                        if (is_sentinel(za[rd][p])) waiting_row = o1[rd] >> ZSHIFT;
+                        if (is_sentinel(zb[rd][p])) waiting_row = o2[rd] >> ZSHIFT;
                     }
-                bool bad = false;
-                if (__builtin_amdgcn_ballot_w64(hmax >= (uint32_t)(LIVE_SENTINEL >> 32)) != 0ull) {
+                if (live_poll_abandon(P, spins, bad, waiting_row, g0)) return;      // wave-uniform
+                __builtin_amdgcn_s_sleep(1);
+                bad = false;
 #pragma unroll
-                    for (int rd = 0; rd < ROUNDS; ++rd)
+                for (int rd = 0; rd < ROUNDS; ++rd) {
+                    // a row is written by one wave, 8 bytes at a time: re-read whole rows that still hold a sentinel
+                    bool ba = false, bb = false;
 #pragma unroll
-                        for (int p = 0; p < D; ++p) bad |= is_sentinel(za[rd][p]) | is_sentinel(zb[rd][p]);
-                }
-                int spins = 0;
-                while (__builtin_amdgcn_ballot_w64(bad) != 0ull) {           // wave-uniform
-                    unsigned waiting_row = 0;
+                    for (int p = 0; p < D; ++p) { ba |= is_sentinel(za[rd][p]); bb |= is_sentinel(zb[rd][p]); }
+                    if (ba) {
 #pragma unroll
-                    for (int rd = 0; rd < ROUNDS; ++rd)
-#pragma unroll
-                        for (int p = 0; p < D; ++p) {
-                            if (is_sentinel(za[rd][p])) waiting_row = o1[rd] >> ZSHIFT;
-                            if (is_sentinel(zb[rd][p])) waiting_row = o2[rd] >> ZSHIFT;
-                        }
-                    if (live_poll_abandon(P, spins, bad, waiting_row, g0)) { gave_up = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    bad = false;
-#pragma unroll
-                    for (int rd = 0; rd < ROUNDS; ++rd) {
-                        // a row is written by one wave, 8 bytes at a time: re-read whole rows that still hold a sentinel
-                        bool ba = false, bb = false;
-#pragma unroll
-                        for (int p = 0; p < D; ++p) { ba |= is_sentinel(za[rd][p]); bb |= is_sentinel(zb[rd][p]); }
-                        if (ba) {
-#pragma unroll
-                            for (int j = 0; j < HW; ++j) row_piece(o1[rd] + 16u * j, za[rd][2 * j], za[rd][2 * j + 1]);
-                        }
-                        if (bb) {
-#pragma unroll
-                            for (int j = 0; j < HW; ++j) row_piece(o2[rd] + 16u * j, zb[rd][2 * j], zb[rd][2 * j + 1]);
-                        }
-#pragma unroll
-                        for (int p = 0; p < D; ++p) bad |= is_sentinel(za[rd][p]) | is_sentinel(zb[rd][p]);
+                        for (int j = 0; j < HW; ++j) row_piece(o1[rd] + 16u * j, za[rd][2 * j], za[rd][2 * j + 1]);
                     }
-                }
-            }
+                    if (bb) {
 #pragma unroll
-            for (int rd = 0; rd < ROUNDS; ++rd) {
-                const int u = rd * L + r;
-                double dv[DP];
-#pragma unroll
-                for (int p = 0; p < DP; ++p) {
-                    if (p < D) {
-                        const double diff = za[rd][p] - zb[rd][p];
-                        const double t1 = scale * diff;
-                        const double t2 = epsall[p] * zt[rd][(D == 1) ? 0 : p];
-                        dv[p] = t1 + t2;
-                    } else {
-                        dv[p] = 0.0;
+                        for (int j = 0; j < HW; ++j) row_piece(o2[rd] + 16u * j, zb[rd][2 * j], zb[rd][2 * j + 1]);
                     }
-                }
-                if (u < CH) {
 #pragma unroll
-                    for (int j = 0; j < DP / 2; ++j)
-                        reinterpret_cast<double2*>(sdelta + (gq * CH + u) * DP)[j] = make_double2(dv[2 * j], dv[2 * j + 1]);
+                    for (int p = 0; p < D; ++p) bad |= is_sentinel(za[rd][p]) | is_sentinel(zb[rd][p]);
                 }
             }
         }
-        if constexpr (LIVE) { if (gave_up) return; }       // wave-uniform
+        // this lane's generations: increments and log u into the LDS rows of the chain
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            const int u = rd * L + r;
+            double dv[DPL];
+#pragma unroll
+            for (int p = 0; p < DP; ++p) {
+                if (p < D) {
+                    const double diff = za[rd][p] - zb[rd][p];
+                    const double t1 = scale * diff;
+                    const double t2 = epsall[p] * zt[rd][(D == 1) ? 0 : p];
+                    dv[p] = t1 + t2;
+                } else {
+                    dv[p] = 0.0;
+                }
+            }
+            dv[DP] = lgv[rd];
+            dv[DP + 1] = 0.0;
+            if (u < CH) {
+#pragma unroll
+                for (int j = 0; j < DPL / 2; ++j)
+                    reinterpret_cast<double2*>(sdelta + (gq * CH + u) * DPL)[j] = make_double2(dv[2 * j], dv[2 * j + 1]);
+            }
+        }
         if (g0 == stamp_g0) DEMCZ_STAMP(P, 3);
         wave_lds_handoff();
-        // the whole chunk's increments into registers first: the LDS latency is paid once, not inside
-        // every generation's dependent chain
-        double dl[CH][DP], dmine[CH][NP];
+        // the chunk after this one: its loads fly during this chunk's generations
+        {
+            const int tb_n = (to_b - len == 0) ? P.K : to_b - len;
+            const int g0n = g0 + len;
+            if constexpr (PIPE) { if (g0n < P.ngen) issue(g0n, chunk_len(g0n, tb_n)); }
+            __builtin_amdgcn_sched_barrier(0);      // the generation code below must not be scheduled in front of the issue
+        }
+        if (g0 == stamp_g0) DEMCZ_STAMP(P, 2);
+        // generations of the chunk: the LDS row of generation u + 1 is read while generation u computes
+        [[maybe_unused]] double tmpr[CH];
+        if constexpr (TEMPER) {
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {
+            for (int u = 0; u < CH; ++u) tmpr[u] = P.temperature[g0 + ((u < len) ? u : len - 1)];
+        }
+        auto read_row = [&](int u, double (&dd)[DPL], double (&mm)[NP]) {
+            const double* row = sdelta + (gq * CH + u) * DPL;
 #pragma unroll
-            for (int j = 0; j < DP / 2; ++j) {
-                const double2 t = reinterpret_cast<const double2*>(sdelta + (gq * CH + u) * DP)[j];
-                dl[u][2 * j] = t.x;
-                dl[u][2 * j + 1] = t.y;
+            for (int j = 0; j < DPL / 2; ++j) {
+                const double2 t = reinterpret_cast<const double2*>(row)[j];
+                dd[2 * j] = t.x;
+                dd[2 * j + 1] = t.y;
             }
 #pragma unroll
-            for (int k = 0; k < NP; ++k) dmine[u][k] = sdelta[(gq * CH + u) * DP + pk[k]];      // this lane's own element(s)
-        }
+            for (int k = 0; k < NP; ++k) mm[k] = row[pk[k]];              // this lane's own element(s)
+        };
+        // one generation from its LDS row (increments, log u) and this lane's own increment(s)
+        auto generation = [&](int u, const double (&dd)[DPL], const double (&mm)[NP]) {
+            double xp[D];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            if (u < len) {       // wave-uniform
-                double xp[D];
+            for (int p = 0; p < D; ++p) xp[p] = x[p] + dd[p];
+            double lpp;
+            if constexpr (TARGET == TARGET_MVNORMAL) {
+                double q = 0.0;
 #pragma unroll
-                for (int p = 0; p < D; ++p) xp[p] = x[p] + dl[u][p];
-                double lpp;
-                if constexpr (TARGET == TARGET_MVNORMAL) {
-                    double q = 0.0;
+                for (int i = 0; i < D; ++i) {
+                    double acc = Wc[(i * (i + 1)) / 2] * (xp[0] - muc[0]);
 #pragma unroll
-                    for (int i = 0; i < D; ++i) {
-                        double acc = Wc[(i * (i + 1)) / 2] * (xp[0] - muc[0]);
-#pragma unroll
-                        for (int j = 1; j <= i; ++j) acc = fma(Wc[(i * (i + 1)) / 2 + j], xp[j] - muc[j], acc);
-                        q = (i == 0) ? acc * acc : fma(acc, acc, q);
-                    }
-                    lpp = fma(-0.5, q, c0c);
-                } else {
-                    double q = 0.0;
-#pragma unroll
-                    for (int i = 0; i < D; ++i) {
-                        const double rr = xp[i] - muc[i];
-                        q = (i == 0) ? rr * rr : fma(rr, rr, q);
-                    }
-                    lpp = -q;
+                    for (int j = 1; j <= i; ++j) acc = fma(Wc[(i * (i + 1)) / 2 + j], xp[j] - muc[j], acc);
+                    q = (i == 0) ? acc * acc : fma(acc, acc, q);
                 }
-                double dlt = lpp - lp;
-                if constexpr (TEMPER) dlt = dlt / tmpr[u];
-                const bool acc = lgu[u] < dlt;
+                lpp = fma(-0.5, q, c0c);
+            } else {
+                double q = 0.0;
 #pragma unroll
-                for (int p = 0; p < D; ++p) x[p] = acc ? xp[p] : x[p];
-                lp = acc ? lpp : lp;
-#pragma unroll
-                for (int k = 0; k < NP; ++k) {
-                    const double ownp = own[k] + dmine[u][k];
-                    own[k] = acc ? ownp : own[k];
-                    const double val = (LP_MERGED && k == 0 && lp_lane) ? lp : own[k];
-                    if (son[k]) *sptr[k] = val;
-                    sptr[k] += sstride[k];       // next generation's slab: a stride, no per-lane multiply
+                for (int i = 0; i < D; ++i) {
+                    const double rr = xp[i] - muc[i];
+                    q = (i == 0) ? rr * rr : fma(rr, rr, q);
                 }
-                if constexpr (!LP_MERGED) {
-                    if (hist_on && lp_lane) *lobj = lp;
-                    lobj += P.N;
+                lpp = -q;
+            }
+            double dlt = lpp - lp;
+            if constexpr (TEMPER) dlt = dlt / tmpr[u];
+            const bool acc = dd[DP] < dlt;
+#pragma unroll
+            for (int p = 0; p < D; ++p) x[p] = acc ? xp[p] : x[p];
+            lp = acc ? lpp : lp;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const double ownp = own[k] + mm[k];
+                own[k] = acc ? ownp : own[k];
+                const double val = (LP_MERGED && k == 0 && lp_lane) ? lp : own[k];
+                if (son[k]) *sptr[k] = val;
+                sptr[k] += sstride[k];       // next generation's slab: a stride, no per-lane multiply
+            }
+            if constexpr (!LP_MERGED) {
+                if (hist_on && lp_lane) *lobj = lp;
+                lobj += P.N;
+            }
+        };
+        if constexpr (!PIPE) {
+            double dall[CH][DPL], mall[CH][NP];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) read_row(u, dall[u], mall[u]);
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if (u < len) generation(u, dall[u], mall[u]);       // wave-uniform
+        } else {
+            double dcur[DPL], dnxt[DPL], mcur[NP], mnxt[NP];
+            read_row(0, dcur, mcur);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                if (u < len) {       // wave-uniform
+                    if (u + 1 < CH) read_row(u + 1, dnxt, mnxt);
+                    generation(u, dcur, mcur);
+#pragma unroll
+                    for (int p = 0; p < DPL; ++p) dcur[p] = dnxt[p];
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) mcur[k] = mnxt[k];
                 }
             }
         }
