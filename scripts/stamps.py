@@ -36,7 +36,7 @@ e.synchronize()
 wall_us = (time.perf_counter() - t0) * 1e6
 lib = _lib.load()
 ncons = (N + 7) // 8
-nprod = ((N + 63) // 64) * 3 * (K * max(lag, 1))
+nprod = ((N + 63) // 64) * 4 * (K * max(lag, 1))      # (rough: producer workgroups of the launch's successor)
 nwg = ncons + nprod
 buf = np.zeros((nwg, 8), dtype=np.uint64)
 lib.demcz_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
