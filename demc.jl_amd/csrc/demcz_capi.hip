@@ -70,6 +70,9 @@ struct demcz_handle {
     bool proposal_pending = false;
     bool gen_open = false;
     // split layout: draw records, double-buffered (this launch reads one, its producer half fills the other)
+    double* d_spec_X = nullptr;       // demcz_run_checked with a threshold: state before the slab enqueued ahead of a decision
+    double* d_spec_lp = nullptr;
+    hipEvent_t spec_ev = nullptr;
     double* pinned_rhat = nullptr;    // demcz_run_checked: pinned host slots the checks' results are copied to
     int64_t pinned_cap = 0;
     bool timing = false;              // demcz_set_kernel_timing: events around every window-kernel launch
@@ -183,6 +186,9 @@ static void free_all(demcz_handle* h)
     if (h->d_stage) (void)hipHostFree(h->d_stage);
     for (auto& pr : h->timed) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (h->pinned_rhat) (void)hipHostFree(h->pinned_rhat);
+    if (h->d_spec_X) (void)hipFree(h->d_spec_X);
+    if (h->d_spec_lp) (void)hipFree(h->d_spec_lp);
+    if (h->spec_ev) (void)hipEventDestroy(h->spec_ev);
     if (h->comm) (void)ncclCommDestroy(h->comm);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
 }
@@ -1704,6 +1710,9 @@ extern "C" int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_
     if (max_checks * d > h->pinned_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->pinned_rhat) (void)hipHostFree(h->pinned_rhat);
+    if (h->d_spec_X) (void)hipFree(h->d_spec_X);
+    if (h->d_spec_lp) (void)hipFree(h->d_spec_lp);
+    if (h->spec_ev) (void)hipEventDestroy(h->spec_ev);
         h->pinned_rhat = nullptr; h->pinned_cap = 0;
         HIPCHK(h, hipHostMalloc((void**)&h->pinned_rhat, (size_t)max_checks * d * sizeof(double), hipHostMallocDefault));
         h->pinned_cap = max_checks * d;
@@ -1715,9 +1724,22 @@ extern "C" int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_
         return mx;
     };
     int32_t rc = DEMCZ_OK;
+    // With a threshold the decision needs the statistic on the host.  Where the run can be rolled back cheaply (one GPU,
+    // immediate visibility, appends owned by the library, no temperature upload per slab) the next slab is enqueued
+    // BEFORE waiting for it, so the GPU does not idle over the host's round trip; a stop then discards that slab:
+    // X, log_obj and the archive size go back to what they were, the rows it appended become unwritten again.
+    const bool speculate = !monitor && !h->comm && h->lag == 0 && !h->external_append && !temperature;
+    const int64_t N = h->cfg.N;
+    if (speculate) {
+        if (!h->d_spec_X) HIPCHK(h, hipMalloc((void**)&h->d_spec_X, (size_t)N * d * sizeof(double)));
+        if (!h->d_spec_lp) HIPCHK(h, hipMalloc((void**)&h->d_spec_lp, (size_t)N * sizeof(double)));
+        if (!h->spec_ev) HIPCHK(h, hipEventCreateWithFlags(&h->spec_ev, hipEventDisableTiming));
+    }
+    bool ahead = false;                 // the slab starting at g has already been enqueued
     while (g <= g_to && rc == DEMCZ_OK) {
         const int64_t nxt = std::min(g_to, ((g - 1) / every + 1) * every);
-        rc = demcz_run(h, g, nxt, gamma, temperature ? temperature + (g - g_from) : nullptr);
+        if (!ahead) rc = demcz_run(h, g, nxt, gamma, temperature ? temperature + (g - g_from) : nullptr);
+        ahead = false;
         if (rc) break;
         if (nxt % every == 0 && nxt - every >= h->g0) {          // demcz.jl:39-41
             double* slot = pinned + (size_t)checks * d;
@@ -1725,9 +1747,44 @@ extern "C" int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_
             if (rc) break;
             ++checks;
             if (!monitor) {
-                if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: synchronise failed"); break; }
+                int64_t M_before = 0;
+                if (speculate && nxt < g_to) {
+                    if (hipEventRecord(h->spec_ev, h->stream) != hipSuccess) { rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: event failed"); break; }
+                    if (hipMemcpyAsync(h->d_spec_X, h->dX, (size_t)N * d * sizeof(double), hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
+                        hipMemcpyAsync(h->d_spec_lp, h->dlp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, h->stream) != hipSuccess) {
+                        rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: snapshot failed");
+                        break;
+                    }
+                    M_before = h->M_app;
+                    const int64_t nn = std::min(g_to, (nxt / every + 1) * every);
+                    rc = demcz_run(h, nxt + 1, nn, gamma, nullptr);
+                    if (rc) break;
+                    ahead = true;
+                    if (hipEventSynchronize(h->spec_ev) != hipSuccess) { rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: synchronise failed"); break; }
+                } else if (hipStreamSynchronize(h->stream) != hipSuccess) {
+                    rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: synchronise failed");
+                    break;
+                }
                 if (max_of(slot) < threshold) {                  // demcz.jl:43
                     if (g_stop) *g_stop = nxt;
+                    if (ahead) {        // discard the slab that ran ahead
+                        if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: synchronise failed"); break; }
+                        rc = check_live_err(h);
+                        if (rc) break;
+                        if (hipMemcpyAsync(h->dX, h->d_spec_X, (size_t)N * d * sizeof(double), hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
+                            hipMemcpyAsync(h->dlp, h->d_spec_lp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, h->stream) != hipSuccess) {
+                            rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: restore failed");
+                            break;
+                        }
+                        const size_t rest = (size_t)(h->M_app - M_before) * (size_t)h->ZS;
+                        if (rest > 0)
+                            hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, h->stream,
+                                               reinterpret_cast<unsigned long long*>(h->dZ + (size_t)M_before * h->ZS), rest, LIVE_SENTINEL);
+                        h->M_app = M_before;
+                        h->M = M_before;
+                        h->g_done = nxt;
+                        h->rec_desc[0].valid = h->rec_desc[1].valid = false;
+                    }
                     break;
                 }
             }

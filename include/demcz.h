@@ -224,7 +224,8 @@ int32_t demcz_get_info(const demcz_handle* h, int64_t* M, int64_t* launches_wind
  * (Rhat_gelman, utils.jl:2-20; demcz.jl:41).  The maximum over parameters of the i-th check goes to
  * rhat_max[i] (i < n_max; may be NULL), the whole vector of the last check to rhat_last[d] (may be NULL).
  * threshold > 0: returns as soon as a check's maximum is below it, with *g_stop = that generation
- * (demcz.jl:43-52; nothing after it has run); otherwise *g_stop = g_to.  *n_checks = checks made.
+ * (demcz.jl:43-52; the state is as if nothing after it had run -- the library may run the next slab ahead of the
+ * decision and discards it); otherwise *g_stop = g_to.  *n_checks = checks made.
  * Needs a history window (Gcap) that holds the generations of the call.  In a sharded run every rank
  * makes the same call; the decision is the same on all of them.                                      */
 int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_to, double gamma, const double* temperature,

@@ -498,7 +498,19 @@ def test_run_checked_is_the_driver_loop(demc, oracle):
     g_stop, mx_c, _ = c.run_checked(1, G, 2.38, every, thr)
     k = int(np.argmax(mx < thr))
     assert g_stop == (k + 1) * every and len(mx_c) == k + 1 and c.M == M0 + N * (g_stop // 10)
-    for e in (a, b, c):
+    # (the library ran the slab after the stop ahead of the decision and discarded it:) the state is that of a run
+    # that ended at g_stop, and the run continues from it like any other
+    d2 = engine()
+    d2.run(1, g_stop, 2.38)
+    for x, y in zip(c.get_state(), d2.get_state()):
+        assert np.array_equal(x, y)
+    if g_stop + 37 <= G:
+        c.run(g_stop + 1, g_stop + 37, 2.38)
+        d2.run(g_stop + 1, g_stop + 37, 2.38)
+        for x, y in zip(c.get_state(), d2.get_state()):
+            assert np.array_equal(x, y)
+        assert np.array_equal(c.get_history(1, g_stop + 37)[0], d2.get_history(1, g_stop + 37)[0])
+    for e in (a, b, c, d2):
         e.close()
     # the sampler's autostop path goes through it and returns what the reference's loop would
     opts = demc.demcopt(d, N=N, K=10, Ngeneration=G, eps_scale=w["eps_scale"], verbose=False, autostop="Rhat",
