@@ -244,7 +244,7 @@ def main():
                                             for n, g in ((16384, 400), (131072, 200), (1048576, 100))]
             except Exception as e:
                 out["chain_count_sweep"] = f"failed: {e}"
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # (the contract: rank 0 at N = 1 only)
             try:
                 out["cpu_baseline"] = cpu_baseline(demc.workloads.mvnormal_problem(d, n_loc), n_loc, d, K, seed, 1.0e7)
             except Exception as e:   # the baseline is reporting only; never fail the bench on it
