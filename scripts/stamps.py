@@ -47,10 +47,10 @@ t00 = s[:, 0].min()
 c = s[:ncons]
 print(f"stamps of the last launch (K={K}, lag={lag}); shader-clock ticks; consumer workgroups: {ncons}, producer: {nprod}")
 print(f"entry skew over all workgroups: {s[:,0].max() - t00} ticks; consumers enter at {np.mean(c[:,0]-t00):.0f} (mean) / {np.max(c[:,0]-t00)} (max)")
-names = {1: "row indices drawn (Philox + LDS write)", 2: "records and gathers issued", 3: "all loads back, increments in LDS",
-         4: "first chunk of generations done", 7: "exit"}
+names = {3: "loads back (hand-off waits included), increments in LDS", 2: "next chunk's loads issued (launches that prefetch)",
+         4: "generations of the chunk done", 7: "exit"}
 print(f"  timed chunk starts at +{np.mean(c[:,5]-c[:,0]):.0f} (mean); chunk-relative below, exit launch-relative")
-for i in (1, 2, 3, 4, 7):
+for i in (3, 2, 4, 7):
     dt = c[:, i] - (c[:, 0] if i == 7 else c[:, 5])
     print(f"  consumer +{np.mean(dt):8.0f} mean  {np.min(dt):6d} min {np.max(dt):6d} max   {names[i]}")
 p = s[ncons:nwg]
