@@ -48,7 +48,7 @@ def measured_traffic(n_loc, d, lanes):
     name = f"window_kernel_pc8<0, {d}, true, false>"      # the LIVE launches (one per slab between R-hat checks)
     for k, v in json.loads(f.read_text())["kernels"].items():
         if name in k:
-            return v.get("bytes_per_launch_raw")
+            return v.get("bytes_per_launch_raw"), v.get("bytes_per_launch_fetch_x2")
     return None
 
 
@@ -222,6 +222,10 @@ def main():
         bytes_per_launch = B * n_loc * gens_per_launch
         avg_launch_s = (ev_ms / 1e3) / max(launches, 1)
         achieved = bytes_per_launch / avg_launch_s / 1e9
+        # PMC bytes per launch (committed rocprofv3 passes): `traffic` = FETCH_SIZE + WRITE_SIZE as counted -- calibrated
+        # exact for this kernel's row gathers; its coalesced record reads (a third of the fetch) are tallied at half on
+        # gfx950 (MI355X_MICROARCH.md, HBM) -- `traffic_fetch_x2` = the upper bound with every fetched byte doubled
+        traffic = (measured_traffic(n_loc, d, eng.info()["lanes_per_chain"]) if K == 10 else None) or (None, None)
         out = {
             "metric": "chain-updates/sec (N x gens/s) + gens-to-Rhat<1.05, MvNormal d=5 N=1024",
             "value": N * S / dt, "unit": "chain-updates/s", "n_gpus": world, "steps": S, "warmup": W,
@@ -233,7 +237,7 @@ def main():
                        "parallelism": f"chains sharded x{world}, Z replicated" if world > 1 else "single GPU"},
             "gens_to_rhat_1p05": gens_to_rhat, "rhat_trace": rhat_trace[-12:], "accept_ratio_mean": acc,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": measured_traffic(n_loc, d, eng.info()["lanes_per_chain"]) if K == 10 else None, "kernel": "demcz::window_kernel_pc8<MVNORMAL, 5, LIVE>" if eng.info()["lanes_per_chain"] == 100 else "demcz::window_kernel",
+                         "traffic": traffic[0], "traffic_fetch_x2": traffic[1], "kernel": "demcz::window_kernel_pc8<MVNORMAL, 5, LIVE>" if eng.info()["lanes_per_chain"] == 100 else "demcz::window_kernel",
                          "launches": launches, "generations_per_launch": gens_per_launch,
                          "avg_launch_us": avg_launch_s * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_chain_update": B},
