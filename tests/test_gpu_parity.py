@@ -517,3 +517,77 @@ def test_run_checked_is_the_driver_loop(demc, oracle):
                         autostop_every=every, autostop_Rhat=thr)
     mc, Z = demc.demcz_sample(w["target"], w["Zinit"], opts, seed=4)
     assert mc.chain.shape[2] == (k + 1) * every and Z.shape[0] == M0 + N * ((k + 1) * every // 10)
+
+
+def test_randomised_shapes_against_the_oracle(demc, oracle):
+    """Seeded random shapes through the library's own layout choice (split layouts with in-launch hand-off for the
+    dimensions they are built for): odd chain counts, K from 1 to 15, block structures, calls cut at arbitrary
+    generations -- chain, log_obj and the archive bit for bit."""
+    rng = np.random.default_rng(20240607)
+    for case in range(40):
+        d = int(rng.choice([2, 3, 4, 5, 8, 10, 20, 6, 7]))
+        N = int(rng.integers(1, 200))
+        K = int(rng.integers(1, 16))
+        G = int(rng.integers(5, 130))
+        blocked = d in (5, 6, 10, 20) and rng.random() < 0.3
+        if blocked:
+            cuts = sorted(set(int(c) for c in rng.integers(1, d, size=int(rng.integers(1, 4)))))
+            edges = [0] + cuts + [d]
+            perm = rng.permutation(d) if rng.random() < 0.5 else np.arange(d)
+            blocks = [[int(p) for p in perm[a:b]] for a, b in zip(edges[:-1], edges[1:])]
+        else:
+            blocks = [list(range(d))]
+        w = demc.workloads.mvnormal_problem(d, max(N, 2))
+        M0 = w["Zinit"].shape[0]
+        seed = int(rng.integers(1, 2**31))
+        e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K), Gcap=G, blockindex=blocks, eps_scale=w["eps_scale"], seed=seed,
+                           target=w["target"])
+        e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+        g = 1
+        while g <= G:
+            step = int(min(G - g + 1, rng.integers(1, 60)))
+            e.run(g, g + step - 1, w["gamma"])
+            g += step
+        ch, lo = e.get_history(1, G)
+        X, lp, Z, M = e.get_state()
+        lanes = e.info()["lanes_per_chain"]
+        e.close()
+        ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, blocks, w["eps_scale"], w["gamma"], seed)
+        tag = (case, d, N, K, G, blocks, lanes)
+        assert np.array_equal(ch, ref["chain"]), tag
+        assert np.array_equal(lo, ref["log_obj"]) and np.array_equal(Z, ref["Z"]) and np.array_equal(X, ref["X"]), tag
+
+
+def test_randomised_annealed_targets_against_the_oracle(demc, oracle):
+    """The same for the tempered accept on the isotropic quadratic and the regression SSE (matrix-core residuals,
+    split form), with random temperatures, observation counts that are not multiples of 16, and cut calls."""
+    rng = np.random.default_rng(77)
+    for case in range(16):
+        kind = "iso" if rng.random() < 0.4 else "linreg"
+        N = int(rng.integers(1, 90))
+        K = int(rng.integers(1, 13))
+        G = int(rng.integers(5, 70))
+        d = 10
+        if kind == "iso":
+            w = demc.workloads.iso_quad_problem(d, max(N, 2))
+        else:
+            w = demc.workloads.linreg_problem(d, max(N, 2), nobs=int(rng.integers(3, 150)))
+        M0 = w["Zinit"].shape[0]
+        seed = int(rng.integers(1, 2**31))
+        temps = np.exp(rng.uniform(-6, 1, size=G))
+        e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K), Gcap=G, blockindex=[range(d)], eps_scale=w["eps_scale"], seed=seed,
+                           target=w["target"])
+        e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+        g = 1
+        while g <= G:
+            step = int(min(G - g + 1, rng.integers(1, 40)))
+            e.run(g, g + step - 1, w["gamma"], temps[g - 1:g + step - 1])
+            g += step
+        ch, lo = e.get_history(1, G)
+        X, lp, Z, M = e.get_state()
+        lanes = e.info()["lanes_per_chain"]
+        e.close()
+        ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed, temperature=temps)
+        tag = (case, kind, N, K, G, lanes)
+        assert np.array_equal(ch, ref["chain"]), tag
+        assert np.array_equal(lo, ref["log_obj"]) and np.array_equal(Z, ref["Z"]) and np.array_equal(X, ref["X"]), tag
