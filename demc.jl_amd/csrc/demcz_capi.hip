@@ -70,6 +70,8 @@ struct demcz_handle {
     bool proposal_pending = false;
     bool gen_open = false;
     // split layout: draw records, double-buffered (this launch reads one, its producer half fills the other)
+    hipStream_t diag_stream = nullptr;   // demcz_run_checked, monitoring: the checks run here beside the next slab
+    hipEvent_t diag_ev = nullptr;
     double* d_spec_X = nullptr;       // demcz_run_checked with a threshold: state before the slab enqueued ahead of a decision
     double* d_spec_lp = nullptr;
     hipEvent_t spec_ev = nullptr;
@@ -189,6 +191,8 @@ static void free_all(demcz_handle* h)
     if (h->d_spec_X) (void)hipFree(h->d_spec_X);
     if (h->d_spec_lp) (void)hipFree(h->d_spec_lp);
     if (h->spec_ev) (void)hipEventDestroy(h->spec_ev);
+    if (h->diag_ev) (void)hipEventDestroy(h->diag_ev);
+    if (h->diag_stream) (void)hipStreamDestroy(h->diag_stream);
     if (h->comm) (void)ncclCommDestroy(h->comm);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
 }
@@ -1188,7 +1192,7 @@ extern "C" int32_t demcz_get_changed(demcz_handle* h, int64_t g_from, int64_t g_
 // ---- R-hat ---------------------------------------------------------------------------------------
 struct RhatPlan { int64_t N, w, s0, n, nd; int d, nchunk; double *S1, *S2, *mean_j, *s2_j, *sums; };
 
-static int32_t rhat_prepare(demcz_handle* h, int64_t g_from, int64_t g_to, RhatPlan& r, bool compute)
+static int32_t rhat_prepare(demcz_handle* h, int64_t g_from, int64_t g_to, RhatPlan& r, bool compute, hipStream_t qs = nullptr)
 {
     int32_t rc = check_hist_range(h, g_from, g_to, "demcz_rhat");
     if (rc) return rc;
@@ -1209,8 +1213,9 @@ static int32_t rhat_prepare(demcz_handle* h, int64_t g_from, int64_t g_to, RhatP
     if (compute) {
         const int bs = 256;
         const unsigned gx = (unsigned)((r.nd + bs - 1) / bs);
-        hipLaunchKernelGGL(rhat_moments_kernel, dim3(gx, 2 * r.nchunk), dim3(bs), 0, h->stream, h->dchain, r.N, r.d, r.s0, r.n, r.nchunk, r.S1, r.S2);
-        hipLaunchKernelGGL(rhat_chainstats_kernel, dim3(gx, 2), dim3(bs), 0, h->stream, h->dchain, r.N, r.d, r.s0, r.n, r.nchunk, r.S1, r.S2, r.mean_j, r.s2_j);
+        if (!qs) qs = h->stream;
+        hipLaunchKernelGGL(rhat_moments_kernel, dim3(gx, 2 * r.nchunk), dim3(bs), 0, qs, h->dchain, r.N, r.d, r.s0, r.n, r.nchunk, r.S1, r.S2);
+        hipLaunchKernelGGL(rhat_chainstats_kernel, dim3(gx, 2), dim3(bs), 0, qs, h->dchain, r.N, r.d, r.s0, r.n, r.nchunk, r.S1, r.S2, r.mean_j, r.s2_j);
         HIPCHK(h, hipGetLastError());
     }
     return DEMCZ_OK;
@@ -1239,10 +1244,20 @@ extern "C" int32_t demcz_rhat_partial(demcz_handle* h, int64_t g_from, int64_t g
 
 // Enqueues the R-hat of generations g_from..g_to and the copy of its d values to `out` (host memory; pinned
 // if the caller wants the copy to be asynchronous); does not wait.
-static int32_t rhat_enqueue(demcz_handle* h, int64_t g_from, int64_t g_to, double* out)
+// `side`: unsharded runs only -- the statistic of a finished slab is computed on a second stream, behind an event,
+// beside the next slab's window kernel (which leaves most of the chip idle at small N).
+static int32_t rhat_enqueue(demcz_handle* h, int64_t g_from, int64_t g_to, double* out, bool side = false)
 {
     RhatPlan r;
-    int32_t rc = rhat_prepare(h, g_from, g_to, r, true);
+    hipStream_t qs = h->stream;
+    if (side && !h->comm) {
+        if (!h->diag_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->diag_stream, hipStreamNonBlocking));
+        if (!h->diag_ev) HIPCHK(h, hipEventCreateWithFlags(&h->diag_ev, hipEventDisableTiming));
+        HIPCHK(h, hipEventRecord(h->diag_ev, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->diag_stream, h->diag_ev, 0));
+        qs = h->diag_stream;
+    }
+    int32_t rc = rhat_prepare(h, g_from, g_to, r, true, qs);
     if (rc) return rc;
     const int d = r.d;
     const int64_t n = r.n;
@@ -1250,9 +1265,9 @@ static int32_t rhat_enqueue(demcz_handle* h, int64_t g_from, int64_t g_to, doubl
     const bool sharded = (h->comm != nullptr);
     double* sums = r.sums;               // [0,d): sum_j mean_j; [d,3d): stage-1 sums; [3d,4d): R-hat
     if (!sharded) {
-        hipLaunchKernelGGL(rhat_tail_kernel, dim3(d), dim3(256), 0, h->stream, r.mean_j, r.s2_j, r.N, d, (double)n, (double)m, sums + 3 * d);
+        hipLaunchKernelGGL(rhat_tail_kernel, dim3(d), dim3(256), 0, qs, r.mean_j, r.s2_j, r.N, d, (double)n, (double)m, sums + 3 * d);
         HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipMemcpyAsync(out, sums + 3 * d, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(out, sums + 3 * d, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, qs));
         return DEMCZ_OK;
     }
     // stage 0 -> all-reduce -> stage 1 with the grand mean formed on the device -> all-reduce ->
@@ -1710,9 +1725,6 @@ extern "C" int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_
     if (max_checks * d > h->pinned_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->pinned_rhat) (void)hipHostFree(h->pinned_rhat);
-    if (h->d_spec_X) (void)hipFree(h->d_spec_X);
-    if (h->d_spec_lp) (void)hipFree(h->d_spec_lp);
-    if (h->spec_ev) (void)hipEventDestroy(h->spec_ev);
         h->pinned_rhat = nullptr; h->pinned_cap = 0;
         HIPCHK(h, hipHostMalloc((void**)&h->pinned_rhat, (size_t)max_checks * d * sizeof(double), hipHostMallocDefault));
         h->pinned_cap = max_checks * d;
@@ -1743,7 +1755,7 @@ extern "C" int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_
         if (rc) break;
         if (nxt % every == 0 && nxt - every >= h->g0) {          // demcz.jl:39-41
             double* slot = pinned + (size_t)checks * d;
-            rc = rhat_enqueue(h, nxt - every + 1, nxt, slot);
+            rc = rhat_enqueue(h, nxt - every + 1, nxt, slot, /*side=*/monitor);
             if (rc) break;
             ++checks;
             if (!monitor) {
@@ -1792,6 +1804,7 @@ extern "C" int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_
         g = nxt + 1;
     }
     if (rc == DEMCZ_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: synchronise failed");
+    if (rc == DEMCZ_OK && h->diag_stream && hipStreamSynchronize(h->diag_stream) != hipSuccess) rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: synchronise failed");
     if (rc == DEMCZ_OK) {
         for (int32_t i = 0; i < checks; ++i)
             if (rhat_max && i < n_max) rhat_max[i] = max_of(pinned + (size_t)i * d);
