@@ -400,6 +400,7 @@ static int32_t ensure_scratch(demcz_handle* h, int64_t n)
 {
     if (n <= h->scratch_cap) return DEMCZ_OK;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->diag_stream) HIPCHK(h, hipStreamSynchronize(h->diag_stream));      // a check may still be reading the old buffer
     if (h->d_scratch) HIPCHK(h, hipFree(h->d_scratch));
     h->d_scratch = nullptr; h->scratch_cap = 0;
     HIPCHK(h, hipMalloc((void**)&h->d_scratch, (size_t)n * sizeof(double)));
