@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
     static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "split layout: MvNormal / isotropic targets");
     constexpr int L = 8, G = 64 / L, DP = ((D + 1) / 2) * 2;
     constexpr int NP = (D + L - 1) / L;                    // history elements a lane stores: r, r+8, ...
-    constexpr int CH = (D <= 5) ? PC8_CHUNK : PC8_CHUNK / 2;      // the chunk's increments (CH x D doubles) live in registers
+    constexpr int CH = (D <= 5) ? PC8_CHUNK : PC8_CHUNK / 2;      // (LIVE launches hold a chunk's CH x D increments in registers)
     DEMCZ_STAMP(P, 0);
     if ((int64_t)blockIdx.x >= P.consumer_blocks) {
         pc_produce<D>(P, (int64_t)blockIdx.x - P.consumer_blocks);
@@ -72,9 +72,8 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
         for (int i = 0; i < D * (D + 1) / 2; ++i) Wc[i] = P.tp.Wp[i];
     }
     int pk[NP];
-    double epsv[NP];
 #pragma unroll
-    for (int k = 0; k < NP; ++k) { pk[k] = (r + L * k < D) ? r + L * k : 0; epsv[k] = P.eps[pk[k]]; }
+    for (int k = 0; k < NP; ++k) pk[k] = (r + L * k < D) ? r + L * k : 0;
     const double c0c = P.tp.c0;
     double lp = P.lpcur[c];
     const double scale = (D == 1) ? P.gamma : P.gamma / sqrt((double)(2 * D));
@@ -114,19 +113,6 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
     // record rows of this chain; a generation is the next double
     const double* rec_lg = P.rec_in + ((int64_t)D * P.N + c) * P.rec_stride;
     const double* rec_ix = P.rec_in + ((int64_t)(D + 1) * P.N + c) * P.rec_stride;
-    // a chunk's CH consecutive generations of one field: CHP/2 16-byte loads off one address (8-byte aligned:
-    // a chunk may start at an odd generation).  Reads up to CHP - 1 generations past the launch's last one:
-    // the buffers are padded; those slots are never used.
-    constexpr int CHP = ((CH + 1) / 2) * 2;
-    typedef double pair8 __attribute__((ext_vector_type(2), aligned(8)));
-    auto fetch_chunk = [](const double* base, double (&out)[CHP]) {
-#pragma unroll
-        for (int j = 0; j < CHP / 2; ++j) {
-            const pair8 t = reinterpret_cast<const pair8*>(base)[j];
-            out[2 * j] = t.x;
-            out[2 * j + 1] = t.y;
-        }
-    };
     // archive addressing: row stride and the whole archive fit 32 bits of byte offset (condition of this
     // layout), the row stride is a power of two for every dimension built: one shift-add per element
     constexpr int ZSC = (D <= 2) ? 2 : (D <= 4) ? 4 : ((D + 7) / 8) * 8;
