@@ -4,17 +4,20 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A *step* is one generation: every chain of the population proposes, evaluates its log-density
-and takes its Metropolis decision once; history, Z appends (every K=10 generations) and the
-split-R-hat autostop statistic (every 1000 generations) run at their configured cadence inside
-the timed region.  Workload at N=1: BASELINE config C2 (MvNormal d=5, correlated Sigma,
-N=1024 chains, K=10).  At N>1 each GPU holds 1024 more chains (weak scaling), Z is replicated
-and the K-boundary rows are all-gathered over RCCL.
+A *step* is what the boundary is crossed per: ONE AUTOSTOP SLAB of the reference's driver loop
+(src/demcz.jl:30-55 with the `demcopt` defaults, DEMC.jl:41) = `autostop_every` = 1000 generations of
+all chains -- every chain proposes, evaluates its log-density and takes its Metropolis decision
+1000 times; the full history is written, Z is appended to every K = 10 generations -- followed by the
+split-R-hat check of that slab (Rhat_gelman, utils.jl:2-20, demcz.jl:41).  `--steps 20` therefore
+times 20 000 generations and 20 R-hat checks; `value` stays N x generations / second.  At least one
+untimed slab of exactly the timed shape always runs first.  Workload at N=1: BASELINE config C2
+(MvNormal d=5, correlated Sigma, N=1024 chains, K=10).  At N>1 each GPU holds 1024 more chains
+(weak scaling), Z is replicated and the K-boundary rows are all-gathered over RCCL.
 
-Prints ONE JSON line (rank 0).  `value` = N_total * K / seconds with inputs resident in HBM.
-`roofline` prices the window kernel (the dominant kernel) against HBM; `cpu_baseline` is the
-CPU oracle ("port": this repo's C restatement of src/demcz.jl, NOT the Julia package) timed on
-one host core on the same workload.
+Prints ONE JSON line (rank 0).  `value` = N_total * generations / seconds with inputs resident in HBM.
+`roofline` prices the window kernel (the dominant kernel) against HBM from HIP events recorded by the
+library on the kernel's own stream; `cpu_baseline` is the CPU oracle ("port": this repo's C
+restatement of src/demcz.jl, NOT the Julia package) timed on one host core on the same workload.
 """
 import argparse
 import json
@@ -35,20 +38,27 @@ def algorithmic_bytes_per_update(d, K):
     return 8.0 * (3 * d + 1 + d / K)
 
 
-def measured_traffic(n_loc, d, lanes):
-    """HBM-side bytes per window-kernel launch from the committed rocprofv3 PMC passes
-    (scripts/collect_profiles.sh + summarize_profiles.py: FETCH_SIZE and WRITE_SIZE in separate
-    passes, KiB units; the window kernel's reads are single-line random gathers, reported raw --
-    see DESIGN.md section 6).  Only valid for the workload the passes were taken on."""
+def measured_traffic(n_loc, d, K, lanes, gens_per_launch):
+    """HBM-side bytes per window-kernel launch from the committed rocprofv3 PMC passes of THIS command
+    (scripts/collect_profiles.sh + summarize_profiles.py: FETCH_SIZE and WRITE_SIZE in separate passes, KiB
+    units, gfx950 corrections as DESIGN.md section 6 describes).  A counter cannot be read from inside the
+    run it counts, so the figure comes from the profile file -- and is only reported when the profiled
+    launches had the shape of the launches just timed (same chains, d, K, layout, generations per launch);
+    otherwise null.  Returns (raw, fetch-doubled upper bound, source) or None."""
     f = ROOT / "profiles" / "latest_traffic.json"
-    if not f.exists() or (n_loc, d) != (1024, 5):
+    if not f.exists():
         return None
-    if lanes != 100:          # the committed passes were taken with the default (split) layout
+    prof = json.loads(f.read_text())
+    shape = prof.get("launch_shape") or {}
+    if (shape.get("chains"), shape.get("dim"), shape.get("K"), shape.get("lanes_per_chain")) != (n_loc, d, K, lanes):
         return None
-    name = f"window_kernel_pc8<0, {d}, true, false>"      # the LIVE launches (one per slab between R-hat checks)
-    for k, v in json.loads(f.read_text())["kernels"].items():
-        if name in k:
-            return v.get("bytes_per_launch_raw"), v.get("bytes_per_launch_fetch_x2")
+    if abs(float(shape.get("generations_per_launch", -1)) - gens_per_launch) > 1e-9:
+        return None
+    for k, v in prof["kernels"].items():
+        if k.startswith(shape.get("kernel_prefix", "window_kernel")):
+            if abs(v.get("launches_per_run_mean_gens", gens_per_launch) - gens_per_launch) > 1e-9:
+                continue
+            return v.get("bytes_per_launch_raw"), v.get("bytes_per_launch_fetch_x2"), f"profiles/{prof.get('tag')}_traffic.json"
     return None
 
 
@@ -85,7 +95,7 @@ def cpu_baseline(w, N, d, K, seed, budget_updates):
     Z0 = w["Zinit"]
     M0 = Z0.shape[0]
     Mcap = M0 + -(-N * G // K)
-    prob = O.Problem(N, d, K, Mcap, w["eps_scale"], seed, target=w["target"].oracle_spec())
+    prob = O.Problem(N, d, K, Mcap, w["eps_scale"], seed, target=w["target"].spec())
     X = np.array(Z0[M0 - N:], order="F")
     lp = O.logp(prob, X)
     Z = np.zeros((Mcap, d), order="F")
@@ -107,7 +117,7 @@ def cpu_baseline(w, N, d, K, seed, budget_updates):
         lp = O.logp(prob, X)
         Gm = 2 * G
         Mcap2 = M0 + -(-N * Gm // K)
-        prob2 = O.Problem(N, d, K, Mcap2, w["eps_scale"], seed, target=w["target"].oracle_spec())
+        prob2 = O.Problem(N, d, K, Mcap2, w["eps_scale"], seed, target=w["target"].spec())
         Z2 = np.zeros((Mcap2, d), order="F")
         Z2[:M0] = Z0
         t0 = time.perf_counter()
@@ -122,8 +132,9 @@ def cpu_baseline(w, N, d, K, seed, budget_updates):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10000)
-    ap.add_argument("--warmup", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=10, help="timed autostop slabs (1000 generations + R-hat check each)")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed slabs of the same shape before them (at least 1 is run)")
+    ap.add_argument("--slab-generations", type=int, default=1000, help="generations per step: autostop_every (DEMC.jl:41)")
     ap.add_argument("--chains-per-gpu", type=int, default=1024)
     ap.add_argument("--dim", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -145,6 +156,8 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if args.steps < 1 or args.warmup < 0 or args.slab_generations < 4:
+        raise SystemExit("need --steps >= 1, --warmup >= 0, --slab-generations >= 4")
     torch.cuda.set_device(local_rank)
     sharding = None
     dist = None
@@ -160,9 +173,11 @@ def main():
     lag = args.append_lag if args.append_lag >= 0 else (0 if world == 1 else 10)
     d, K, n_loc = args.dim, 10, args.chains_per_gpu
     N = n_loc * world
-    W, S = args.warmup, args.steps
-    G = W + S
-    every, thr, seed = 1000, 1.05, 31953150
+    every = args.slab_generations
+    S = args.steps
+    W = max(args.warmup, 1)          # one slab of the timed shape always runs first (code objects, record buffers, draws)
+    G = (W + S) * every
+    thr, seed = 1.05, 31953150
     w = demc.workloads.mvnormal_problem(d, N)
     stream = torch.cuda.Stream()
     X, logp = demc.initial_state(w["target"], w["Zinit"], N, G, K, None, "last_rows")
@@ -201,11 +216,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if W > 0:
-        advance(1, W, False)
+    advance(1, W * every, False)
     fence()
     t0 = time.perf_counter()
-    ev_ms, launches = advance(W + 1, G, True)
+    ev_ms, launches = advance(W * every + 1, G, True)
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -214,30 +228,40 @@ def main():
         dt = float(t.item())
 
     # a cheap end-of-run sanity check on the sampler output (not timed)
-    acc = runner.accept_ratio_mean(max(1, G - min(S, 1000) + 1), G) if S >= 2 else float("nan")
+    acc = runner.accept_ratio_mean(G - every + 1, G)
+    live_on, live_redos = eng.live_status()
+    lanes = eng.info()["lanes_per_chain"]
+    runner.close()        # (frees the device's LIVE slot for the sweep's handles)
 
     if rank == 0:
         B = algorithmic_bytes_per_update(d, K)
-        gens_per_launch = S / max(launches, 1)
+        gens = S * every
+        gens_per_launch = gens / max(launches, 1)
         bytes_per_launch = B * n_loc * gens_per_launch
         avg_launch_s = (ev_ms / 1e3) / max(launches, 1)
         achieved = bytes_per_launch / avg_launch_s / 1e9
-        # PMC bytes per launch (committed rocprofv3 passes): `traffic` = FETCH_SIZE + WRITE_SIZE as counted -- calibrated
-        # exact for this kernel's row gathers; its coalesced record reads (a third of the fetch) are tallied at half on
-        # gfx950 (MI355X_MICROARCH.md, HBM) -- `traffic_fetch_x2` = the upper bound with every fetched byte doubled
-        traffic = (measured_traffic(n_loc, d, eng.info()["lanes_per_chain"]) if K == 10 else None) or (None, None)
+        # PMC bytes per launch from the committed rocprofv3 passes of this same command; null unless the profiled
+        # launches had this shape.  `traffic` = FETCH_SIZE + WRITE_SIZE as counted; `traffic_fetch_x2` = the upper
+        # bound with every fetched byte doubled (MI355X_MICROARCH.md, HBM: gfx950 halves coalesced streaming reads)
+        traffic = measured_traffic(n_loc, d, K, lanes, gens_per_launch) or (None, None, None)
+        split = lanes == 100
         out = {
             "metric": "chain-updates/sec (N x gens/s) + gens-to-Rhat<1.05, MvNormal d=5 N=1024",
-            "value": N * S / dt, "unit": "chain-updates/s", "n_gpus": world, "steps": S, "warmup": W,
+            "value": N * gens / dt, "unit": "chain-updates/s", "n_gpus": world, "steps": S, "warmup": W,
             "ms_per_step": dt / S * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"C2: MvNormal d={d} correlated Sigma, N={n_loc} chains/GPU x {world} GPU, K={K}, "
-                                   f"gamma=2.38, eps=1e-5, full-history + Z append + split-Rhat every {every}",
-                       "chains_total": N, "dim": d, "K": K, "lanes_per_chain": eng.info()["lanes_per_chain"], "append_lag": lag,
+                                   f"gamma=2.38, eps=1e-5; step = one autostop slab = {every} generations with full "
+                                   f"history + Z append every K + the slab's split-Rhat check (demcz.jl:30-55)",
+                       "chains_total": N, "dim": d, "K": K, "generations_per_step": every, "generations_timed": gens,
+                       "lanes_per_chain": lanes, "append_lag": lag, "live_launches": live_on, "live_redos": live_redos,
                        "parallelism": f"chains sharded x{world}, Z replicated" if world > 1 else "single GPU"},
             "gens_to_rhat_1p05": gens_to_rhat, "rhat_trace": rhat_trace[-12:], "accept_ratio_mean": acc,
+            "value_window_kernels_only": N * gens / (ev_ms / 1e3) if ev_ms > 0 else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic[0], "traffic_fetch_x2": traffic[1], "kernel": "demcz::window_kernel_pc8<MVNORMAL, 5, LIVE>" if eng.info()["lanes_per_chain"] == 100 else "demcz::window_kernel",
+                         "traffic": traffic[0], "traffic_fetch_x2": traffic[1], "traffic_source": traffic[2],
+                         "kernel": (f"demcz::window_kernel_pc8<MVNORMAL, {d}, LIVE={'true' if live_on else 'false'}>" if split
+                                    else "demcz::window_kernel"),
                          "launches": launches, "generations_per_launch": gens_per_launch,
                          "avg_launch_us": avg_launch_s * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_chain_update": B},
@@ -255,7 +279,6 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "chain-updates/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {e}"}
         print(json.dumps(out))
-    runner.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <deque>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -93,6 +94,19 @@ struct demcz_handle {
 #endif
     int64_t rec_cap = 0;              // generations each buffer holds
     int rec_cur = 0;
+    mutable bool lds_raised = false;  // hipFuncAttributeMaxDynamicSharedMemorySize raised on this handle's device (the attribute is per device)
+    bool no_live = false;             // a LIVE hand-off failed on this handle: one launch per K-window from then on
+    bool live_claimed = false;        // this handle holds its device's LIVE slot (one handle per device at a time)
+    unsigned int live_spin_limit = 0; // polls before a LIVE wait gives up (0: the default, demcz_kernels_rec.h)
+    // LIVE launches are verified at the next synchronising call; until then the state they started from and the
+    // calls made since are kept, so that a failed hand-off is redone with one launch per K-window (live_verify)
+    struct RunCall { int64_t g_from, g_to; double gamma; bool tempered; std::vector<double> temperature; };
+    std::vector<RunCall> live_log;
+    double* d_safe_X = nullptr;
+    double* d_safe_lp = nullptr;
+    int64_t safe_M = 0, safe_M_app = 0, safe_g_done = 0;
+    bool replaying = false;
+    int32_t live_redos = 0;
     struct RecDesc { bool valid = false; int64_t g_first = 0, M = 0, rows = 0; int32_t ngen = 0, boff = 0; } rec_desc[2];
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -151,6 +165,10 @@ static bool pc_available(int target_kind, int d, bool full_block);
 static bool split_ml_available(int target_kind, int d, bool full_block, int64_t nobs);
 static int32_t flush_exchanges(demcz_handle* h);
 static int32_t check_live_err(demcz_handle* h);
+static int32_t live_verify(demcz_handle* h);
+static void live_release(demcz_handle* h);
+static int64_t live_span(demcz_handle* h);
+static int32_t rec_reserve(demcz_handle* h, int64_t gens);
 
 extern "C" int32_t demcz_abi_version(void) { return DEMCZ_ABI_VERSION; }
 
@@ -188,6 +206,8 @@ static void free_all(demcz_handle* h)
     if (h->d_stage) (void)hipHostFree(h->d_stage);
     for (auto& pr : h->timed) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (h->pinned_rhat) (void)hipHostFree(h->pinned_rhat);
+    if (h->d_safe_X) (void)hipFree(h->d_safe_X);
+    if (h->d_safe_lp) (void)hipFree(h->d_safe_lp);
     if (h->d_spec_X) (void)hipFree(h->d_spec_X);
     if (h->d_spec_lp) (void)hipFree(h->d_spec_lp);
     if (h->spec_ev) (void)hipEventDestroy(h->spec_ev);
@@ -383,6 +403,7 @@ extern "C" int32_t demcz_destroy(demcz_handle* h)
     if (!h) return DEMCZ_OK;
     (void)hipSetDevice(h->cfg.device_id);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    live_release(h);
     free_all(h);
     delete h;
     return DEMCZ_OK;
@@ -466,6 +487,7 @@ extern "C" int32_t demcz_set_state(demcz_handle* h, const double* X, const doubl
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->M = M0;
     h->M_app = M0;
+    h->live_log.clear();
     h->rec_desc[0].valid = h->rec_desc[1].valid = false;
     for (auto& pe : h->pending) if (pe.ev) (void)hipEventDestroy(pe.ev);
     h->pending.clear();
@@ -483,6 +505,10 @@ extern "C" int32_t demcz_get_state(demcz_handle* h, double* X, double* logp, dou
     if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
     if (!h->has_state) return fail(h, DEMCZ_ERR_STATE, "demcz_get_state: no state set");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    {
+        int32_t rcv = live_verify(h);
+        if (rcv) return rcv;
+    }
     const int d = h->cfg.d;
     const int64_t N = h->cfg.N;
     if (X) HIPCHK(h, hipMemcpyAsync(X, h->dX, (size_t)N * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -503,7 +529,7 @@ extern "C" int32_t demcz_get_state(demcz_handle* h, double* X, double* logp, dou
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (M) *M = h->M_app;
-    return check_live_err(h);
+    return DEMCZ_OK;
 }
 
 extern "C" int32_t demcz_set_history_origin(demcz_handle* h, int64_t g0)
@@ -511,6 +537,10 @@ extern "C" int32_t demcz_set_history_origin(demcz_handle* h, int64_t g0)
     if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
     if (g0 < 0) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_set_history_origin: g0 >= 0");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    if (!h->live_log.empty()) {          // unverified LIVE launches wrote their history under the old origin
+        int32_t rcv = live_verify(h);
+        if (rcv) return rcv;
+    }
     // slot 0's predecessor is the current log_obj if exactly g0 generations have been run
     h->origin_valid = h->has_state && (h->g_done == g0 || h->g_done == h->g0);
     if (h->has_state)
@@ -542,13 +572,10 @@ static void launch_window_ml(const demcz_handle* h, const WindowParams& P)
 {
     constexpr int NG = ml_waves<TARGET>() * (64 / L);      // chains per workgroup
     const size_t dyn = ml_dynamic_lds<TARGET, D, L>(P.tp.nobs);
-    if (dyn > 48 * 1024) {
-        static bool raised = false;                         // once per process and instantiation
-        if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_ml<TARGET, D, L>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
-            raised = true;
-        }
+    if (dyn > 48 * 1024 && !h->lds_raised) {               // once per handle: the attribute belongs to the device
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_ml<TARGET, D, L>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
+        h->lds_raised = true;
     }
     hipLaunchKernelGGL((window_kernel_ml<TARGET, D, L>), dim3((unsigned)((P.N + NG - 1) / NG)), dim3(64 * ml_waves<TARGET>()),
                        dyn, h->stream, P);
@@ -646,11 +673,10 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
     } else if (lr_split) {
         const dim3 grid((unsigned)blocks), wg(64 * ML_LR_WAVES);
         const size_t dyn = ml_dynamic_lds<TARGET_LINREG_SSE, 10, 16>(P.tp.nobs);
-        static bool raised = false;
-        if (!raised) {
+        if (!h->lds_raised) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_ml<TARGET_LINREG_SSE, 10, 16, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_ml<TARGET_LINREG_SSE, 10, 16, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
-            raised = true;
+            h->lds_raised = true;
         }
         if (live) hipLaunchKernelGGL((window_kernel_ml<TARGET_LINREG_SSE, 10, 16, true, true>), grid, wg, dyn, h->stream, P);
         else hipLaunchKernelGGL((window_kernel_ml<TARGET_LINREG_SSE, 10, 16, true, false>), grid, wg, dyn, h->stream, P);
@@ -678,23 +704,32 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
 // Records of the launch (g .. g+ngen-1 against M rows) are in d_rec[rec_cur] when this returns: either
 // the previous launch's producer half made them, or a producer-only launch is enqueued now.  Then
 // `P` is completed so that this launch's producer half prepares (next_g, next_ngen, next_M).
+// Both record buffers hold `gens` generations per (field, chain) afterwards.  demcz_run reserves the most a
+// launch of this handle can need before it starts timing or launching (so no allocation, synchronisation or
+// memset ever sits between two window launches); pc_prepare only grows them if a caller outruns that.
+static int32_t rec_reserve(demcz_handle* h, int64_t gens)
+{
+    if (gens <= h->rec_cap) return DEMCZ_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int b = 0; b < 2; ++b) {
+        if (h->d_rec[b]) HIPCHK(h, hipFree(h->d_rec[b]));
+        h->d_rec[b] = nullptr;
+        // (+ REC_PAD doubles: a consumer's last 16-byte chunk fetch may run past its row's last generation)
+        const size_t nd = (size_t)gens * (size_t)rec_fields(h) * h->cfg.N + REC_PAD;
+        HIPCHK(h, hipMalloc((void**)&h->d_rec[b], nd * sizeof(double)));
+        HIPCHK(h, hipMemsetAsync(h->d_rec[b], 0, nd * sizeof(double), h->stream));   // row 0: always a legal index
+        h->rec_desc[b].valid = false;
+    }
+    h->rec_cap = gens;
+    return DEMCZ_OK;
+}
+
 static int32_t pc_prepare(demcz_handle* h, WindowParams& P, int64_t cur_rows, int64_t next_g, int64_t next_ngen, int64_t next_M,
                           int64_t next_rows, int32_t next_boff)
 {
-    const int d = h->cfg.d;
-    const int64_t need = std::max<int64_t>(P.ngen, next_ngen);
-    if (need > h->rec_cap) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        for (int b = 0; b < 2; ++b) {
-            if (h->d_rec[b]) HIPCHK(h, hipFree(h->d_rec[b]));
-            h->d_rec[b] = nullptr;
-            // (+ REC_PAD doubles: a consumer's last 16-byte chunk fetch may run past its row's last generation)
-            const size_t nd = (size_t)need * (size_t)rec_fields(h) * h->cfg.N + REC_PAD;
-            HIPCHK(h, hipMalloc((void**)&h->d_rec[b], nd * sizeof(double)));
-            HIPCHK(h, hipMemsetAsync(h->d_rec[b], 0, nd * sizeof(double), h->stream));   // row 0: always a legal index
-            h->rec_desc[b].valid = false;
-        }
-        h->rec_cap = need;
+    {
+        int32_t rcr = rec_reserve(h, std::max<int64_t>(P.ngen, next_ngen));
+        if (rcr) return rcr;
     }
     P.rec_stride = h->rec_cap;
     const int cur = h->rec_cur;
@@ -892,12 +927,68 @@ static int32_t flush_exchanges(demcz_handle* h)
 static int32_t check_live_err(demcz_handle* h)
 {
     unsigned int e[4] = {0, 0, 0, 0};
+    if (!h->d_live_err) return DEMCZ_OK;         // (the scratch handles of the *_array diagnostics run no chains)
     HIPCHK(h, hipMemcpy(e, h->d_live_err, sizeof(e), hipMemcpyDeviceToHost));
     if (e[0])
         return fail(h, DEMCZ_ERR_HIP, "demcz_run: an archive row appended inside the launch never became visible (LIVE hand-off): "
                                       "generation " + std::to_string(e[1]) + " of the launch, row " + std::to_string(e[2]) +
                                       ", workgroup " + std::to_string(e[3]) + ", rows appended " + std::to_string(h->M_app));
     return DEMCZ_OK;
+}
+
+// What a failed hand-off leaves behind is undone: X, log_obj, M go back to the state before the first unverified
+// demcz_run call, the rows written since read as unwritten again, the error word is cleared, and the handle stops
+// using LIVE launches.  Returns the calls made since (for live_verify to redo).
+static int32_t live_rollback(demcz_handle* h, std::vector<demcz_handle::RunCall>& calls)
+{
+    calls.swap(h->live_log);
+    h->live_log.clear();
+    const int64_t N = h->cfg.N;
+    const int d = h->cfg.d;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->diag_stream) HIPCHK(h, hipStreamSynchronize(h->diag_stream));
+    HIPCHK(h, hipMemcpyAsync(h->dX, h->d_safe_X, (size_t)N * d * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->dlp, h->d_safe_lp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (h->M_app > h->safe_M_app) {
+        const size_t rest = (size_t)(h->M_app - h->safe_M_app) * (size_t)h->ZS;
+        hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, h->stream,
+                           reinterpret_cast<unsigned long long*>(h->dZ + (size_t)h->safe_M_app * h->ZS), rest, LIVE_SENTINEL);
+        HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipMemsetAsync(h->d_live_err, 0, 4 * sizeof(unsigned int), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->M = h->safe_M;
+    h->M_app = h->safe_M_app;
+    h->g_done = h->safe_g_done;
+    h->rec_desc[0].valid = h->rec_desc[1].valid = false;
+    h->no_live = true;
+    live_release(h);
+    ++h->live_redos;
+    return DEMCZ_OK;
+}
+
+// Every entry point that hands results to the caller goes through here: the stream is drained, and if a LIVE
+// launch since the last verification gave up waiting for a row, everything since then is redone with one launch
+// per K-window (bit-identical results; the handle stays in that mode).  DEMCZ_OK afterwards means the results are valid.
+static int32_t live_verify(demcz_handle* h)
+{
+    if (h->live_log.empty() || h->replaying) return check_live_err(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    unsigned int e[4] = {0, 0, 0, 0};
+    HIPCHK(h, hipMemcpy(e, h->d_live_err, sizeof(e), hipMemcpyDeviceToHost));
+    if (!e[0]) { h->live_log.clear(); return DEMCZ_OK; }
+    std::vector<demcz_handle::RunCall> calls;
+    int32_t rc = live_rollback(h, calls);
+    if (rc) return rc;
+    h->replaying = true;
+    for (const auto& c : calls) {
+        rc = demcz_run(h, c.g_from, c.g_to, c.gamma, c.tempered ? c.temperature.data() : nullptr);
+        if (rc) break;
+    }
+    h->replaying = false;
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return check_live_err(h);
 }
 
 // The consumer workgroups of a LIVE launch wait for each other's rows, so all of them must be resident at
@@ -955,13 +1046,43 @@ static int64_t live_wg_capacity(demcz_handle* h)
 // Generations one LIVE launch of the split layout may span (0: not applicable -- other layouts, sharded
 // runs, deferred visibility, appends owned by the caller, more consumer workgroups than may wait for each
 // other).  Bounded by the draw records it needs.
+// The waves of a LIVE launch wait for each other, so the residency rule above must hold for everything the
+// process has in flight on the device: ONE handle per device uses LIVE launches at a time (the first to ask keeps
+// the slot until it is destroyed); other handles on that device run one launch per K-window -- same results.
+// (Another PROCESS on the GPU is outside this rule; the bounded poll + the automatic redo in demcz_run_checked /
+//  check_live_err cover it.)
+static std::mutex g_live_mutex;
+static demcz_handle* g_live_owner[64] = {nullptr};
+
+static bool live_claim(demcz_handle* h)
+{
+    if (h->live_claimed) return true;
+    const int dev = h->cfg.device_id;
+    if (dev < 0 || dev >= 64) return false;
+    std::lock_guard<std::mutex> lk(g_live_mutex);
+    if (g_live_owner[dev] != nullptr && g_live_owner[dev] != h) return false;
+    g_live_owner[dev] = h;
+    h->live_claimed = true;
+    return true;
+}
+
+static void live_release(demcz_handle* h)
+{
+    if (!h->live_claimed) return;
+    std::lock_guard<std::mutex> lk(g_live_mutex);
+    const int dev = h->cfg.device_id;
+    if (dev >= 0 && dev < 64 && g_live_owner[dev] == h) g_live_owner[dev] = nullptr;
+    h->live_claimed = false;
+}
+
 static int64_t live_span(demcz_handle* h)
 {
-    if (h->lanes != DEMCZ_LAYOUT_SPLIT || h->comm || h->lag > 0 || h->external_append) return 0;
+    if (h->lanes != DEMCZ_LAYOUT_SPLIT || h->comm || h->lag > 0 || h->external_append || h->no_live) return 0;
     static const bool disabled = (getenv("DEMCZ_NO_LIVE") != nullptr);     // safety valve: one launch per K-window
     if (disabled) return 0;
     const int per_wg = h->split_per_wg;
     if ((h->cfg.N + per_wg - 1) / per_wg > live_wg_capacity(h)) return 0;
+    if (!live_claim(h)) return 0;
     const int64_t per_gen = rec_fields(h) * h->cfg.N * (int64_t)sizeof(double);
     const int64_t span = (int64_t)(64ll << 20) / per_gen;        // 64 MiB of records per buffer (C2: 1170 generations)
     return std::max<int64_t>(h->cfg.K, std::min<int64_t>(span, 1 << 20));
@@ -1026,15 +1147,50 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
 #endif
     const int E = h->lag;
     int64_t g = g_from;
+    if (h->lanes == DEMCZ_LAYOUT_SPLIT) {
+        // draw-record buffers: sized ONCE for the longest launch this handle can make -- a LIVE launch spans up
+        // to live_span() generations (never more than the run is long: Gcap, when a history is kept), any other
+        // at most a K-window / a batch of E windows -- before anything of this call is timed or enqueued
+        const int64_t lm = live_span(h);
+        int64_t cap = (lm > 0) ? lm : (int64_t)K * std::max(E, 1);
+        if (lm > 0 && hist) cap = std::max<int64_t>(std::min<int64_t>(cap, h->cfg.Gcap), std::min<int64_t>(cap, G));
+        int32_t rcr = rec_reserve(h, cap);
+        if (rcr) return rcr;
+    }
+    if (!h->replaying && live_span(h) > 0) {
+        // this call may issue LIVE launches: they are verified at the next synchronising entry point, and redone
+        // from here (live_verify) should a row hand-off inside one of them fail
+        if (h->live_log.size() >= 256) {            // bound the redo: verify now (a synchronisation every 256 calls)
+            int32_t rcv = live_verify(h);
+            if (rcv) return rcv;
+        }
+        if (live_span(h) > 0) {
+            if (h->live_log.empty()) {
+                const int64_t N = h->cfg.N;
+                const int d = h->cfg.d;
+                if (!h->d_safe_X) HIPCHK(h, hipMalloc((void**)&h->d_safe_X, (size_t)N * d * sizeof(double)));
+                if (!h->d_safe_lp) HIPCHK(h, hipMalloc((void**)&h->d_safe_lp, (size_t)N * sizeof(double)));
+                HIPCHK(h, hipMemcpyAsync(h->d_safe_X, h->dX, (size_t)N * d * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+                HIPCHK(h, hipMemcpyAsync(h->d_safe_lp, h->dlp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+                h->safe_M = h->M; h->safe_M_app = h->M_app; h->safe_g_done = h->g_done;
+            }
+            demcz_handle::RunCall rcall{g_from, g_to, gamma, temperature != nullptr, {}};
+            if (temperature) rcall.temperature.assign(temperature, temperature + G);
+            h->live_log.push_back(std::move(rcall));
+        }
+    }
     // demcz_set_kernel_timing: ONE event pair around the back-to-back window launches of this call (an event
     // between two launches would put a bubble into the stream it is meant to measure)
-    hipEvent_t tev0 = nullptr, tev1 = nullptr;
+    struct EventPair {          // destroyed on every error return; handed to h->timed on success
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } tev;
     int64_t timed_launches = 0;
     const bool timed = h->timing && h->timed.size() < 4096;
     if (timed) {
-        HIPCHK(h, hipEventCreate(&tev0));
-        HIPCHK(h, hipEventCreate(&tev1));
-        HIPCHK(h, hipEventRecord(tev0, h->stream));
+        HIPCHK(h, hipEventCreate(&tev.a));
+        HIPCHK(h, hipEventCreate(&tev.b));
+        HIPCHK(h, hipEventRecord(tev.a, h->stream));
     }
     while (g <= g_to) {
         const int64_t next_boundary = ((g - 1) / K + 1) * K;      // first multiple of K that is >= g
@@ -1091,6 +1247,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         // boundaries whose rows generations of this same launch draw from
         const bool live = live_max > 0 && ((w_end - 1) / K - (g - 1) / K) > 0;
         P.live_err = h->d_live_err;
+        P.live_spin_limit = h->live_spin_limit ? (int32_t)h->live_spin_limit : LIVE_SPIN_LIMIT;
         rc = launch_window(h, P, live);
         if (rc) return rc;
         ++timed_launches;
@@ -1121,8 +1278,9 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         g = w_end + 1;
     }
     if (timed) {
-        HIPCHK(h, hipEventRecord(tev1, h->stream));
-        h->timed.emplace_back(tev0, tev1);
+        HIPCHK(h, hipEventRecord(tev.b, h->stream));
+        h->timed.emplace_back(tev.a, tev.b);
+        tev.a = tev.b = nullptr;
         h->timed_launches += timed_launches;
     }
     if (sharded && E > 0) {                 // nothing stays un-exchanged across calls
@@ -1139,7 +1297,7 @@ extern "C" int32_t demcz_synchronize(demcz_handle* h)
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
-    return check_live_err(h);
+    return live_verify(h);
 }
 
 static int32_t check_hist_range(demcz_handle* h, int64_t g_from, int64_t g_to, const char* who)
@@ -1156,6 +1314,8 @@ extern "C" int32_t demcz_get_history(demcz_handle* h, int64_t g_from, int64_t g_
     int32_t rc = check_hist_range(h, g_from, g_to, "demcz_get_history");
     if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    rc = live_verify(h);
+    if (rc) return rc;
     const int64_t N = h->cfg.N, G = g_to - g_from + 1, s0 = g_from - h->g0 - 1;
     const int d = h->cfg.d;
     if (chain)
@@ -1165,7 +1325,7 @@ extern "C" int32_t demcz_get_history(demcz_handle* h, int64_t g_from, int64_t g_
         HIPCHK(h, hipMemcpyAsync(log_obj, h->dlogobj + (size_t)N * s0, (size_t)N * G * sizeof(double),
                                  hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return check_live_err(h);
+    return DEMCZ_OK;
 }
 
 extern "C" int32_t demcz_get_changed(demcz_handle* h, int64_t g_from, int64_t g_to, int64_t* changed)
@@ -1178,6 +1338,8 @@ extern "C" int32_t demcz_get_changed(demcz_handle* h, int64_t g_from, int64_t g_
         return fail(h, DEMCZ_ERR_STATE, "demcz_get_changed: the log_obj before the first history slot is not known "
                                         "(set the history origin when exactly g0 generations have been run)");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    rc = live_verify(h);
+    if (rc) return rc;
     rc = ensure_scratch(h, G);
     if (rc) return rc;
     static_assert(sizeof(long long) == sizeof(double), "scratch reuse");
@@ -1226,7 +1388,9 @@ extern "C" int32_t demcz_rhat_partial(demcz_handle* h, int64_t g_from, int64_t g
 {
     if (!h || !out || (stage != 0 && stage != 1) || (stage == 1 && !grand)) return DEMCZ_ERR_INVALID_ARGUMENT;
     RhatPlan r;
-    int32_t rc = rhat_prepare(h, g_from, g_to, r, true);
+    int32_t rc = live_verify(h);
+    if (rc) return rc;
+    rc = rhat_prepare(h, g_from, g_to, r, true);
     if (rc) return rc;
     const int d = r.d;
     if (stage == 0) {
@@ -1288,7 +1452,9 @@ static int32_t rhat_enqueue(demcz_handle* h, int64_t g_from, int64_t g_to, doubl
 extern "C" int32_t demcz_rhat(demcz_handle* h, int64_t g_from, int64_t g_to, double* rhat)
 {
     if (!h || !rhat) return DEMCZ_ERR_INVALID_ARGUMENT;
-    int32_t rc = rhat_enqueue(h, g_from, g_to, rhat);
+    int32_t rc = live_verify(h);
+    if (rc) return rc;
+    rc = rhat_enqueue(h, g_from, g_to, rhat);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return DEMCZ_OK;
@@ -1302,6 +1468,8 @@ extern "C" int32_t demcz_accept_ratio(demcz_handle* h, int64_t g_from, int64_t g
     const int64_t N = h->cfg.N, w = g_to - g_from + 1, s0 = g_from - h->g0 - 1;
     if (w < 2) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_accept_ratio: need at least 2 generations");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    rc = live_verify(h);
+    if (rc) return rc;
     rc = ensure_scratch(h, N);
     if (rc) return rc;
     hipLaunchKernelGGL(changed_per_chain_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, h->stream, h->dlogobj, N, s0, w, h->d_scratch);
@@ -1319,6 +1487,8 @@ extern "C" int32_t demcz_mean_cov(demcz_handle* h, int64_t g_from, int64_t g_to,
     const int64_t N = h->cfg.N, w = g_to - g_from + 1, s0 = g_from - h->g0 - 1;
     const int d = h->cfg.d;
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    rc = live_verify(h);
+    if (rc) return rc;
     rc = ensure_scratch(h, (int64_t)d * (d + 1) + d);
     if (rc) return rc;
     double* sums = h->d_scratch;
@@ -1494,6 +1664,7 @@ extern "C" int32_t demcz_comm_init(demcz_handle* h, const void* unique_id_128B, 
 {
     if (!h || !unique_id_128B || nranks < 1 || rank < 0 || rank >= nranks) return DEMCZ_ERR_INVALID_ARGUMENT;
     if (h->comm) return fail(h, DEMCZ_ERR_STATE, "demcz_comm_init: communicator already initialised");
+    if (!h->live_log.empty()) { int32_t rcv = live_verify(h); if (rcv) return rcv; }
     if (h->cfg.chain_id0 != (int64_t)rank * h->cfg.N)
         return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_comm_init: chain_id0 must be rank * N (equal shards in rank order)");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
@@ -1555,6 +1726,7 @@ extern "C" int32_t demcz_append_rows(demcz_handle* h, const double* rows, int64_
 extern "C" int32_t demcz_set_external_append(demcz_handle* h, int32_t enabled)
 {
     if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (!h->live_log.empty()) { int32_t rcv = live_verify(h); if (rcv) return rcv; }
     h->external_append = enabled != 0;
     return DEMCZ_OK;
 }
@@ -1562,6 +1734,7 @@ extern "C" int32_t demcz_set_external_append(demcz_handle* h, int32_t enabled)
 extern "C" int32_t demcz_set_append_lag(demcz_handle* h, int32_t batches)
 {
     if (!h || batches < 0 || batches > 64) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (!h->live_log.empty()) { int32_t rcv = live_verify(h); if (rcv) return rcv; }
     if (h->M_app != h->M || !h->pending.empty()) return fail(h, DEMCZ_ERR_STATE, "demcz_set_append_lag: rows are still pending");
     if (h->external_append && batches) return fail(h, DEMCZ_ERR_STATE, "demcz_set_append_lag: caller-driven appends schedule their own visibility");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
@@ -1592,6 +1765,7 @@ extern "C" int32_t demcz_set_append_lag(demcz_handle* h, int32_t batches)
 extern "C" int32_t demcz_set_rng_offset(demcz_handle* h, int64_t generations)
 {
     if (!h || generations < 0) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (!h->live_log.empty()) { int32_t rcv = live_verify(h); if (rcv) return rcv; }
     h->rng_offset = generations;
     h->rec_desc[0].valid = h->rec_desc[1].valid = false;
     return DEMCZ_OK;
@@ -1708,12 +1882,10 @@ extern "C" int32_t demcz_debug_read_stamps(demcz_handle* h, unsigned long long* 
 }
 #endif
 
-extern "C" int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_to, double gamma, const double* temperature,
-                                     int64_t every, double threshold, int64_t* g_stop, int32_t* n_checks,
-                                     double* rhat_max, int32_t n_max, double* rhat_last)
+static int32_t run_checked_body(demcz_handle* h, int64_t g_from, int64_t g_to, double gamma, const double* temperature,
+                                int64_t every, double threshold, int64_t* g_stop, int32_t* n_checks,
+                                double* rhat_max, int32_t n_max, double* rhat_last)
 {
-    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
-    if (every < 4 || g_from < 1 || g_to < g_from) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_run_checked: need every >= 4 and 1 <= g_from <= g_to");
     const int d = h->cfg.d;
     int32_t checks = 0;
     int64_t g = g_from;
@@ -1727,8 +1899,9 @@ extern "C" int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->pinned_rhat) (void)hipHostFree(h->pinned_rhat);
         h->pinned_rhat = nullptr; h->pinned_cap = 0;
-        HIPCHK(h, hipHostMalloc((void**)&h->pinned_rhat, (size_t)max_checks * d * sizeof(double), hipHostMallocDefault));
-        h->pinned_cap = max_checks * d;
+        const int64_t cap = std::max<int64_t>(max_checks, 1024) * d;       // (no reallocation between calls of different length)
+        HIPCHK(h, hipHostMalloc((void**)&h->pinned_rhat, (size_t)cap * sizeof(double), hipHostMallocDefault));
+        h->pinned_cap = cap;
     }
     double* pinned = h->pinned_rhat;
     auto max_of = [d](const double* r) {
@@ -1790,13 +1963,24 @@ extern "C" int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_
                             break;
                         }
                         const size_t rest = (size_t)(h->M_app - M_before) * (size_t)h->ZS;
-                        if (rest > 0)
+                        if (rest > 0) {
                             hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, h->stream,
                                                reinterpret_cast<unsigned long long*>(h->dZ + (size_t)M_before * h->ZS), rest, LIVE_SENTINEL);
+                            if (hipGetLastError() != hipSuccess) { rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: restore failed"); break; }
+                        }
+                        // its history slots read as never written again (zeros, demcz.jl:24)
+                        const int64_t s_lo = nxt - h->g0, s_hi = std::min<int64_t>(h->g_done - h->g0, h->cfg.Gcap);
+                        if (s_hi > s_lo &&
+                            (hipMemsetAsync(h->dchain + (size_t)N * d * s_lo, 0, (size_t)N * d * (s_hi - s_lo) * sizeof(double), h->stream) != hipSuccess ||
+                             hipMemsetAsync(h->dlogobj + (size_t)N * s_lo, 0, (size_t)N * (s_hi - s_lo) * sizeof(double), h->stream) != hipSuccess)) {
+                            rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: restore failed");
+                            break;
+                        }
                         h->M_app = M_before;
                         h->M = M_before;
                         h->g_done = nxt;
                         h->rec_desc[0].valid = h->rec_desc[1].valid = false;
+                        if (!h->live_log.empty()) h->live_log.pop_back();     // the discarded slab is not to be redone
                     }
                     break;
                 }
@@ -1813,6 +1997,47 @@ extern "C" int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_
         if (n_checks) *n_checks = checks;
     }
     return rc;
+}
+
+extern "C" int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_to, double gamma, const double* temperature,
+                                     int64_t every, double threshold, int64_t* g_stop, int32_t* n_checks,
+                                     double* rhat_max, int32_t n_max, double* rhat_last)
+{
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (every < 4 || g_from < 1 || g_to < g_from) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_run_checked: need every >= 4 and 1 <= g_from <= g_to");
+    if (!h->has_state) return fail(h, DEMCZ_ERR_STATE, "demcz_run_checked: call demcz_set_state first");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    // everything before this call is verified first, so that a failed LIVE hand-off inside it rolls back to HERE
+    int32_t rc = live_verify(h);
+    if (rc) return rc;
+    rc = run_checked_body(h, g_from, g_to, gamma, temperature, every, threshold, g_stop, n_checks, rhat_max, n_max, rhat_last);
+    if (h->live_log.empty()) return rc;
+    // the statistics and the stop decision above may rest on a slab whose row hand-off failed: look, and if so
+    // undo the whole call and make it again with one launch per K-window (the handle stays in that mode)
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: synchronise failed");
+    unsigned int e[4] = {0, 0, 0, 0};
+    HIPCHK(h, hipMemcpy(e, h->d_live_err, sizeof(e), hipMemcpyDeviceToHost));
+    if (!e[0]) { h->live_log.clear(); return rc; }
+    std::vector<demcz_handle::RunCall> dropped;
+    rc = live_rollback(h, dropped);
+    if (rc) return rc;
+    return run_checked_body(h, g_from, g_to, gamma, temperature, every, threshold, g_stop, n_checks, rhat_max, n_max, rhat_last);
+}
+
+// ---- diagnostic entry points (not part of the contract of SURVEY.md 8(b); benchmarks and tests only) ----------
+extern "C" int32_t demcz_set_live_spin_limit(demcz_handle* h, int32_t polls)
+{
+    if (!h || polls < 0) return DEMCZ_ERR_INVALID_ARGUMENT;
+    h->live_spin_limit = (unsigned int)polls;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_get_live_status(const demcz_handle* h, int32_t* live_enabled, int32_t* redos)
+{
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (live_enabled) *live_enabled = (h->lanes == DEMCZ_LAYOUT_SPLIT && !h->no_live && h->live_claimed) ? 1 : 0;
+    if (redos) *redos = h->live_redos;
+    return DEMCZ_OK;
 }
 
 extern "C" int32_t demcz_set_kernel_timing(demcz_handle* h, int32_t enabled)

@@ -88,6 +88,7 @@ struct WindowParams {
     int32_t next_ngen;
     int32_t consumer_blocks; // workgroups [0, consumer_blocks) consume, the rest produce
     unsigned int* live_err;  // LIVE launches: set when a row another wave should have appended never showed up
+    int32_t live_spin_limit; // LIVE launches: polls of one wait before it is given up (LIVE_SPIN_LIMIT unless a test lowers it)
 #ifdef DEMCZ_STAMPS
     unsigned long long* stamps;   // diagnostic build only (scripts/stamps.py): 8 s_memtime values per workgroup
 #endif

@@ -130,7 +130,7 @@ __device__ __forceinline__ void pcb_produce(const WindowParams& P, int64_t pb)
 // waits cannot form a cycle; all consumer workgroups are single waves and co-resident (N <= 8192:
 // at most 1024 of them on 256 CUs).  A bounded spin turns a lost row into an error word, not a hang.
 constexpr unsigned long long LIVE_SENTINEL = 0xFFF4DEADC0DE5EEDull;
-constexpr int LIVE_SPIN_LIMIT = 1 << 18;      // ~0.1-0.3 s of polling
+constexpr int LIVE_SPIN_LIMIT = 1 << 18;      // ~0.1-0.3 s of polling (the default of WindowParams::live_spin_limit)
 
 __device__ __forceinline__ double live_load(const double* p)
 {
@@ -149,7 +149,7 @@ __device__ __forceinline__ bool is_sentinel(double v) { return (unsigned long lo
 // [1] generation of the launch, [2] archive row, [3] workgroup.
 __device__ __forceinline__ bool live_poll_abandon(const WindowParams& P, int& spins, bool lane_waiting, unsigned row, int gi)
 {
-    const bool timeout = (++spins > LIVE_SPIN_LIMIT);
+    const bool timeout = (++spins >= P.live_spin_limit);
     bool abandon = timeout;
     if (!timeout && (spins & 255) == 0)
         abandon = __hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;

@@ -158,6 +158,16 @@ class HipEngine:
         self._chk(self._L.demcz_get_kernel_time(self._h, C.byref(n), C.byref(ms)))
         return int(n.value), float(ms.value)
 
+    def set_live_spin_limit(self, polls: int):
+        """Diagnostic: polls before a LIVE row wait gives up (tests force the fall-back path with 1)."""
+        self._chk(self._L.demcz_set_live_spin_limit(self._h, C.c_int32(int(polls))))
+
+    def live_status(self):
+        """Diagnostic: (LIVE launches in use, number of fall-backs to one launch per K-window)."""
+        on, redos = C.c_int32(0), C.c_int32(0)
+        self._chk(self._L.demcz_get_live_status(self._h, C.byref(on), C.byref(redos)))
+        return bool(on.value), int(redos.value)
+
     def synchronize(self):
         self._chk(self._L.demcz_synchronize(self._h))
 

@@ -49,7 +49,7 @@ class MvNormalTarget:
         keep += [self.mu, self.W]
         cfg.mu, cfg.W, cfg.c0 = _lib.ptr(self.mu), _lib.ptr(self.W), self.c0
 
-    def oracle_spec(self):
+    def spec(self):
         return dict(kind="mvnormal", mu=self.mu, W=self.W, c0=self.c0)
 
 
@@ -68,7 +68,7 @@ class IsoQuadTarget:
         keep += [self.mu]
         cfg.mu = _lib.ptr(self.mu)
 
-    def oracle_spec(self):
+    def spec(self):
         return dict(kind="iso_quad", mu=self.mu)
 
 
@@ -91,7 +91,7 @@ class LinRegSSETarget:
         keep += [self.design, self.y]
         cfg.design, cfg.yobs, cfg.nobs = _lib.ptr(self.design), _lib.ptr(self.y), self.design.shape[0]
 
-    def oracle_spec(self):
+    def spec(self):
         return dict(kind="linreg_sse", design=self.design, y=self.y)
 
 

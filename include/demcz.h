@@ -232,6 +232,12 @@ int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_to, double 
                           int64_t every, double threshold, int64_t* g_stop, int32_t* n_checks,
                           double* rhat_max, int32_t n_max, double* rhat_last);
 
+/* ------------------------------------------------------------------------------------------------------
+ * DIAGNOSTIC entry points -- NOT part of the drop-in contract; a binding of the reference
+ * surface needs none of them.  They exist for bench.py (kernel timing), for tests (self-test of the draw
+ * arithmetic, forcing the LIVE hand-off's time-out path) and for integrators who want to look inside.
+ * ------------------------------------------------------------------------------------------------------ */
+
 /* Timing of the window kernels on the stream they are launched on: while enabled, every demcz_run call
  * brackets its back-to-back window launches with one HIP event pair (an event between two launches would
  * stall the stream being measured).  demcz_get_kernel_time synchronises, returns the number of window
@@ -245,6 +251,15 @@ int32_t demcz_get_kernel_time(demcz_handle* h, int64_t* launches, double* millis
  * check the device arithmetic against any host implementation of the spec, bit for bit. */
 int32_t demcz_selftest_draws(int32_t device_id, uint64_t seed, uint64_t chain, uint64_t blk0, int32_t n,
                              uint64_t* words, double* normals, double* logu);
+
+/* LIVE launches (split layout on one GPU: a launch runs through many K boundaries and its waves hand the appended
+ * rows to each other through the archive itself).  A wave that polls `polls` times for a row without seeing it
+ * gives up; the library then redoes everything since the last verified point with one launch per K-window and
+ * keeps the handle in that mode (results are bit-identical either way).  polls = 0 restores the default (2^18).
+ * demcz_get_live_status: *live_enabled = 1 while the handle issues LIVE launches, *redos = times it had to
+ * fall back.  Tests lower the limit to 1 to walk the fall-back path. */
+int32_t demcz_set_live_spin_limit(demcz_handle* h, int32_t polls);
+int32_t demcz_get_live_status(const demcz_handle* h, int32_t* live_enabled, int32_t* redos);
 
 #ifdef __cplusplus
 }

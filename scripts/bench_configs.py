@@ -37,7 +37,7 @@ def cpu_rows():
     M0 = w["Zinit"].shape[0]
     for label, sched in (("CPU-fair 1 thread, synchronous", 0), ("CPU-fair 1 thread, sequential (reference order)", 1)):
         Mcap = M0 + N * Gc // 10
-        prob = O.Problem(N, d, 10, Mcap, w["eps_scale"], 1, target=w["target"].oracle_spec())
+        prob = O.Problem(N, d, 10, Mcap, w["eps_scale"], 1, target=w["target"].spec())
         X = np.array(w["Zinit"][-N:], order="F"); lp = O.logp(prob, X)
         Z = np.zeros((Mcap, d), order="F"); Z[:M0] = w["Zinit"]
         t0 = time.perf_counter(); O.run(prob, X, lp, Z, M0, 1, Gc, 2.38, schedule=sched, native=True); dt = time.perf_counter() - t0
@@ -46,7 +46,7 @@ def cpu_rows():
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     for thr in sorted({min(ncores, 4), min(ncores, 8)}):
         Mcap = M0 + N * Gc // 10
-        prob = O.Problem(N, d, 10, Mcap, w["eps_scale"], 1, target=w["target"].oracle_spec())
+        prob = O.Problem(N, d, 10, Mcap, w["eps_scale"], 1, target=w["target"].spec())
         X = np.array(w["Zinit"][-N:], order="F"); lp = O.logp(prob, X)
         Z = np.zeros((Mcap, d), order="F"); Z[:M0] = w["Zinit"]
         t0 = time.perf_counter(); O.run(prob, X, lp, Z, M0, 1, Gc, 2.38, native=True, threads=thr); dt = time.perf_counter() - t0

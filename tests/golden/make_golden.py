@@ -22,7 +22,7 @@ OUT = Path(__file__).resolve().parent
 def traj(name, w, N, G, blocks, seed, gamma, temperature=None, schedule=0, K=10):
     r = oracle_sample(O, w["target"], w["Zinit"], N, K, G, blocks, w["eps_scale"], gamma, seed,
                       temperature=temperature, schedule=schedule)
-    spec = w["target"].oracle_spec()
+    spec = w["target"].spec()
     tgt = {f"target_{k}": v for k, v in spec.items() if k != "kind"}
     nb = [list(b) for b in (blocks or [range(w["d"])])]
     np.savez_compressed(OUT / f"{name}.npz", kind=spec["kind"], Zinit=w["Zinit"], eps_scale=w["eps_scale"], N=N, K=K, G=G,
@@ -49,7 +49,7 @@ def main():
 
     # (i) single block-steps with every intermediate
     w = demc.workloads.mvnormal_problem(5, 8)
-    prob = O.Problem(8, 5, 10, 80, w["eps_scale"], 31953150, blocks=[[0, 1, 2], [3], [4, 2]], target=w["target"].oracle_spec())
+    prob = O.Problem(8, 5, 10, 80, w["eps_scale"], 31953150, blocks=[[0, 1, 2], [3], [4, 2]], target=w["target"].spec())
     Z = np.zeros((80, 5), order="F")
     Z[:50] = w["Zinit"][:50]
     rows = []

@@ -7,7 +7,7 @@ def oracle_sample(O, target, Z0, N, K, G, blocks, eps, gamma, seed, temperature=
     """Oracle twin of demcz_sample's generation loop.  Returns dict(chain, log_obj, X, logp, Z, M, changed)."""
     M0, d = Z0.shape
     Mcap = M0 + -(-N * G // K)
-    prob = O.Problem(N, d, K, Mcap, eps, seed, blocks=blocks, target=target.oracle_spec())
+    prob = O.Problem(N, d, K, Mcap, eps, seed, blocks=blocks, target=target.spec())
     if X0 is None:
         X = np.array(Z0[M0 - N:], order="F") if init == "last_rows" else np.zeros((N, d), order="F")
     else:

@@ -14,7 +14,7 @@ class OracleEngine:
                  stream=None, lanes_per_chain=0):
         self.N, self.d, self.K, self.Mcap, self.Gcap = N, d, K, Mcap, Gcap
         self.prob = O.Problem(N, d, K, Mcap, eps_scale, seed, blocks=[list(b) for b in blockindex],
-                              chain_id0=chain_id0, target=target.oracle_spec())
+                              chain_id0=chain_id0, target=target.spec())
         self.chain = np.zeros((N, d, Gcap), order="F")
         self.log_obj = np.zeros((N, Gcap), order="F")
         self.changed = np.zeros(Gcap, dtype=np.int64)

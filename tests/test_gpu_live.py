@@ -1,0 +1,113 @@
+"""GPU: the in-launch row hand-off (LIVE launches of the split layout) and what happens when it fails.
+
+A LIVE launch runs through many K boundaries; its waves hand the appended rows to each other through the
+archive itself (demcz_kernels_rec.h).  A wave that does not see a row within its poll limit gives up and
+flags the launch; the library then redoes everything since the last verified point with one launch per
+K-window and keeps the handle in that mode.  These tests lower the poll limit to 1 (diagnostic entry point
+demcz_set_live_spin_limit), so that the very first wait anywhere times out, and require the results to be
+the oracle's, bit for bit, all the same."""
+import numpy as np
+import pytest
+
+from helpers import oracle_sample
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(demc, w, N, d, K, G, seed, lanes=0):
+    M0 = w["Zinit"].shape[0]
+    e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K + 1), Gcap=G, blockindex=[range(d)],
+                       eps_scale=w["eps_scale"], seed=seed, target=w["target"], lanes_per_chain=lanes)
+    e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+    return e
+
+
+@pytest.mark.parametrize("K", [1, 3])
+def test_forced_handoff_timeout_is_redone_bit_exact(demc, oracle, K):
+    """demcz_run + a synchronising call: poll limit 1 makes a wave give up at its first wait (K = 1: every
+    generation draws from rows appended one generation earlier, so there are waits at once)."""
+    N, d, G, seed = 512, 5, 120, 41
+    w = demc.workloads.mvnormal_problem(d, N)
+    e = _engine(demc, w, N, d, K, G, seed)
+    assert e.info()["lanes_per_chain"] == 100
+    e.set_live_spin_limit(1)
+    e.run(1, 50, w["gamma"])
+    e.run(51, G, w["gamma"])                       # two calls in the log: both are redone
+    e.synchronize()                                # verifies, rolls back, redoes
+    on, redos = e.live_status()
+    assert redos == 1 and not on, "the poll limit of 1 must have forced the fall-back"
+    chain, lobj = e.get_history(1, G)
+    X, lp, Z, M = e.get_state()
+    # the handle keeps working, one launch per K-window from now on
+    e.set_live_spin_limit(0)
+    e.close()
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed)
+    assert np.array_equal(chain, ref["chain"]) and np.array_equal(lobj, ref["log_obj"])
+    assert np.array_equal(X, ref["X"]) and np.array_equal(lp, ref["logp"]) and M == ref["M"] and np.array_equal(Z, ref["Z"])
+
+
+def test_forced_handoff_timeout_inside_run_checked(demc, oracle):
+    """demcz_run_checked never returns statistics of a voided slab: the whole call is redone, and the trace,
+    the stop decision and the state are those of a run that never used LIVE launches."""
+    N, d, K, G, every, seed = 256, 5, 2, 400, 100, 43
+    w = demc.workloads.mvnormal_problem(d, N)
+    a = _engine(demc, w, N, d, K, G, seed)
+    a.set_live_spin_limit(1)
+    ga, ta, la = a.run_checked(1, G, w["gamma"], every, 0.0)
+    on, redos = a.live_status()
+    assert redos == 1 and not on
+    cha, loa = a.get_history(1, G)
+    Xa, lpa, Za, Ma = a.get_state()
+    a.close()
+    b = _engine(demc, w, N, d, K, G, seed)          # undisturbed twin
+    gb, tb, lb = b.run_checked(1, G, w["gamma"], every, 0.0)
+    onb, redosb = b.live_status()
+    assert redosb == 0 and onb
+    chb, lob = b.get_history(1, G)
+    Xb, lpb, Zb, Mb = b.get_state()
+    b.close()
+    assert ga == gb and np.array_equal(ta, tb) and np.array_equal(la, lb)
+    assert np.array_equal(cha, chb) and np.array_equal(loa, lob) and np.array_equal(Za, Zb) and Ma == Mb
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed)
+    assert np.array_equal(cha, ref["chain"]) and np.array_equal(Za, ref["Z"])
+
+
+def test_one_live_handle_per_device(demc, oracle):
+    """Two handles on one GPU: the first keeps the device's LIVE slot, the second runs one launch per
+    K-window (its consumer waves could otherwise starve the first one's); both are bit-exact, and the slot
+    is free again once the first is destroyed."""
+    N, d, K, G = 256, 5, 5, 60
+    w = demc.workloads.mvnormal_problem(d, N)
+    a = _engine(demc, w, N, d, K, G, 7)
+    b = _engine(demc, w, N, d, K, G, 8)
+    a.run(1, G, w["gamma"])
+    b.run(1, G, w["gamma"])
+    a.synchronize(); b.synchronize()
+    assert a.live_status()[0] and not b.live_status()[0]
+    assert a.info()["window_launches"] < b.info()["window_launches"]
+    cha, _ = a.get_history(1, G)
+    chb, _ = b.get_history(1, G)
+    a.close()
+    c = _engine(demc, w, N, d, K, G, 9)
+    c.run(1, G, w["gamma"]); c.synchronize()
+    assert c.live_status()[0]
+    b.close(); c.close()
+    for ch, seed in ((cha, 7), (chb, 8)):
+        ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed)
+        assert np.array_equal(ch, ref["chain"])
+
+
+def test_discarded_speculative_slab_leaves_no_trace(demc):
+    """demcz_run_checked with a threshold runs the next slab ahead of the decision and discards it on a stop:
+    afterwards the history beyond g_stop reads as never written (zeros, demcz.jl:24), not as stale data."""
+    N, d, K, every = 256, 5, 10, 200
+    G = 5 * every
+    w = demc.workloads.mvnormal_problem(d, N)
+    e = _engine(demc, w, N, d, K, G, 3)
+    g_stop, trace, last = e.run_checked(1, G, w["gamma"], every, 3.0)      # a generous threshold: stops early
+    assert g_stop < G and trace[-1] < 3.0
+    ch, lo = e.get_history(g_stop + 1, min(G, g_stop + every))
+    assert not ch.any() and not lo.any()
+    ch0, _ = e.get_history(1, g_stop)
+    assert ch0.any()
+    e.close()

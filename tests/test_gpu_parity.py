@@ -111,7 +111,7 @@ def test_device_statistics_vs_oracle(demc, oracle):
         mean, cov = e.mean_cov(a, b)
         om, oc = oracle.mean_cov_chain(mc.chain[:, :, a - 1:b])
         assert np.allclose(mean, om, rtol=1e-12) and np.allclose(cov, oc, rtol=1e-9, atol=1e-18)
-    lp0 = oracle.logp(oracle.Problem(N, d, 10, 10, w["eps_scale"], 2, target=w["target"].oracle_spec()), w["Zinit"][-N:])
+    lp0 = oracle.logp(oracle.Problem(N, d, 10, 10, w["eps_scale"], 2, target=w["target"].spec()), w["Zinit"][-N:])
     prev = np.concatenate([lp0[:, None], mc.log_obj[:, :-1]], axis=1)
     assert np.array_equal(e.get_changed(1, G), (mc.log_obj != prev).sum(axis=0))
     runner.close()
@@ -149,7 +149,7 @@ def test_host_closure_mode_equals_device_target(demc, oracle):
     trajectory equals the device-target run bit for bit."""
     d, N, G = 6, 24, 25
     w = demc.workloads.mvnormal_problem(d, N)
-    prob = oracle.Problem(1, d, 10, 10, w["eps_scale"], 0, target=w["target"].oracle_spec())
+    prob = oracle.Problem(1, d, 10, 10, w["eps_scale"], 0, target=w["target"].spec())
     closure = lambda x: float(oracle.logp(prob, x[None, :])[0])      # noqa: E731
     a, Za = demc.demcz_sample(closure, w["Zinit"], N, 10, G, 3, BLOCKS_D6, w["eps_scale"], 2.38, verbose=False, seed=3)
     b, Zb = demc.demcz_sample(w["target"], w["Zinit"], N, 10, G, 3, BLOCKS_D6, w["eps_scale"], 2.38, verbose=False, seed=3)
@@ -332,7 +332,7 @@ def test_no_history_handle_and_closure_anneal(demc, oracle):
         e.get_history(1, G)
     e.close()
     w = demc.workloads.iso_quad_problem(10, 12)
-    prob = oracle.Problem(1, 10, 10, 10, w["eps_scale"], 0, target=w["target"].oracle_spec())
+    prob = oracle.Problem(1, 10, 10, 10, w["eps_scale"], 0, target=w["target"].spec())
     closure = lambda x: float(oracle.logp(prob, x[None, :])[0])      # noqa: E731
     args = (w["Zinit"], 12, 10, 30, 1, [range(10)], w["eps_scale"], 2.38)
     kw = dict(verbose=False, T0=2, TN=1e-2, seed=8, adaptγ={"adapt_every": 10})

@@ -104,7 +104,7 @@ def test_anneal_schedule_and_gamma_adaptation(oracle):
     # replay with the oracle, adapting gamma by the reference's formula
     M0 = w["Zinit"].shape[0]
     Mcap = M0 + -(-N * G // 10)
-    prob = oracle.Problem(N, d, 10, Mcap, w["eps_scale"], 6, target=w["target"].oracle_spec())
+    prob = oracle.Problem(N, d, 10, Mcap, w["eps_scale"], 6, target=w["target"].spec())
     X = np.array(w["Zinit"][M0 - N:], order="F")
     lp = oracle.logp(prob, X)
     Zo = np.zeros((Mcap, d), order="F")

@@ -100,7 +100,7 @@ def test_index_draw_definition(oracle):
     import demc_jl_amd as demc
     w = demc.workloads.mvnormal_problem(d, 8)
     for M in (2, 3, 50, 1000003):
-        prob = oracle.Problem(N, d, 10, max(M, 8), w["eps_scale"], 5, target=w["target"].oracle_spec())
+        prob = oracle.Problem(N, d, 10, max(M, 8), w["eps_scale"], 5, target=w["target"].spec())
         Z = np.zeros((prob.Mcap, d), order="F")
         cnt = np.zeros((min(M, 50), min(M, 50)))
         for g in range(1, 400):
@@ -121,5 +121,5 @@ def test_blocks_per_generation(oracle):
     w = demc.workloads.mvnormal_problem(6, 8)
     for blocks, expect in [([range(6)], 1 + 3 + 1), ([[0], [1, 2], [3, 4, 5]], (1 + 1 + 1) + (1 + 1 + 1) + (1 + 2 + 1)),
                            ([[5, 0, 3]], 1 + 2 + 1)]:
-        prob = oracle.Problem(8, 6, 10, 100, w["eps_scale"], 1, blocks=blocks, target=w["target"].oracle_spec())
+        prob = oracle.Problem(8, 6, 10, 100, w["eps_scale"], 1, blocks=blocks, target=w["target"].spec())
         assert prob.blocks_per_generation() == expect

@@ -74,7 +74,7 @@ def test_openmp_loop_is_bit_identical(oracle):
     outs = []
     for thr in (0, 1, 3):
         Mcap = M0 + N * G // K
-        prob = oracle.Problem(N, d, K, Mcap, w["eps_scale"], 7, target=w["target"].oracle_spec())
+        prob = oracle.Problem(N, d, K, Mcap, w["eps_scale"], 7, target=w["target"].spec())
         X = np.array(w["Zinit"][-N:], order="F"); lp = oracle.logp(prob, X)
         Z = np.zeros((Mcap, d), order="F"); Z[:M0] = w["Zinit"]
         M, chain, lobj, changed = oracle.run(prob, X, lp, Z, M0, 1, G, 2.38, threads=thr)
