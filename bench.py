@@ -143,6 +143,10 @@ def main():
     ap.add_argument("--append-lag", type=int, default=-1,
                     help="demcz_set_append_lag batches; default 0 on one GPU (the reference's schedule), 10 when sharded "
                          "(the K-boundary all-gather overlaps the next windows)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the rendezvous (nccl = RCCL; gloo with --dry-run)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="everything up to the first GPU call: arguments, rendezvous, sharding plan, the exchange of the 128-byte "
+                         "communicator id -- printed as JSON by rank 0 (lets a host without GPUs check the N > 1 launch path)")
     args = ap.parse_args()
 
     import torch
@@ -158,13 +162,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if args.steps < 1 or args.warmup < 0 or args.slab_generations < 4:
         raise SystemExit("need --steps >= 1, --warmup >= 0, --slab-generations >= 4")
-    torch.cuda.set_device(local_rank)
+    if not args.dry_run:
+        torch.cuda.set_device(local_rank)
     sharding = None
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dry_run:
+            dist.init_process_group(args.backend)
+        else:
+            dist.init_process_group(args.backend, device_id=torch.device("cuda", local_rank))
         from demc_jl_amd.dist import torch_sharding
         sharding = torch_sharding(mode="rccl")
 
@@ -179,6 +187,27 @@ def main():
     G = (W + S) * every
     thr, seed = 1.05, 31953150
     w = demc.workloads.mvnormal_problem(d, N)
+    if args.dry_run:
+        # what make_runner / demcz_comm_init would be given, without touching a GPU
+        X, logp = demc.initial_state(w["target"], w["Zinit"], N, G, K, None, "last_rows")
+        plan = {"world": world, "rank": rank, "local_rank": local_rank, "chains_total": N, "chains_per_gpu": n_loc,
+                "chain_id0": rank * n_loc, "append_lag": lag, "generations": G, "warmup_slabs": W, "timed_slabs": S,
+                "Mcap": int(w["Zinit"].shape[0] + -(-N * G // K)), "X_shard_shape": list(X[rank * n_loc:(rank + 1) * n_loc].shape),
+                "mode": sharding.mode if sharding else "single GPU"}
+        if sharding is not None:
+            uid = bytes(range(128)) if rank == 0 else None         # stands in for demcz_comm_unique_id's ncclUniqueId
+            got = sharding.broadcast_bytes(uid)
+            plan["unique_id_ok"] = (got == bytes(range(128)))
+            parts = sharding.all_gather(np.full(3, float(rank)))
+            plan["all_gather_ranks"] = [float(p[0]) for p in parts]
+            plans = [None] * world
+            dist.all_gather_object(plans, plan)
+            if rank == 0:
+                print(json.dumps({"dry_run": True, "ranks": plans}))
+            dist.destroy_process_group()
+        else:
+            print(json.dumps({"dry_run": True, "ranks": [plan]}))
+        return
     stream = torch.cuda.Stream()
     X, logp = demc.initial_state(w["target"], w["Zinit"], N, G, K, None, "last_rows")
     runner = demc.make_runner(w["target"], w["Zinit"], N, K, G, [range(d)], w["eps_scale"], X, logp, seed=seed,

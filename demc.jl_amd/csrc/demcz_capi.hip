@@ -109,7 +109,9 @@ struct demcz_handle {
     int32_t live_redos = 0;
     struct RecDesc { bool valid = false; int64_t g_first = 0, M = 0, rows = 0; int32_t ngen = 0, boff = 0; } rec_desc[2];
     // multi-GPU
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;          // collectives on the compute stream: synchronous all-gather, R-hat all-reduces
+    ncclComm_t comm_side = nullptr;     // its duplicate (ncclCommSplit) for the batched all-gathers on the side stream: operations
+                                        // of ONE communicator are serialised by RCCL whatever stream they are enqueued on
     int nranks = 1, rank = 0;
     double* d_gather = nullptr;
     // deferred visibility of appended rows (demcz_set_append_lag): M counts the rows proposals may
@@ -213,6 +215,7 @@ static void free_all(demcz_handle* h)
     if (h->spec_ev) (void)hipEventDestroy(h->spec_ev);
     if (h->diag_ev) (void)hipEventDestroy(h->diag_ev);
     if (h->diag_stream) (void)hipStreamDestroy(h->diag_stream);
+    if (h->comm_side) (void)ncclCommDestroy(h->comm_side);
     if (h->comm) (void)ncclCommDestroy(h->comm);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
 }
@@ -880,7 +883,7 @@ static int32_t exchange_batch(demcz_handle* h)
     HIPCHK(h, hipEventRecord(ready, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->comm_stream, ready, 0));
     HIPCHK(h, hipEventDestroy(ready));
-    NCCLCHK(h, ncclAllGather(h->d_send[buf], h->d_recv[buf], (size_t)N * d * cnt, ncclDouble, h->comm, h->comm_stream));
+    NCCLCHK(h, ncclAllGather(h->d_send[buf], h->d_recv[buf], (size_t)N * d * cnt, ncclDouble, h->comm_side, h->comm_stream));
     const int64_t tot = N * d * cnt * h->nranks;
     hipLaunchKernelGGL(append_batch_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->comm_stream, h->dZ, h->ZS,
                        h->batch_base, (const double*)h->d_recv[buf], N, h->nranks, cnt, d);
@@ -1741,6 +1744,8 @@ extern "C" int32_t demcz_set_append_lag(demcz_handle* h, int32_t batches)
     if (h->comm && batches > 0) {
         // side stream + double-buffered batch slabs: [E][d][n_loc] out, [R][E][d][n_loc] in
         if (!h->comm_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+        // a communicator of its own for the side stream (collective over the parent: every rank makes this call)
+        if (!h->comm_side) NCCLCHK(h, ncclCommSplit(h->comm, 0, h->rank, &h->comm_side, nullptr));
         const size_t one = (size_t)h->cfg.N * h->cfg.d * sizeof(double);
         HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipStreamSynchronize(h->comm_stream));
@@ -2037,6 +2042,36 @@ extern "C" int32_t demcz_get_live_status(const demcz_handle* h, int32_t* live_en
     if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
     if (live_enabled) *live_enabled = (h->lanes == DEMCZ_LAYOUT_SPLIT && !h->no_live && h->live_claimed) ? 1 : 0;
     if (redos) *redos = h->live_redos;
+    return DEMCZ_OK;
+}
+
+// The scatter kernels of a sharded run -- append_gathered_kernel (synchronous exchange) and append_batch_kernel
+// (batched exchange) -- applied to a slab the CALLER built in the layout an all-gather over R ranks delivers,
+// [R][cnt][d][n_loc] with n_loc = this handle's N: lets a one-GPU box check the index arithmetic for R > 1.
+extern "C" int32_t demcz_debug_append_slab(demcz_handle* h, const double* slab, int32_t R, int32_t cnt, int32_t batched)
+{
+    if (!h || !slab || R < 1 || cnt < 1 || (!batched && cnt != 1)) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (!h->has_state) return fail(h, DEMCZ_ERR_STATE, "demcz_debug_append_slab: no state");
+    if (h->lag != 0 || !h->pending.empty()) return fail(h, DEMCZ_ERR_STATE, "demcz_debug_append_slab: rows are pending");
+    const int64_t N = h->cfg.N, rows = N * R * cnt;
+    const int d = h->cfg.d;
+    if (h->M_app + rows > h->cfg.Mcap) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_debug_append_slab: Z capacity exceeded");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    int32_t rc = ensure_scratch(h, rows * d);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_scratch, slab, (size_t)rows * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const int64_t tot = rows * d;
+    if (batched)
+        hipLaunchKernelGGL(append_batch_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->dZ, h->ZS,
+                           h->M_app, (const double*)h->d_scratch, N, (int)R, (int)cnt, d);
+    else
+        hipLaunchKernelGGL(append_gathered_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->dZ, h->ZS,
+                           h->M_app, (const double*)h->d_scratch, N, (int)R, d);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->M_app += rows;
+    h->M = h->M_app;
+    h->rec_desc[0].valid = h->rec_desc[1].valid = false;
     return DEMCZ_OK;
 }
 

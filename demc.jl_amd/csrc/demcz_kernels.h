@@ -599,7 +599,7 @@ __global__ void __launch_bounds__(256) changed_from_history_kernel(const double*
     const double* cur = logobj + N * s;
     const double* prev = (s == 0) ? lp_origin : logobj + N * (s - 1);
     int k = 0;
-    for (int64_t c = threadIdx.x; c < N; c += 256) k += (cur[c] != prev[c]) ? 1 : 0;
+    for (int64_t c = threadIdx.x; c < N; c += 256) k += ((cur[c] - prev[c]) != 0.0) ? 1 : 0;   // diff(.) .!= 0: a NaN difference counts
     cnt[threadIdx.x] = k;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
@@ -619,7 +619,7 @@ __global__ void changed_per_chain_kernel(const double* logobj, int64_t N, int64_
     double prev = logobj[c + N * s0];
     for (int64_t t = 1; t < w; ++t) {
         double cur = logobj[c + N * (s0 + t)];
-        k += (cur != prev) ? 1 : 0;
+        k += ((cur - prev) != 0.0) ? 1 : 0;      // diff(.) .!= 0 (utils.jl:61): a NaN difference counts
         prev = cur;
     }
     ratio[c] = (double)k / (double)(w - 1);

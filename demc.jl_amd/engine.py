@@ -241,6 +241,13 @@ class HipEngine:
             raise ValueError("rows must be nrows x d")
         self._chk(self._L.demcz_append_rows(self._h, _lib.ptr(rows), rows.shape[0], rows.shape[0]))
 
+    def debug_append_slab(self, slab, R, cnt, batched):
+        """Diagnostic: run the sharded exchange's scatter kernel on a caller-built [R][cnt][d][N] slab."""
+        slab = _lib.f64(slab)
+        if slab.size != R * cnt * self.d * self.N:
+            raise ValueError("slab must hold R*cnt*d*N doubles")
+        self._chk(self._L.demcz_debug_append_slab(self._h, _lib.ptr(slab), int(R), int(cnt), 1 if batched else 0))
+
     def export_current_device(self, device_ptr: int):
         self._chk(self._L.demcz_export_current_device(self._h, C.c_void_p(device_ptr)))
 

@@ -46,6 +46,15 @@ class MC:
     log_obj: np.ndarray          # N x G       log obj along the chain
     Xcurrent: np.ndarray         # N x d       population
     log_objcurrent: np.ndarray   # N           log obj values
+    # (not in the reference, which draws from a global RNG:) generations every chain's Philox stream has consumed when
+    # this result was made.  None = the length of `chain` (right for any result that carries its whole history); a
+    # checkpoint, which keeps only the last generation, records the true count here so that `prevrun=` resumes the
+    # streams where they stopped instead of replaying them.
+    rng_generations: Optional[int] = None
+
+    @property
+    def generations_drawn(self):
+        return int(self.chain.shape[2]) if self.rng_generations is None else int(self.rng_generations)
 
 
 @dataclass
@@ -299,6 +308,12 @@ def make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp,
     return _Runner(engines, sh, K, N, d, append_lag=append_lag)
 
 
+def _generations_drawn(prevrun):
+    """Generations the chains' random streams have consumed by the end of `prevrun` (see MC.rng_generations)."""
+    n = getattr(prevrun, "rng_generations", None)
+    return int(prevrun.chain.shape[2]) if n is None else int(n)
+
+
 def initial_state(logobj, Zmat, N, Ngeneration, K, prevrun, init):
     """demcz.jl:13-22.  Returns (X, logp or None)."""
     M0, d = Zmat.shape
@@ -338,7 +353,7 @@ def _run_generations(runner, logobj, g_from, g_to, gamma, Nblocks, temperature=N
         eng.end_generation(g)
 
 
-def _finish(runner, prevrun, G, padded_Z, Mcap):
+def _finish(runner, prevrun, G, padded_Z, Mcap, rng_offset=0):
     chain, lobj = runner.history(1, G)
     X, lp, Z, M = runner.state()
     if padded_Z:
@@ -348,7 +363,7 @@ def _finish(runner, prevrun, G, padded_Z, Mcap):
     if prevrun is not None:                                                          # demcz.jl:58-59
         chain = np.asfortranarray(np.concatenate([prevrun.chain, chain], axis=2))
         lobj = np.asfortranarray(np.concatenate([prevrun.log_obj, lobj], axis=1))
-    return MC(chain, lobj, X, lp), Z
+    return MC(chain, lobj, X, lp, rng_generations=int(rng_offset) + int(G)), Z
 
 
 def print_status(runner, ig, printlast=500):
@@ -398,7 +413,7 @@ def demcz_sample(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
     autostop = _sym(autostop)
     X, logp = initial_state(logobj, Zmat, N, Ngeneration, K, prevrun, init)
     if rng_offset is None:       # a resumed run continues the chains' random streams where prevrun stopped
-        rng_offset = 0 if prevrun is None else prevrun.chain.shape[2]
+        rng_offset = 0 if prevrun is None else _generations_drawn(prevrun)
     runner = make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp, seed=seed,
                           sharding=sharding, device_id=device_id, engine_factory=engine_factory,
                           lanes_per_chain=lanes_per_chain, stream=stream, rng_offset=rng_offset, append_lag=append_lag)
@@ -415,7 +430,7 @@ def demcz_sample(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
                                     np.max(runner.rhat(ig - autostop_every + 1, ig)) < autostop_Rhat):
                 if runner.accept_ratio_mean(ig - autostop_every + 1, ig) < 0.1:       # demcz.jl:42,44-46
                     print("Warning: accept ratio below 10% on average")
-                res = _finish(runner, prevrun, ig, padded_Z, Mcap)                  # demcz.jl:47-52
+                res = _finish(runner, prevrun, ig, padded_Z, Mcap, rng_offset)                  # demcz.jl:47-52
                 return (res + (runner,)) if return_runner else res
         while ig < Ngeneration:                                                     # demcz.jl:30
             stops = [Ngeneration]
@@ -434,9 +449,9 @@ def demcz_sample(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
                     # demcz.jl:42,44-46 (intent: per-chain ratio over log_obj[:, window])
                     if runner.accept_ratio_mean(ig - autostop_every + 1, ig) < 0.1:
                         print("Warning: accept ratio below 10% on average")
-                    res = _finish(runner, prevrun, ig, padded_Z, Mcap)              # demcz.jl:47-52
+                    res = _finish(runner, prevrun, ig, padded_Z, Mcap, rng_offset)              # demcz.jl:47-52
                     return (res + (runner,)) if return_runner else res
-        res = _finish(runner, prevrun, Ngeneration, padded_Z, Mcap)                 # demcz.jl:58-62
+        res = _finish(runner, prevrun, Ngeneration, padded_Z, Mcap, rng_offset)                 # demcz.jl:58-62
         return (res + (runner,)) if return_runner else res
     finally:
         if not return_runner:
@@ -471,7 +486,7 @@ def demcz_anneal(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
         eps_scale = 1e-4 * np.ones(d)
     X, logp = initial_state(logobj, Zmat, N, Ngeneration, K, prevrun, init)
     if rng_offset is None:
-        rng_offset = 0 if prevrun is None else prevrun.chain.shape[2]
+        rng_offset = 0 if prevrun is None else _generations_drawn(prevrun)
     runner = make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp, seed=seed,
                           sharding=sharding, device_id=device_id, engine_factory=engine_factory,
                           lanes_per_chain=lanes_per_chain, stream=stream, rng_offset=rng_offset, append_lag=append_lag)
@@ -506,6 +521,6 @@ def demcz_anneal(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
                     γ = max(adapt["minγ"], γ * 0.5)
                 elif accept_ratio > 0.5:
                     γ = min(adapt["maxγ"], γ * 1.5)
-        return _finish(runner, prevrun, Ngeneration, padded_Z, Mcap)                # demcz_anneal.jl:60-64
+        return _finish(runner, prevrun, Ngeneration, padded_Z, Mcap, rng_offset)                # demcz_anneal.jl:60-64
     finally:
         runner.close()

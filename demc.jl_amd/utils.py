@@ -79,16 +79,20 @@ def convergence_check(chain, log_obj, figure_path=None, verbose=True, parnames=N
     return acc, Rhat
 
 
-def save_checkpoint(path, mc: MC, Z, generations_done, seed, opts=None):
-    """Everything a resumed run needs: final states, archive, how far the RNG streams have advanced."""
+def save_checkpoint(path, mc: MC, Z, generations_done=None, seed=0, opts=None):
+    """Everything a resumed run needs: final states, archive, how far the RNG streams have advanced
+    (`generations_done`; default: what `mc` itself records, MC.generations_drawn)."""
+    if generations_done is None:
+        generations_done = mc.generations_drawn
     np.savez_compressed(path, Xcurrent=mc.Xcurrent, log_objcurrent=mc.log_objcurrent, last_chain=mc.chain[:, :, -1:],
                         last_log_obj=mc.log_obj[:, -1:], Z=Z, generations_done=int(generations_done), seed=int(seed))
 
 
 def load_checkpoint(path):
-    """Returns (prevrun, Z, generations_done, seed): pass ``prevrun=prevrun, rng_offset=generations_done,
-    seed=seed`` to ``demcz_sample`` to continue the same stream."""
+    """Returns (prevrun, Z, generations_done, seed): pass ``prevrun=prevrun, seed=seed`` to ``demcz_sample`` to continue
+    the same streams -- the returned ``prevrun`` keeps only the last generation of the history but records
+    ``generations_done`` (MC.rng_generations), so the resumed run draws what an uninterrupted one would."""
     f = np.load(path)
     prev = MC(np.asfortranarray(f["last_chain"]), np.asfortranarray(f["last_log_obj"]), np.asfortranarray(f["Xcurrent"]),
-              np.array(f["log_objcurrent"]))
+              np.array(f["log_objcurrent"]), rng_generations=int(f["generations_done"]))
     return prev, np.asfortranarray(f["Z"]), int(f["generations_done"]), int(f["seed"])

@@ -261,6 +261,13 @@ int32_t demcz_selftest_draws(int32_t device_id, uint64_t seed, uint64_t chain, u
 int32_t demcz_set_live_spin_limit(demcz_handle* h, int32_t polls);
 int32_t demcz_get_live_status(const demcz_handle* h, int32_t* live_enabled, int32_t* redos);
 
+/* The scatter step of the sharded K-boundary exchange on caller data: `slab` (host) has the layout an all-gather
+ * over R ranks delivers, [R][cnt][d][n_loc] doubles with n_loc = the handle's N; its R*cnt*n_loc rows are appended
+ * in the order an unsharded run appends them (boundary, then rank, then chain).  batched = 0: the kernel of the
+ * synchronous exchange (cnt must be 1); 1: the kernel of the batched one.  Lets a one-GPU machine check the R > 1
+ * index arithmetic that otherwise only runs behind ncclAllGather on R GPUs. */
+int32_t demcz_debug_append_slab(demcz_handle* h, const double* slab, int32_t R, int32_t cnt, int32_t batched);
+
 #ifdef __cplusplus
 }
 #endif

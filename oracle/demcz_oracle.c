@@ -198,6 +198,23 @@ static uint64_t mulhi64(uint64_t a, uint64_t b)
     return (uint64_t)(((unsigned __int128)a * b) >> 64);
 }
 
+/* The two archive rows of a block-step from the two words of its first Philox block (0-based):
+ * i1 ~ U{0..M-1}, i2 ~ U of the other M-1 -- the O(1) equivalent of collect(1:M) / rand / deleteat! / rand
+ * (demcz.jl:176-179). */
+static void draw_rows(uint64_t r1, uint64_t r2, int64_t M, uint64_t* i1, uint64_t* i2)
+{
+    *i1 = mulhi64(r1, (uint64_t)M);
+    uint64_t j = mulhi64(r2, (uint64_t)(M - 1));
+    *i2 = j + (j >= *i1 ? 1 : 0);
+}
+
+ORACLE_API void oracle_draw_rows(uint64_t seed, uint64_t chain, uint64_t blk, int64_t M, uint64_t out[2])
+{
+    uint64_t r1, r2;
+    draw_block(seed, chain, blk, &r1, &r2);
+    draw_rows(r1, r2, M, &out[0], &out[1]);
+}
+
 /* ------------------------------------------------------------------------------------------
  * Targets (the user log-densities the BASELINE configs exercise; NOT in the reference's
  * src/).
@@ -320,9 +337,8 @@ static int block_step(const oracle_problem* p, const double* Z, int64_t M, uint6
     const int npairs = (nn + 1) / 2;
     uint64_t r1, r2;
     draw_block(p->seed, chain, blk0, &r1, &r2);
-    uint64_t i1 = mulhi64(r1, (uint64_t)M);
-    uint64_t j = mulhi64(r2, (uint64_t)(M - 1));
-    uint64_t i2 = j + (j >= i1 ? 1 : 0);
+    uint64_t i1, i2;
+    draw_rows(r1, r2, M, &i1, &i2);
     double zn[256];
     for (int pr = 0; pr < npairs; ++pr) {
         draw_block(p->seed, chain, blk0 + 1 + (uint64_t)pr, &r1, &r2);
@@ -413,7 +429,7 @@ ORACLE_API int oracle_demcz_run(const oracle_problem* p, double* X, double* logp
             }
             for (int t = 0; t < d; ++t) X[c + N * t] = x[t];
             logp[c] = lp;
-            if (lp != lp_before) ++changed;
+            if ((lp - lp_before) != 0.0) ++changed;      /* diff(log_obj) .!= 0: a NaN difference counts (demcz.jl:42) */
             if (chain_out)
                 for (int t = 0; t < d; ++t) chain_out[c + N * (t + (int64_t)d * gi)] = x[t];
             if (logobj_out) logobj_out[c + N * gi] = lp;
@@ -466,7 +482,7 @@ ORACLE_API int oracle_demcz_run_omp(const oracle_problem* p, double* X, double* 
             }
             for (int t = 0; t < d; ++t) X[c + N * t] = x[t];
             logp[c] = lp;
-            if (lp != lp_before) ++changed;
+            if ((lp - lp_before) != 0.0) ++changed;      /* diff(log_obj) .!= 0: a NaN difference counts (demcz.jl:42) */
             if (chain_out)
                 for (int t = 0; t < d; ++t) chain_out[c + N * (t + (int64_t)d * gi)] = x[t];
             if (logobj_out) logobj_out[c + N * gi] = lp;
@@ -551,7 +567,7 @@ ORACLE_API void oracle_changed_per_chain(const double* log_obj, int64_t N, int64
     for (int64_t c = 0; c < N; ++c) {
         int64_t k = 0;
         for (int64_t g = 1; g < G; ++g)
-            if (log_obj[c + N * g] != log_obj[c + N * (g - 1)]) ++k;
+            if ((log_obj[c + N * g] - log_obj[c + N * (g - 1)]) != 0.0) ++k;     /* diff(.) .!= 0, utils.jl:61 */
         out[c] = k;
     }
 }

@@ -131,6 +131,13 @@ def draw_block(seed, chain, blk):
     return int(o[0]), int(o[1])
 
 
+def draw_rows(seed, chain, blk, M):
+    """0-based archive rows (i1, i2) a block-step whose first Philox block is `blk` draws from M rows."""
+    o = (C.c_uint64 * 2)()
+    lib().oracle_draw_rows(C.c_uint64(seed), C.c_uint64(chain), C.c_uint64(blk), C.c_int64(M), o)
+    return int(o[0]), int(o[1])
+
+
 def dm_log(x):
     L = lib()
     x = np.asarray(x, dtype=np.float64)

@@ -84,3 +84,29 @@ def test_two_ranks_deferred_exchange_equal_single_process(tmp_path):
         p = np.load(tmp_path / f"rank{r}.npz")
         assert p["chain"].shape[2] == G and np.array_equal(p["Z"], Z)
         assert np.array_equal(p["chain"], mc.chain[r * N // 2:(r + 1) * N // 2])
+
+
+def test_bench_multi_gpu_launch_path_dry_run():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per GPU) up to the first GPU
+    call: argument handling, rendezvous, the sharding plan (equal shards in rank order, global chain ids), the
+    broadcast of the 128-byte communicator id and an all-gather -- over gloo, on a host without GPUs."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "0",
+           "--dry-run", "--backend", "gloo"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["dry_run"] and len(out["ranks"]) == 2
+    for rk, p in enumerate(out["ranks"]):
+        assert (p["world"], p["rank"], p["chains_total"], p["chains_per_gpu"], p["chain_id0"]) == (2, rk, 2048, 1024, rk * 1024)
+        assert p["append_lag"] == 10 and p["mode"] == "rccl" and p["unique_id_ok"] and p["all_gather_ranks"] == [0.0, 1.0]
+        assert p["warmup_slabs"] == 1 and p["timed_slabs"] == 3 and p["generations"] == 4000      # one untimed slab always runs
+        assert p["X_shard_shape"] == [1024, 5] and p["Mcap"] == 2048 + 2048 * 400
+    # a world size that does not match --gpus is refused before anything else happens
+    bad = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                         timeout=120, env={k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}, cwd=str(ROOT))
+    assert bad.returncode != 0 and "torch.distributed.run" in (bad.stderr + bad.stdout)

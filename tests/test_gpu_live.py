@@ -111,3 +111,32 @@ def test_discarded_speculative_slab_leaves_no_trace(demc):
     ch0, _ = e.get_history(1, g_stop)
     assert ch0.any()
     e.close()
+
+
+@pytest.mark.parametrize("R,cnt,batched", [(2, 1, False), (8, 1, False), (2, 1, True), (2, 3, True), (8, 4, True), (3, 2, True)])
+def test_sharded_scatter_kernels_for_R_ranks(demc, R, cnt, batched):
+    """append_gathered_kernel / append_batch_kernel with R > 1 (otherwise reachable only behind ncclAllGather on R
+    GPUs): a slab in the all-gather's layout [R][cnt][d][n_loc] must land in the archive in the order an unsharded run
+    appends -- boundary, then rank, then chain (demcz.jl:88-91 for N = R * n_loc chains)."""
+    n_loc, d = 37, 5
+    w = demc.workloads.mvnormal_problem(d, n_loc)
+    M0 = w["Zinit"].shape[0]
+    e = demc.HipEngine(N=n_loc, d=d, K=10, Mcap=M0 + 2 * R * cnt * n_loc, Gcap=0, blockindex=[range(d)], eps_scale=w["eps_scale"],
+                       seed=1, target=w["target"])
+    e.set_state(w["Zinit"][-n_loc:], None, w["Zinit"])
+    rng = np.random.default_rng(R * 100 + cnt)
+    # states[s][r] = the n_loc x d block rank r holds at boundary s
+    states = rng.standard_normal((cnt, R, n_loc, d))
+    slab = np.empty((R, cnt, d, n_loc))
+    for r in range(R):
+        for s in range(cnt):
+            slab[r, s] = states[s, r].T                       # each rank sends [cnt][d][n_loc] (column-major n_loc x d blocks)
+    e.debug_append_slab(slab, R, cnt, batched)
+    e.debug_append_slab(slab * 2.0, R, cnt, batched)            # a second exchange lands behind the first
+    X, lp, Z, M = e.get_state()
+    e.close()
+    want = states.reshape(cnt * R * n_loc, d)                 # boundary-major, then rank, then chain
+    assert M == M0 + 2 * R * cnt * n_loc
+    assert np.array_equal(Z[:M0], w["Zinit"])
+    assert np.array_equal(Z[M0:M0 + R * cnt * n_loc], want)
+    assert np.array_equal(Z[M0 + R * cnt * n_loc:], 2.0 * want)

@@ -286,7 +286,9 @@ def test_utils_mirror_reference_postprocessing(demc, oracle, tmp_path):
     one, Zone = demc.demcz_sample(w["target"], Z0, N, 10, 2 * G, 1, [range(d)], w["eps_scale"], 2.38, verbose=False, seed=7)
     demc.save_checkpoint(tmp_path / "ck.npz", mc, Z, G, 7)
     prev, Zc, done, seed = demc.load_checkpoint(tmp_path / "ck.npz")
-    res, Zres = demc.demcz_sample(w["target"], Zc, *args, prevrun=prev, rng_offset=done, verbose=False, seed=seed)
+    # (no rng_offset: the checkpoint's prevrun itself records how far the streams have advanced)
+    res, Zres = demc.demcz_sample(w["target"], Zc, *args, prevrun=prev, verbose=False, seed=seed)
+    assert done == G and prev.generations_drawn == G and res.generations_drawn == 2 * G
     assert np.array_equal(res.chain[:, :, 1:], one.chain[:, :, G:]) and np.array_equal(Zres, Zone)
 
 
@@ -591,3 +593,83 @@ def test_randomised_annealed_targets_against_the_oracle(demc, oracle):
         tag = (case, kind, N, K, G, lanes)
         assert np.array_equal(ch, ref["chain"]), tag
         assert np.array_equal(lo, ref["log_obj"]) and np.array_equal(Z, ref["Z"]) and np.array_equal(X, ref["X"]), tag
+
+
+# ---- temperature == 0 (demcz_anneal.jl:18 default TN = 0.; test/test_anneal_parallel.jl uses it) -----------------
+def _temps_with_zeros(G):
+    """T(ig) = tempbaseline(ig, G, 5, 0.) is 0 for every ig >= 1 (demcz_anneal.jl:1-3): (lp' - lp)/0 = +-Inf accepts
+    every improvement and nothing else, 0/0 = NaN rejects (demcz_anneal.jl:172-178).  A few finite and denormal-range
+    temperatures are mixed in so the tempered division itself is exercised next to the zeros."""
+    T = np.zeros(G)
+    T[::7] = 2.5
+    T[3::11] = 1e-300
+    T[5::13] = 1e300
+    return T
+
+
+@pytest.mark.parametrize("kind,d,N,blocks,lanes", [
+    ("iso", 10, 48, None, 0),            # split layout, replicated consumer, TEMPER instantiation
+    ("iso", 10, 48, None, 8),            # 8 lanes per chain, fused
+    ("iso", 10, 48, None, 1),            # one lane per chain
+    ("mvn", 5, 70, None, 0),             # split layout, MvNormal, tempered
+    ("mvn", 20, 24, None, 0),            # split form of the 16-lane layout
+    ("mvn", 20, 24, None, 16),           # 16 lanes fused
+    ("mvn", 6, 30, [[0], [1, 2], [5, 3, 4]], 0),     # block updates, split form
+    ("mvn", 6, 30, [[0], [1, 2], [5, 3, 4]], 8),     # block updates, fused
+    ("mvn", 6, 30, [[0], [1, 2], [5, 3, 4]], 1),     # block updates, one lane
+    ("mvn", 7, 20, None, 1),             # runtime-d kernel
+    ("linreg", 10, 40, None, 0),         # regression target, split form (matrix-core residuals)
+    ("linreg", 10, 40, None, 16),        # regression target, fused
+    ("linreg", 10, 40, None, 1),
+])
+def test_zero_temperature_bit_exact(demc, oracle, kind, d, N, blocks, lanes):
+    G, K, seed = 45, 10, 23
+    w = (demc.workloads.iso_quad_problem(d, N) if kind == "iso" else
+         demc.workloads.linreg_problem(d, N, nobs=70) if kind == "linreg" else demc.workloads.mvnormal_problem(d, N))
+    bl = blocks or [range(d)]
+    T = _temps_with_zeros(G)
+    mc, Z, = demc.demcz_anneal(w["target"], w["Zinit"], N, K, G, len(bl), bl, w["eps_scale"], w["gamma"], verbose=False,
+                               seed=seed, adaptγ={"adapt": False}, lanes_per_chain=lanes,
+                               temperaturefun=lambda ig, Ng, T0, TN: float(T[ig - 1]))
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, [list(b) for b in bl] if blocks else None, w["eps_scale"],
+                        w["gamma"], seed, temperature=T)
+    assert np.array_equal(mc.chain, ref["chain"]) and np.array_equal(mc.log_obj, ref["log_obj"]) and np.array_equal(Z, ref["Z"])
+    # at T = 0 the log-density never decreases (greedy), and generations with T = 0 did accept improvements
+    zero = np.flatnonzero(T == 0.0)
+    zero = zero[zero > 0]
+    assert np.all(mc.log_obj[:, zero] >= mc.log_obj[:, zero - 1])
+    assert np.any(mc.log_obj[:, zero] > mc.log_obj[:, zero - 1])
+
+
+def test_reference_default_TN_zero_schedule(demc, oracle):
+    """demcz_anneal's positional default TN = 0. (demcz_anneal.jl:18) through the real schedule function."""
+    d, N, G = 10, 16, 60
+    w = demc.workloads.iso_quad_problem(d, N)
+    mc, Z = demc.demcz_anneal(w["target"], w["Zinit"], N, 10, G, 1, [range(d)], w["eps_scale"], 2.38, verbose=False, T0=5.0,
+                              seed=3, adaptγ={"adapt": False})            # TN defaults to 0.
+    T = np.array([demc.tempbaseline(g, G, 5.0, 0.0) for g in range(1, G + 1)])
+    assert not T.any()
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, 10, G, None, w["eps_scale"], 2.38, 3, temperature=T)
+    assert np.array_equal(mc.chain, ref["chain"]) and np.array_equal(Z, ref["Z"])
+
+
+@pytest.mark.parametrize("tempered", [False, True])
+def test_host_closure_path_equals_oracle(demc, oracle, tempered):
+    """The host-closure mode (demcz_propose / demcz_accept_commit / demcz_end_generation: update_demcz_chain_block cut
+    at the closure call demcz.jl:189) against the ORACLE directly, block updates and zero temperatures included.
+    The closure is the oracle's own log-density, so every double must agree."""
+    d, N, G, K, seed = 6, 21, 25, 5, 77
+    w = demc.workloads.mvnormal_problem(d, N)
+    blocks = [[0], [1, 2], [5, 3, 4]]
+    prob1 = oracle.Problem(1, d, K, 10, w["eps_scale"], 0, target=w["target"].spec())
+    closure = lambda x: float(oracle.logp(prob1, np.asarray(x)[None, :])[0])
+    T = _temps_with_zeros(G) if tempered else None
+    if tempered:
+        mc, Z = demc.demcz_anneal(closure, w["Zinit"], N, K, G, len(blocks), blocks, w["eps_scale"], w["gamma"], verbose=False,
+                                  seed=seed, adaptγ={"adapt": False}, temperaturefun=lambda ig, Ng, T0, TN: float(T[ig - 1]))
+    else:
+        mc, Z = demc.demcz_sample(closure, w["Zinit"], N, K, G, len(blocks), blocks, w["eps_scale"], w["gamma"], verbose=False,
+                                  seed=seed)
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, blocks, w["eps_scale"], w["gamma"], seed, temperature=T)
+    assert np.array_equal(mc.chain, ref["chain"]) and np.array_equal(mc.log_obj, ref["log_obj"])
+    assert np.array_equal(mc.Xcurrent, ref["X"]) and np.array_equal(Z, ref["Z"])

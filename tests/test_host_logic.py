@@ -74,6 +74,31 @@ def test_prevrun_concatenates_and_resumes(oracle):
     assert np.array_equal(a.chain, b.chain) and np.array_equal(Za, Zb)
 
 
+def test_checkpoint_resume_continues_the_random_streams(oracle, tmp_path):
+    """A checkpoint keeps one generation of history; the prevrun it restores must still resume the chains'
+    Philox streams where they stopped -- WITHOUT the caller passing rng_offset (it used to replay
+    generations 2..G+1 of the first run's draws silently).  Twice in a row: G + G + G == 3G in one go."""
+    d, N, G = 5, 6, 30
+    w = demc.workloads.mvnormal_problem(d, N)
+    kw = dict(verbose=False, engine_factory=OracleEngine)
+    args = (N, 10, G, 1, [range(d)], w["eps_scale"], 2.38)
+    one, Zone = demc.demcz_sample(w["target"], w["Zinit"][:50], N, 10, 3 * G, 1, [range(d)], w["eps_scale"], 2.38, seed=4, **kw)
+    mc, Z = demc.demcz_sample(w["target"], w["Zinit"][:50], *args, seed=4, **kw)
+    assert mc.generations_drawn == G
+    for leg in (1, 2):
+        demc.save_checkpoint(tmp_path / f"ck{leg}.npz", mc, Z, seed=4)
+        prev, Zc, done, seed = demc.load_checkpoint(tmp_path / f"ck{leg}.npz")
+        assert done == leg * G and prev.chain.shape[2] == 1 and prev.generations_drawn == leg * G and seed == 4
+        mc, Z = demc.demcz_sample(w["target"], Zc, *args, prevrun=prev, seed=seed, **kw)
+        assert mc.generations_drawn == (leg + 1) * G
+        # demcz.jl:58-59 concatenates prevrun's (one-generation) history in front of the new one
+        assert np.array_equal(mc.chain[:, :, 1:], one.chain[:, :, leg * G:(leg + 1) * G])
+    assert np.array_equal(Z, Zone) and np.array_equal(mc.Xcurrent, one.Xcurrent)
+    # an explicit rng_offset still wins (e.g. to decorrelate on purpose)
+    other, _ = demc.demcz_sample(w["target"], Zc, *args, prevrun=prev, seed=seed, rng_offset=10 ** 6, **kw)
+    assert not np.array_equal(other.chain[:, :, 1:], mc.chain[:, :, 1:])
+
+
 def test_autostop_truncates_at_first_passing_check(oracle):
     """demcz.jl:39-53 through the opts path (the canonical defaults, Q8)."""
     d, N = 5, 32
