@@ -52,7 +52,11 @@ struct DemczError <: Exception; code::Int32; msg::String; end
 lasterr(h) = unsafe_string(ccall((:demcz_last_error, libdemcz), Cstring, (Ptr{Cvoid},), h))
 chk(rc, h=C_NULL) = rc == 0 ? nothing : throw(DemczError(rc, lasterr(h)))
 
-function create(t::DeviceTarget, N, d, K, Mcap, Gcap, blockindex, eps_scale, seed; device_id=0)
+# `logobj` of the reference's surface: one of the device targets above, or ANY Julia function x::Vector{Float64} -> Float64
+# (demcz.jl:189 calls it once per block-step per chain; such a closure runs on the host, see run_closure! below)
+const LogObj = Union{DeviceTarget,Function}
+
+function create(t::LogObj, N, d, K, Mcap, Gcap, blockindex, eps_scale, seed; device_id=0)
     offs = Int32[0; cumsum(length.(blockindex))]
     idx = Int32[i - 1 for b in blockindex for i in b]                       # 1-based -> 0-based
     eps = Vector{Float64}(eps_scale)
@@ -61,7 +65,8 @@ function create(t::DeviceTarget, N, d, K, Mcap, Gcap, blockindex, eps_scale, see
         kind, mu, W, c0, design, y, nobs =
             t isa MvNormalTarget ? (Int32(0), pointer(t.μ), pointer(t.W), t.c0, Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0) :
             t isa IsoQuadTarget ? (Int32(1), pointer(t.μ), Ptr{Float64}(C_NULL), 0.0, Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0) :
-            (Int32(2), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0.0, pointer(t.X), pointer(t.y), size(t.X, 1))
+            t isa LinRegSSETarget ? (Int32(2), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0.0, pointer(t.X), pointer(t.y), size(t.X, 1)) :
+            (Int32(3), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0.0, Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0)   # DEMCZ_TARGET_HOST_CALLBACK
         cfg = DemczConfig(N, 0, d, K, Mcap, Gcap, length(blockindex), pointer(offs), pointer(idx), pointer(eps),
                           UInt64(seed), device_id, kind, mu, W, c0, design, y, nobs, C_NULL, 0, 0)
         chk(ccall((:demcz_create, libdemcz), Int32, (Ref{Ptr{Cvoid}}, Ref{DemczConfig}), h, cfg))   # config is copied
@@ -111,34 +116,81 @@ function state(h, N, d)
     X, lp, Z
 end
 
+# ---- host-closure mode: update_demcz_chain_block cut at the closure call demcz.jl:189 ----------------------
+# demcz_propose draws (i1, i2, normals, log u) for block `ib` of generation `g` and returns the N proposals; the
+# closure is evaluated here, on the host; demcz_accept_commit applies demcz.jl:190-194 (tempered:
+# demcz_anneal.jl:165,172-178); demcz_end_generation does runchain!'s bookkeeping demcz.jl:84-91.
+# `ib` is 1-based like the reference's loop variable (demcz.jl:168); the C ABI is 0-based.
+propose!(h, Xprop::Matrix{Float64}, g, ib, γ) =
+    chk(ccall((:demcz_propose, libdemcz), Int32, (Ptr{Cvoid}, Int64, Int32, Float64, Ptr{Float64}), h, g, ib - 1, γ, Xprop), h)
+accept_commit!(h, lp::Vector{Float64}) =
+    chk(ccall((:demcz_accept_commit, libdemcz), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h, lp, C_NULL), h)
+accept_commit!(h, lp::Vector{Float64}, temperature::Real) =
+    chk(ccall((:demcz_accept_commit, libdemcz), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ref{Float64}), h, lp, Float64(temperature)), h)
+end_generation!(h, g) = chk(ccall((:demcz_end_generation, libdemcz), Int32, (Ptr{Cvoid}, Int64), h, g), h)
+
+function run_closure!(h, logobj::Function, N, d, Nblocks, g_from, g_to, γ, temperature=nothing)
+    Xp = Matrix{Float64}(undef, N, d)
+    lp = Vector{Float64}(undef, N)
+    for g in g_from:g_to                                                               # demcz.jl:30
+        for ib in 1:Nblocks                                                            # update_blocks, demcz.jl:168
+            propose!(h, Xp, g, ib, γ)                                                  # demcz.jl:176-188 for all N chains
+            for ic in 1:N
+                lp[ic] = logobj(Xp[ic, :])                                             # demcz.jl:189
+            end
+            temperature === nothing ? accept_commit!(h, lp) : accept_commit!(h, lp, temperature[g-g_from+1])
+        end
+        end_generation!(h, g)                                                          # demcz.jl:84-91
+    end
+end
+
+# generations g_from..g_to: one library call for a device target, the propose / evaluate / commit loop for a closure
+advance!(h, t::DeviceTarget, N, d, Nblocks, g_from, g_to, γ, temperature=nothing) = run!(h, g_from, g_to, γ, temperature)
+advance!(h, f::Function, N, d, Nblocks, g_from, g_to, γ, temperature=nothing) = run_closure!(h, f, N, d, Nblocks, g_from, g_to, γ, temperature)
+
+# start state of a run, demcz.jl:13-22 (chains start at the last N rows of Zmat -- the documented intent of :15)
+function start_state(t::LogObj, Zmat, N, prevrun)
+    if prevrun === nothing
+        X = Matrix{Float64}(Zmat[end-N+1:end, :])
+        lp = t isa Function ? Float64[t(X[i, :]) for i in 1:N] : nothing               # demcz.jl:17 (device targets: on the device)
+        return X, lp, 0
+    end
+    Matrix{Float64}(prevrun.chain[:, :, end]), Vector{Float64}(prevrun.log_objcurrent[:, end]), size(prevrun.chain, 3)   # :20-21
+end
+
 # ---- drivers: src/demcz.jl:1-63 and src/demcz_anneal.jl:14-65 with the device below runchain! -------------
-demcz_sample(t::DeviceTarget, Zmat, opts::DEMCopt; prevrun=nothing, seed=0) =
+demcz_sample(t::LogObj, Zmat, opts::DEMCopt; prevrun=nothing, seed=0) =
     demcz_sample(t, Zmat, opts.N, opts.K, opts.Ngeneration, opts.Nblocks, opts.blockindex, opts.eps_scale, opts.γ;
                  prevrun=prevrun, verbose=opts.verbose, print_step=opts.print_step, autostop=opts.autostop,
                  autostop_Rhat=opts.autostop_Rhat, autostop_every=opts.autostop_every, seed=seed)
 
-function demcz_sample(t::DeviceTarget, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockindex=[1:size(Zmat, 2)],
+function demcz_sample(t::LogObj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockindex=[1:size(Zmat, 2)],
                       eps_scale=1e-4 * ones(size(Zmat, 2)), γ=2.38; prevrun=nothing, verbose=true, print_step=100,
                       autostop=:no, autostop_Rhat=1.01, autostop_every=1000, seed=0)
     nrowZ, d = size(Zmat)
     Mcap = nrowZ + Int(ceil(N * Ngeneration / K))                                     # demcz.jl:11
-    X = prevrun === nothing ? Zmat[end-N+1:end, :] : prevrun.chain[:, :, end]         # demcz.jl:15 (intent), :20
-    lp = prevrun === nothing ? nothing : prevrun.log_objcurrent[:, end]               # :17 on the device, :21
+    X, lp, drawn = start_state(t, Zmat, N, prevrun)
     h = create(t, N, d, K, Mcap, Ngeneration, blockindex, eps_scale, seed)
     try
-        set_state(h, Matrix{Float64}(X), lp, Matrix{Float64}(Zmat))
-        prevrun === nothing || set_rng_offset(h, size(prevrun.chain, 3))
+        set_state(h, X, lp, Matrix{Float64}(Zmat))
+        drawn == 0 || set_rng_offset(h, drawn)                                         # the chains' streams continue
         ig = 0
-        if autostop == :Rhat                                                           # demcz.jl:30-53 in one call
+        if autostop == :Rhat && t isa DeviceTarget                                     # demcz.jl:30-53 in one call
             ig = run_checked!(h, 1, Ngeneration, γ, autostop_every, autostop_Rhat)
-            if ig % autostop_every == 0 && maximum(rhat(h, ig - autostop_every + 1, ig, d)) < autostop_Rhat
-                sum(accept_ratio(h, ig - autostop_every + 1, ig, N)) / N < 0.1 && println("Warning: accept ratio below 10% on average")
+        elseif autostop == :Rhat                                                       # closure: the same loop on the host
+            while ig < Ngeneration
+                nxt = min(Ngeneration, (ig ÷ autostop_every + 1) * autostop_every)
+                advance!(h, t, N, d, Nblocks, ig + 1, nxt, γ); ig = nxt
+                ig % autostop_every == 0 && maximum(rhat(h, ig - autostop_every + 1, ig, d)) < autostop_Rhat && break   # demcz.jl:39-43
             end
         else
-            run!(h, 1, Ngeneration, γ); ig = Ngeneration
+            advance!(h, t, N, d, Nblocks, 1, Ngeneration, γ); ig = Ngeneration
         end
-        chain, log_obj = history(h, N, d, 1, ig)
-        Xc, lpc, Z = state(h, N, d)
+        if autostop == :Rhat && ig % autostop_every == 0 && maximum(rhat(h, ig - autostop_every + 1, ig, d)) < autostop_Rhat
+            sum(accept_ratio(h, ig - autostop_every + 1, ig, N)) / N < 0.1 && println("Warning: accept ratio below 10% on average")   # demcz.jl:42-46
+        end
+        chain, log_obj = history(h, N, d, 1, ig)                                       # demcz.jl:47
+        Xc, lpc, Z = state(h, N, d)                                                    # Z[1:M,:], demcz.jl:51
         mc = prevrun === nothing ? MC(chain, log_obj, Xc, lpc) :
              MC(cat(prevrun.chain, chain, dims=3), cat(prevrun.log_obj, log_obj, dims=2), Xc, lpc)   # demcz.jl:58-59
         return mc, Z
@@ -149,23 +201,28 @@ end
 
 tempbaseline(ig, Ng, T0, TN) = T0 * (TN / T0)^(ig / Ng)                                 # demcz_anneal.jl:1-3
 
-function demcz_anneal(t::DeviceTarget, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockindex=[1:size(Zmat, 2)],
+demcz_anneal(t::LogObj, Zmat, opts::DEMCopt; prevrun=nothing, temperaturefun::Function=tempbaseline,
+             adaptγ=Dict("adapt" => true, "minγ" => 0.1, "maxγ" => 4.0, "adapt_every" => 500), seed=0) =   # demcz_anneal.jl:14-16
+    demcz_anneal(t, Zmat, opts.N, opts.K, opts.Ngeneration, opts.Nblocks, opts.blockindex, opts.eps_scale, opts.γ;
+                 prevrun=prevrun, verbose=opts.verbose, print_step=opts.print_step, temperaturefun=temperaturefun,
+                 T0=opts.T0, TN=opts.TN, adaptγ=adaptγ, seed=seed)
+
+function demcz_anneal(t::LogObj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockindex=[1:size(Zmat, 2)],
                       eps_scale=1e-4 * ones(size(Zmat, 2)), γ=2.38; prevrun=nothing, verbose=true, print_step=100,
                       temperaturefun::Function=tempbaseline, T0=3, TN=0.0,
                       adaptγ=Dict("adapt" => true, "minγ" => 0.1, "maxγ" => 4.0, "adapt_every" => 500), seed=0)
     nrowZ, d = size(Zmat)
     Mcap = nrowZ + Int(ceil(N * Ngeneration / K))
-    X = prevrun === nothing ? Zmat[end-N+1:end, :] : prevrun.chain[:, :, end]
-    lp = prevrun === nothing ? nothing : prevrun.log_objcurrent[:, end]
+    X, lp, drawn = start_state(t, Zmat, N, prevrun)
     h = create(t, N, d, K, Mcap, Ngeneration, blockindex, eps_scale, seed)
     try
-        set_state(h, Matrix{Float64}(X), lp, Matrix{Float64}(Zmat))
-        prevrun === nothing || set_rng_offset(h, size(prevrun.chain, 3))
+        set_state(h, X, lp, Matrix{Float64}(Zmat))
+        drawn == 0 || set_rng_offset(h, drawn)
         ae = adaptγ["adapt_every"]; ig = 0
         while ig < Ngeneration                                                         # demcz_anneal.jl:39
             nxt = adaptγ["adapt"] ? min(Ngeneration, (ig ÷ ae + 1) * ae) : Ngeneration
             temps = Float64[temperaturefun(g, Ngeneration, T0, TN) for g in ig+1:nxt]   # demcz_anneal.jl:69
-            run!(h, ig + 1, nxt, γ, temps); ig = nxt
+            advance!(h, t, N, d, Nblocks, ig + 1, nxt, γ, temps); ig = nxt
             if adaptγ["adapt"] && ig % ae == 0                                         # demcz_anneal.jl:48-57
                 accept = (ae > 1 ? sum(changed(h, ig - ae + 2, ig)) : 0) / (N * ae)
                 if accept < 0.1; γ = max(adaptγ["minγ"], γ * 0.5) elseif accept > 0.5; γ = min(adaptγ["maxγ"], γ * 1.5) end
