@@ -37,7 +37,7 @@ SYMBOLS = [
     "demcz_rhat_partial", "demcz_set_rng_offset", "demcz_rhat_array", "demcz_accept_ratio_array",
     "demcz_mean_cov_array", "demcz_set_append_lag", "demcz_run_checked", "demcz_set_kernel_timing",
     "demcz_get_kernel_time", "demcz_set_live_spin_limit", "demcz_get_live_status",
-    "demcz_debug_append_slab",
+    "demcz_debug_append_slab", "demcz_get_changed_total",
 ]
 
 
@@ -104,6 +104,7 @@ def load():
     L.demcz_synchronize.argtypes = [C.c_void_p]
     L.demcz_get_history.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _dp, _dp]
     L.demcz_get_changed.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _lp]
+    L.demcz_get_changed_total.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _lp, _ip]
     L.demcz_rhat.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _dp]
     L.demcz_accept_ratio.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _dp]
     L.demcz_mean_cov.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _dp, _dp]

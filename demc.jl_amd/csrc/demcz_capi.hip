@@ -108,6 +108,13 @@ struct demcz_handle {
     bool replaying = false;
     int32_t live_redos = 0;
     struct RecDesc { bool valid = false; int64_t g_first = 0, M = 0, rows = 0; int32_t ngen = 0, boff = 0; } rec_desc[2];
+    // accept mask by ballot: per launch and consumer wave {changed over the launch, changed in its first generation};
+    // a ring of launches, newest last (demcz_get_changed_total)
+    unsigned int* d_acc = nullptr;
+    int64_t acc_waves = 0;            // consumer waves of a window launch of this handle's layout
+    int32_t acc_slots = 0, acc_next = 0;
+    struct LaunchRec { int64_t g_first, g_last; int32_t slot; };
+    std::deque<LaunchRec> acc_log;
     // multi-GPU
     ncclComm_t comm = nullptr;          // collectives on the compute stream: synchronous all-gather, R-hat all-reduces
     ncclComm_t comm_side = nullptr;     // its duplicate (ncclCommSplit) for the batched all-gathers on the side stream: operations
@@ -190,6 +197,7 @@ static hipError_t dev_alloc_copy(T** dst, const T* src, size_t n, hipStream_t s)
 
 static void free_all(demcz_handle* h)
 {
+    if (h->d_acc) (void)hipFree(h->d_acc);
     void* bufs[] = {h->dZ, h->dX, h->dlp, h->dchain, h->dlogobj, h->dlp_origin, h->dtemp, h->d_block_offsets,
                     h->d_slot_of, h->d_slot_role, h->d_eps, h->d_mu, h->d_Wp, h->d_design, h->d_y, h->d_scratch, h->dXprop,
                     h->dlogu, h->d_gather};
@@ -393,6 +401,26 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         CRCHK(hipMalloc((void**)&h->dXprop, (size_t)N * d * sizeof(double)));
         CRCHK(hipMalloc((void**)&h->dlogu, (size_t)N * sizeof(double)));
     }
+    if (cfg->target_kind != DEMCZ_TARGET_HOST_CALLBACK) {
+        // waves that run chains in one window launch (every one writes its two counters)
+        int64_t waves;
+        if (h->lanes == DEMCZ_LAYOUT_SPLIT) {
+            const int64_t wgs = (N + h->split_per_wg - 1) / h->split_per_wg;
+            waves = wgs * ((h->split_kind == 2 && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? ML_LR_WAVES : 1);
+        } else if (h->lanes > 1) {
+            const int per_wave = 64 / h->lanes;
+            const bool lr = h->full_block && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE;
+            waves = lr ? ((N + (int64_t)ML_LR_WAVES * per_wave - 1) / ((int64_t)ML_LR_WAVES * per_wave)) * ML_LR_WAVES
+                       : (N + per_wave - 1) / per_wave;
+        } else {
+            waves = (N + WINDOW_BS - 1) / WINDOW_BS;
+        }
+        h->acc_waves = waves;
+        h->acc_slots = (int32_t)std::min<int64_t>(4096, std::max<int64_t>(64, (int64_t)(64ll << 20) / (waves * 8)));
+        const size_t nb = (size_t)h->acc_slots * (size_t)waves * 2 * sizeof(unsigned int);
+        CRCHK(hipMalloc((void**)&h->d_acc, nb));
+        CRCHK(hipMemsetAsync(h->d_acc, 0, nb, h->stream));
+    }
     h->stage_cap = std::max<int64_t>(4096, (int64_t)d * (d + 1) + 64);
     CRCHK(hipHostMalloc((void**)&h->d_stage, (size_t)h->stage_cap * sizeof(double), hipHostMallocDefault));
     CRCHK(hipStreamSynchronize(h->stream));   // the host vectors above go out of scope
@@ -491,6 +519,7 @@ extern "C" int32_t demcz_set_state(demcz_handle* h, const double* X, const doubl
     h->M = M0;
     h->M_app = M0;
     h->live_log.clear();
+    h->acc_log.clear();
     h->rec_desc[0].valid = h->rec_desc[1].valid = false;
     for (auto& pe : h->pending) if (pe.ev) (void)hipEventDestroy(pe.ev);
     h->pending.clear();
@@ -963,6 +992,7 @@ static int32_t live_rollback(demcz_handle* h, std::vector<demcz_handle::RunCall>
     h->M = h->safe_M;
     h->M_app = h->safe_M_app;
     h->g_done = h->safe_g_done;
+    while (!h->acc_log.empty() && h->acc_log.back().g_last > h->safe_g_done) h->acc_log.pop_back();
     h->rec_desc[0].valid = h->rec_desc[1].valid = false;
     h->no_live = true;
     live_release(h);
@@ -1139,6 +1169,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     P.tp = target_params(h);
     P.snap = nullptr;
     P.K = K;
+    P.acc_out = nullptr; P.live_err = h->d_live_err; P.live_spin_limit = LIVE_SPIN_LIMIT;
     P.rec_in = nullptr; P.rec_out = nullptr; P.next_g_first = 0; P.next_M = 0; P.next_ngen = 0; P.consumer_blocks = 0;
     P.next_rows = 0; P.next_boff = 0; P.rec_stride = 0;
 #ifdef DEMCZ_STAMPS
@@ -1251,8 +1282,14 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         const bool live = live_max > 0 && ((w_end - 1) / K - (g - 1) / K) > 0;
         P.live_err = h->d_live_err;
         P.live_spin_limit = h->live_spin_limit ? (int32_t)h->live_spin_limit : LIVE_SPIN_LIMIT;
+        P.acc_out = h->d_acc ? h->d_acc + (size_t)h->acc_next * (size_t)h->acc_waves * 2 : nullptr;
         rc = launch_window(h, P, live);
         if (rc) return rc;
+        if (h->d_acc) {
+            h->acc_log.push_back({g, w_end, h->acc_next});
+            h->acc_next = (h->acc_next + 1) % h->acc_slots;
+            if ((int64_t)h->acc_log.size() > h->acc_slots) h->acc_log.pop_front();
+        }
         ++timed_launches;
         if (nbound > 0 && !h->external_append) {
             const int64_t rows = h->cfg.N * (sharded ? h->nranks : 1);
@@ -1352,6 +1389,73 @@ extern "C" int32_t demcz_get_changed(demcz_handle* h, int64_t g_from, int64_t g_
     static_assert(sizeof(int64_t) == sizeof(long long), "int64 layout");
     HIPCHK(h, hipMemcpyAsync(changed, h->d_scratch, (size_t)G * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DEMCZ_OK;
+}
+
+namespace demcz {
+// sum over `nslots` consecutive ring slots (from slot0, modulo `ring`) of the per-wave launch totals, minus the
+// first-generation counts of slot0 when `skip_first`
+__global__ void __launch_bounds__(256) sum_counts_kernel(const unsigned int* acc, int64_t waves, int slot0, int nslots, int ring,
+                                                         int skip_first, long long* out)
+{
+    __shared__ long long red[256];
+    long long a = 0;
+    for (int64_t i = threadIdx.x; i < (int64_t)nslots * waves; i += 256) {
+        const int sl = (int)(i / waves);
+        const int64_t w = i % waves;
+        const unsigned int* e = acc + ((size_t)((slot0 + sl) % ring) * (size_t)waves + (size_t)w) * 2;
+        a += (long long)e[0];
+        if (skip_first && sl == 0) a -= (long long)e[1];
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
+}  // namespace demcz
+
+extern "C" int32_t demcz_get_changed_total(demcz_handle* h, int64_t g_from, int64_t g_to, int64_t* total, int32_t* from_ballots)
+{
+    if (!h || !total || g_from < 1 || g_to < g_from) return DEMCZ_ERR_INVALID_ARGUMENT;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    int32_t rc = live_verify(h);
+    if (rc) return rc;
+    // whole launches whose generations are exactly g_from..g_to, or g_from-1..g_to with the first generation's own
+    // count taken off (the window sum of demcz_anneal.jl:50 has no predecessor for its first column)
+    int first = -1, last = -1, skip = 0;
+    for (int i = 0; i < (int)h->acc_log.size(); ++i) {
+        const auto& r = h->acc_log[i];
+        if (first < 0 && (r.g_first == g_from || r.g_first == g_from - 1) && r.g_last >= g_from) { first = i; skip = (r.g_first == g_from - 1); }
+        if (first >= 0 && r.g_last == g_to) { last = i; break; }
+    }
+    bool ok = first >= 0 && last >= first;
+    for (int i = first; ok && i < last; ++i)
+        ok = h->acc_log[i].g_last + 1 == h->acc_log[i + 1].g_first && (h->acc_log[i].slot + 1) % h->acc_slots == h->acc_log[i + 1].slot;
+    if (ok && h->d_acc) {
+        rc = ensure_scratch(h, 1);
+        if (rc) return rc;
+        static_assert(sizeof(long long) == sizeof(double), "scratch reuse");
+        hipLaunchKernelGGL(sum_counts_kernel, dim3(1), dim3(256), 0, h->stream, (const unsigned int*)h->d_acc, h->acc_waves,
+                           (int)h->acc_log[first].slot, last - first + 1, (int)h->acc_slots, skip, (long long*)h->d_scratch);
+        HIPCHK(h, hipGetLastError());
+        long long v = 0;
+        HIPCHK(h, hipMemcpyAsync(&v, h->d_scratch, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        *total = (int64_t)v;
+        if (from_ballots) *from_ballots = 1;
+        return DEMCZ_OK;
+    }
+    // not a union of whole launches (or a host-closure handle): count from the history, as the checker does
+    std::vector<int64_t> ch((size_t)(g_to - g_from + 1));
+    rc = demcz_get_changed(h, g_from, g_to, ch.data());
+    if (rc) return rc;
+    int64_t t = 0;
+    for (int64_t v : ch) t += v;
+    *total = t;
+    if (from_ballots) *from_ballots = 0;
     return DEMCZ_OK;
 }
 
@@ -1473,9 +1577,16 @@ extern "C" int32_t demcz_accept_ratio(demcz_handle* h, int64_t g_from, int64_t g
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     rc = live_verify(h);
     if (rc) return rc;
-    rc = ensure_scratch(h, N);
+    rc = ensure_scratch(h, 2 * N);
     if (rc) return rc;
-    hipLaunchKernelGGL(changed_per_chain_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, h->stream, h->dlogobj, N, s0, w, h->d_scratch);
+    {   // chains x time chunks: enough workgroups to fill the chip whatever the shape of the window
+        const int64_t cb = (N + 63) / 64;
+        const int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((w - 1 + 31) / 32, 1024), (4096 + cb - 1) / cb));
+        unsigned int* cnt = reinterpret_cast<unsigned int*>(h->d_scratch + N);
+        HIPCHK(h, hipMemsetAsync(cnt, 0, (size_t)N * sizeof(unsigned int), h->stream));
+        hipLaunchKernelGGL(changed_per_chain_kernel, dim3((unsigned)cb, (unsigned)nchunk), dim3(64), 0, h->stream, h->dlogobj, N, s0, w, nchunk, cnt);
+        hipLaunchKernelGGL(changed_ratio_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, (const unsigned int*)cnt, N, w, h->d_scratch);
+    }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(ratio, h->d_scratch, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1492,10 +1603,18 @@ extern "C" int32_t demcz_mean_cov(demcz_handle* h, int64_t g_from, int64_t g_to,
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     rc = live_verify(h);
     if (rc) return rc;
-    rc = ensure_scratch(h, (int64_t)d * (d + 1) + d);
+    const int T = (d + MC_TS - 1) / MC_TS, npair = T * (T + 1) / 2;
+    const int64_t cb = (N + 255) / 256;
+    const int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((w + 15) / 16, 512), (2048 + cb * npair - 1) / (cb * npair)));
+    const int64_t nblk_xy = cb * nchunk;
+    rc = ensure_scratch(h, (int64_t)d * (d + 1) + d + nblk_xy * npair * MC_VALS);
     if (rc) return rc;
     double* sums = h->d_scratch;
-    hipLaunchKernelGGL(meancov_kernel, dim3(d, d + 1), dim3(256), 0, h->stream, h->dchain, N, d, s0, w, sums);
+    double* partial = sums + (int64_t)d * (d + 1) + d;
+    hipLaunchKernelGGL(meancov_partial_kernel, dim3((unsigned)cb, (unsigned)nchunk, (unsigned)npair), dim3(256), 0, h->stream,
+                       (const double*)h->dchain, N, d, s0, w, nchunk, partial);
+    hipLaunchKernelGGL(meancov_final_kernel, dim3((unsigned)((d * (d + 1) + 63) / 64)), dim3(64), 0, h->stream, (const double*)partial, d,
+                       (int)nblk_xy, sums);
     HIPCHK(h, hipGetLastError());
     std::vector<double> hs((size_t)d * (d + 1)), ref((size_t)d);
     HIPCHK(h, hipMemcpyAsync(hs.data(), sums, hs.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1986,6 +2105,7 @@ static int32_t run_checked_body(demcz_handle* h, int64_t g_from, int64_t g_to, d
                         h->g_done = nxt;
                         h->rec_desc[0].valid = h->rec_desc[1].valid = false;
                         if (!h->live_log.empty()) h->live_log.pop_back();     // the discarded slab is not to be redone
+                        while (!h->acc_log.empty() && h->acc_log.back().g_last > nxt) h->acc_log.pop_back();
                     }
                     break;
                 }

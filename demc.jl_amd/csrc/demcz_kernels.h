@@ -89,10 +89,29 @@ struct WindowParams {
     int32_t consumer_blocks; // workgroups [0, consumer_blocks) consume, the rest produce
     unsigned int* live_err;  // LIVE launches: set when a row another wave should have appended never showed up
     int32_t live_spin_limit; // LIVE launches: polls of one wait before it is given up (LIVE_SPIN_LIMIT unless a test lowers it)
+    // Accept mask by wavefront ballot: every wave counts, per generation, the chains whose log_obj changed
+    // ((lp_after - lp_before) != 0: the event diff(log_obj, dims=2) .!= 0 counts, demcz.jl:42, demcz_anneal.jl:50) with
+    // one ballot + s_bcnt1 into a scalar register and writes {sum over the launch, count of its first generation}
+    // once, at the end, to acc_out[2 * wave] -- no atomics, no second pass over log_obj (nullptr: not wanted).
+    unsigned int* acc_out;
 #ifdef DEMCZ_STAMPS
     unsigned long long* stamps;   // diagnostic build only (scripts/stamps.py): 8 s_memtime values per workgroup
 #endif
 };
+
+// Chains of this wave whose log_obj changed in a generation: ballot of the lanes that speak for a chain.
+__device__ __forceinline__ unsigned int wave_count_changed(double lp_after, double lp_before, bool speaks)
+{
+    const double df = lp_after - lp_before;          // NaN (from +-Inf - +-Inf, or NaN) counts, as in Julia's diff(.) .!= 0
+    return (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(speaks && (df != 0.0)));
+}
+__device__ __forceinline__ void wave_store_counts(const WindowParams& P, int64_t wave, unsigned int total, unsigned int first)
+{
+    if (P.acc_out && (threadIdx.x & 63) == 0) {
+        P.acc_out[2 * wave] = total;
+        P.acc_out[2 * wave + 1] = first;
+    }
+}
 
 // One archive row (16-byte aligned) <-> registers, as 16-byte accesses.
 template <int D>
@@ -208,9 +227,11 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel(const WindowParams P)
     rng_seek(st, P.seed, (uint64_t)(P.chain_id0 + c), (uint64_t)(P.g_first - 1) * (uint64_t)P.S);
     int to_b = P.to_boundary;            // countdown to the next K boundary
     int64_t nb = 0;                      // boundaries passed inside this launch
+    unsigned int cnt_total = 0, cnt_first = 0;
 
     for (int gi = 0; gi < P.ngen; ++gi) {
         const int nblocks = FULL ? 1 : P.Nblocks;
+        const double lp_gen0 = lp;
         for (int ib = 0; ib < nblocks; ++ib) {
             uint64_t r1, r2, i1, i2;
             rng_next(st, r1, r2);
@@ -276,6 +297,11 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel(const WindowParams P)
             for (int p = 0; p < D; ++p) x[p] = acc ? xp[p] : x[p];
             lp = acc ? lpp : lp;
         }
+        {
+            const unsigned int k = wave_count_changed(lp, lp_gen0, true);
+            cnt_total += k;
+            cnt_first = (gi == 0) ? k : cnt_first;
+        }
         const int64_t slot = P.slot_first + gi;
         if (P.chain) {
 #pragma unroll
@@ -295,6 +321,7 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel(const WindowParams P)
 #pragma unroll
     for (int p = 0; p < D; ++p) P.Xcur[c + P.N * p] = x[p];
     P.lpcur[c] = lp;
+    wave_store_counts(P, blockIdx.x, cnt_total, cnt_first);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -319,8 +346,10 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel_generic(const WindowP
     rng_seek(st, P.seed, (uint64_t)(P.chain_id0 + c), (uint64_t)(P.g_first - 1) * (uint64_t)P.S);
     int to_b = P.to_boundary;            // countdown to the next K boundary
     int64_t nb = 0;                      // boundaries passed inside this launch
+    unsigned int cnt_total = 0, cnt_first = 0;
 
     for (int gi = 0; gi < P.ngen; ++gi) {
+        const double lp_gen0 = lp;
         for (int ib = 0; ib < P.Nblocks; ++ib) {
             uint64_t r1, r2, i1, i2;
             rng_next(st, r1, r2);
@@ -362,6 +391,11 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel_generic(const WindowP
                 lp = lpp;
             }
         }
+        {
+            const unsigned int k = wave_count_changed(lp, lp_gen0, true);
+            cnt_total += k;
+            cnt_first = (gi == 0) ? k : cnt_first;
+        }
         const int64_t slot = P.slot_first + gi;
         if (P.chain) {
             for (int p = 0; p < d; ++p) P.chain[c + P.N * (p + (int64_t)d * slot)] = xs[p * WINDOW_BS + tid];
@@ -379,6 +413,7 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel_generic(const WindowP
     }
     for (int p = 0; p < d; ++p) P.Xcur[c + P.N * p] = xs[p * WINDOW_BS + tid];
     P.lpcur[c] = lp;
+    wave_store_counts(P, blockIdx.x, cnt_total, cnt_first);
 }
 
 // K6: log-density of n points X (n x d, ld ldX) -> out.  Used for the initial log_objcurrent.
@@ -609,51 +644,126 @@ __global__ void __launch_bounds__(256) changed_from_history_kernel(const double*
     if (threadIdx.x == 0) out[blockIdx.x] = cnt[0];
 }
 
-// K7a: per-chain count of generations in slots s0+1 .. s0+w-1 whose log_obj differs from the
-// previous slot (src/utils.jl:61).
-__global__ void changed_per_chain_kernel(const double* logobj, int64_t N, int64_t s0, int64_t w, double* ratio)
+// K7a: per-chain count of generations in slots s0+1 .. s0+w-1 whose log_obj differs from the previous slot
+// (src/utils.jl:61).  Grid: x over chains (64 per workgroup), y over time chunks -- the work scales with N x w;
+// integer partial counts are added with atomics (order-free, exact), changed_ratio_kernel divides.
+__global__ void __launch_bounds__(64) changed_per_chain_kernel(const double* logobj, int64_t N, int64_t s0, int64_t w, int nchunk,
+                                                               unsigned int* cnt)
 {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (c >= N) return;
-    int64_t k = 0;
-    double prev = logobj[c + N * s0];
-    for (int64_t t = 1; t < w; ++t) {
-        double cur = logobj[c + N * (s0 + t)];
-        k += ((cur - prev) != 0.0) ? 1 : 0;      // diff(.) .!= 0 (utils.jl:61): a NaN difference counts
+    const int64_t per = (w - 1 + nchunk - 1) / nchunk;                 // differences t = 1 .. w-1
+    const int64_t t0 = 1 + (int64_t)blockIdx.y * per, t1 = (t0 + per < w) ? t0 + per : w;
+    if (t0 >= t1) return;
+    unsigned int k = 0;
+    double prev = logobj[c + N * (s0 + t0 - 1)];
+    for (int64_t t = t0; t < t1; ++t) {
+        const double cur = logobj[c + N * (s0 + t)];
+        k += ((cur - prev) != 0.0) ? 1u : 0u;      // diff(.) .!= 0 (utils.jl:61): a NaN difference counts
         prev = cur;
     }
-    ratio[c] = (double)k / (double)(w - 1);
+    atomicAdd(&cnt[c], k);
 }
 
-// K7b: sums for mean_cov_chain (src/utils.jl:96-111).  One workgroup per (p, q) pair (q = d means
-// "mean of p"), shifted by ref[p] = first element so the one-pass covariance keeps its digits.
-__global__ void __launch_bounds__(256) meancov_kernel(const double* chain, int64_t N, int d, int64_t s0, int64_t w,
-                                                      double* out /* d*(d+1) */)
+__global__ void changed_ratio_kernel(const unsigned int* cnt, int64_t N, int64_t w, double* ratio)
 {
-    __shared__ double ra[256];
-    const int p = blockIdx.x, q = blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < N) ratio[c] = (double)cnt[c] / (double)(w - 1);
+}
+
+// K7b: sums for mean_cov_chain (src/utils.jl:96-111), shifted by ref[p] = the first sample of parameter p so that
+// the one-pass covariance keeps its digits.  The parameters are cut into tiles of MC_TS; a workgroup takes 256 chains x
+// one chunk of generations x one tile pair (I <= J) and every thread accumulates the MC_TS x MC_TS products (and, on
+// the diagonal, the MC_TS sums) of its chain in registers: the history is read ceil(d/8)+1 times instead of d+1, by
+// (N/256) x chunks x pairs workgroups instead of d(d+1) in all.  Workgroup partials are combined by meancov_final_kernel
+// in a fixed order (deterministic).
+constexpr int MC_TS = 8;
+constexpr int MC_VALS = MC_TS * MC_TS + MC_TS;
+
+__global__ void __launch_bounds__(256) meancov_partial_kernel(const double* chain, int64_t N, int d, int64_t s0, int64_t w, int nchunk,
+                                                              double* partial)
+{
+    __shared__ double red[4][MC_VALS];
+    // tile pair of this workgroup: blockIdx.z enumerates (I, J), I <= J
+    const int T = (d + MC_TS - 1) / MC_TS;
+    int I = 0, J = (int)blockIdx.z;
+    while (J >= T - I) { J -= T - I; ++I; }
+    J += I;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t per = (w + nchunk - 1) / nchunk;
+    const int64_t t0 = (int64_t)blockIdx.y * per, t1 = (t0 + per < w) ? t0 + per : w;
     const int64_t stride = N * d;
-    const double rp = chain[N * p + stride * s0];
-    const double rq = (q < d) ? chain[N * q + stride * s0] : 0.0;
-    double a = 0.0;
-    const int64_t total = N * w;
-    for (int64_t k = threadIdx.x; k < total; k += 256) {
-        const int64_t c = k % N, t = k / N;
-        const double vp = chain[c + N * p + stride * (s0 + t)] - rp;
-        if (q < d) {
-            const double vq = chain[c + N * q + stride * (s0 + t)] - rq;
-            a = fma(vp, vq, a);
-        } else {
-            a += vp;
+    double acc[MC_TS][MC_TS], sm[MC_TS];
+#pragma unroll
+    for (int a = 0; a < MC_TS; ++a) {
+        sm[a] = 0.0;
+#pragma unroll
+        for (int b = 0; b < MC_TS; ++b) acc[a][b] = 0.0;
+    }
+    if (c < N) {
+        double ri[MC_TS], rj[MC_TS];
+#pragma unroll
+        for (int a = 0; a < MC_TS; ++a) {
+            ri[a] = (I * MC_TS + a < d) ? chain[N * (I * MC_TS + a) + stride * s0] : 0.0;
+            rj[a] = (J * MC_TS + a < d) ? chain[N * (J * MC_TS + a) + stride * s0] : 0.0;
+        }
+        for (int64_t t = t0; t < t1; ++t) {
+            const double* base = chain + c + stride * (s0 + t);
+            double xi[MC_TS], xj[MC_TS];
+#pragma unroll
+            for (int a = 0; a < MC_TS; ++a) {
+                xi[a] = (I * MC_TS + a < d) ? base[N * (I * MC_TS + a)] - ri[a] : 0.0;
+                xj[a] = (J * MC_TS + a < d) ? base[N * (J * MC_TS + a)] - rj[a] : 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < MC_TS; ++a) {
+                sm[a] += xi[a];
+#pragma unroll
+                for (int b = 0; b < MC_TS; ++b) acc[a][b] = fma(xi[a], xj[b], acc[a][b]);
+            }
         }
     }
-    ra[threadIdx.x] = a;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) ra[threadIdx.x] += ra[threadIdx.x + s];
-        __syncthreads();
+    // wave reduction of every accumulator, then the four waves through LDS
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < MC_TS; ++a) {
+#pragma unroll
+        for (int b = 0; b <= MC_TS; ++b) {
+            double v = (b < MC_TS) ? acc[a][b] : sm[a];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) red[wv][(b < MC_TS) ? a * MC_TS + b : MC_TS * MC_TS + a] = v;
+        }
     }
-    if (threadIdx.x == 0) out[p + d * q] = ra[0];
+    __syncthreads();
+    if (threadIdx.x < MC_VALS) {
+        const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partial[blk * MC_VALS + threadIdx.x] = v;
+    }
+}
+
+// out[p + d*q] = sum (x_p - ref_p)(x_q - ref_q) for q < d, out[p + d*d] = sum (x_p - ref_p): one thread per entry,
+// partials added in workgroup order
+__global__ void meancov_final_kernel(const double* partial, int d, int nblk_xy, double* out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= d * (d + 1)) return;
+    const int p = e % d, q = e / d;
+    const int T = (d + MC_TS - 1) / MC_TS;
+    int lo = p, hi = (q < d) ? q : p;
+    bool swap = false;
+    if (q < d && q / MC_TS < p / MC_TS) { lo = q; hi = p; swap = true; }
+    const int I = lo / MC_TS, J = (q < d) ? hi / MC_TS : I;
+    int z = 0;
+    for (int i = 0; i < I; ++i) z += T - i;
+    z += J - I;
+    int idx;
+    if (q == d) idx = MC_TS * MC_TS + p % MC_TS;
+    else idx = swap ? (q % MC_TS) * MC_TS + p % MC_TS : (p % MC_TS) * MC_TS + q % MC_TS;
+    double a = 0.0;
+    for (int b = 0; b < nblk_xy; ++b) a += partial[((size_t)z * nblk_xy + b) * MC_VALS + idx];
+    out[e] = a;
 }
 
 // Self-test of the draw pipeline: for block index blk0 + i of chain `chain`, the two raw words,

@@ -169,6 +169,7 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
     double za_c[NP], zb_c[NP], zt_c[NP];
     int to_b = P.to_boundary;            // countdown to the next K boundary
     int64_t nb = 0;                      // boundaries passed inside this launch
+    unsigned int cnt_total = 0, cnt_first = 0;      // accept mask by ballot (WindowParams::acc_out)
     auto issue_draws = [&](int gi) {
         if constexpr (REC) {
             const uint64_t ii = ix_next;
@@ -376,7 +377,13 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
         double dlt = lpp - lp;
         if (P.temperature) dlt = dlt / P.temperature[gi];
         const bool acc = logu < dlt;
-        lp = acc ? lpp : lp;
+        {
+            const double lp_new = acc ? lpp : lp;
+            const unsigned int kc = wave_count_changed(lp_new, lp, r == 0 && active);
+            cnt_total += kc;
+            cnt_first = (gi == 0) ? kc : cnt_first;
+            lp = lp_new;
+        }
         const int64_t slot = P.slot_first + gi;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -413,6 +420,7 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
         if (p < D && active) P.Xcur[c + P.N * p] = x[k];
     }
     if (r == 0 && active) P.lpcur[c] = lp;
+    wave_store_counts(P, (int64_t)blockIdx.x * WAVES + (int64_t)(threadIdx.x >> 6), cnt_total, cnt_first);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -582,7 +590,9 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
     int ib_n = 0, gi_n = 0;                                // block-step whose draws are in flight
     int to_b = P.to_boundary;
     int64_t nb = 0;
+    unsigned int cnt_total = 0, cnt_first = 0;             // accept mask by ballot (WindowParams::acc_out)
     for (int gi = 0; gi < P.ngen; ++gi) {
+        const double lp_gen0 = lp;
         for (int ib = 0; ib < NB; ++ib) {
             if constexpr (LIVE) {
                 // the gather was issued a block-step ago; rows appended since then by other waves read as the
@@ -673,6 +683,11 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
             for (int k = 0; k < NP; ++k) x[k] = acc ? xp[k] : x[k];
             wave_lds_handoff();
         }
+        {
+            const unsigned int kc = wave_count_changed(lp, lp_gen0, r == 0);
+            cnt_total += kc;
+            cnt_first = (gi == 0) ? kc : cnt_first;
+        }
         const int64_t slot = P.slot_first + gi;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -702,6 +717,7 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
         if (p < D) P.Xcur[c + P.N * p] = x[k];
     }
     if (r == 0) P.lpcur[c] = lp;
+    wave_store_counts(P, blockIdx.x, cnt_total, cnt_first);
 }
 
 }  // namespace demcz

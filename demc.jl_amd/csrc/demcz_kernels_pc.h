@@ -79,6 +79,7 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
     const double scale = (D == 1) ? P.gamma : P.gamma / sqrt((double)(2 * D));
     int to_b = P.to_boundary;
     int64_t nb = 0;
+    unsigned int cnt_total = 0, cnt_first = 0;             // accept mask by ballot (WindowParams::acc_out)
     // What a lane stores every generation: its own element(s) of the history row -- tracked beside the
     // replicated state (own' = own + its increment: the same addition on the same values) -- and, where
     // the group has a lane to spare (D < 8), lane D stores log_obj in the same instruction.  Pointers
@@ -334,7 +335,13 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
             const bool acc = dd[DP] < dlt;
 #pragma unroll
             for (int p = 0; p < D; ++p) x[p] = acc ? xp[p] : x[p];
-            lp = acc ? lpp : lp;
+            {
+                const double lp_new = acc ? lpp : lp;
+                const unsigned int kc = wave_count_changed(lp_new, lp, r == 0 && live);
+                cnt_total += kc;
+                cnt_first = (g0 + u == 0) ? kc : cnt_first;
+                lp = lp_new;
+            }
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const double ownp = own[k] + mm[k];
@@ -395,6 +402,7 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
         if (p < D && live) P.Xcur[c + P.N * p] = own[k];
     }
     if (r == 0 && live) P.lpcur[c] = lp;
+    wave_store_counts(P, blockIdx.x, cnt_total, cnt_first);
     DEMCZ_STAMP(P, 7);
 }
 

@@ -184,6 +184,13 @@ class HipEngine:
         self._chk(self._L.demcz_get_changed(self._h, int(g_from), int(g_to), _lib.ptr(out, _lib._lp)))
         return out
 
+    def changed_total(self, g_from, g_to, with_source=False):
+        """Sum of get_changed over g_from..g_to, from the window kernels' ballot counters when the range is made of
+        whole launches (demcz_get_changed_total).  with_source: also return whether the ballots answered."""
+        tot, src = C.c_int64(0), C.c_int32(0)
+        self._chk(self._L.demcz_get_changed_total(self._h, int(g_from), int(g_to), C.byref(tot), C.byref(src)))
+        return (int(tot.value), bool(src.value)) if with_source else int(tot.value)
+
     def rhat(self, g_from, g_to):
         out = np.empty(self.d)
         self._chk(self._L.demcz_rhat(self._h, int(g_from), int(g_to), _lib.ptr(out)))

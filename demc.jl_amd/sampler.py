@@ -247,6 +247,14 @@ class _Runner:
             c = self.sh.all_reduce_sum(np.ascontiguousarray(c.astype(np.float64))).astype(np.int64)
         return c
 
+    def changed_total(self, g_from, g_to):
+        """sum(diff(log_obj[:, g_from-1:g_to], dims=2) .!= 0) over all chains: the count of demcz_anneal.jl:50, from the
+        window kernels' ballot counters (no pass over the history)."""
+        t = float(sum(e.changed_total(g_from, g_to) for e in self.engines))
+        if self.sh is not None and self.sh.world_size > 1:
+            t = float(self.sh.all_reduce_sum(np.array([t]))[0])
+        return int(t)
+
     def accept_ratio_mean(self, g_from, g_to):
         r = np.concatenate([e.accept_ratio(g_from, g_to) for e in self.engines])
         s = np.array([r.sum(), float(r.size)])
@@ -515,8 +523,8 @@ def demcz_anneal(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
             if adapt["adapt"] and ig % ae == 0:                                     # demcz_anneal.jl:48-57
                 # sum(diff(log_obj[:, ig-ae+1:ig], dims=2) .!= 0) / (N*ae): the first column of the
                 # window has no predecessor inside the window
-                ch = runner.changed(ig - ae + 2, ig) if ae > 1 else np.zeros(0)
-                accept_ratio = float(ch.sum()) / (N * ae)
+                nch = runner.changed_total(ig - ae + 2, ig) if ae > 1 else 0
+                accept_ratio = float(nch) / (N * ae)
                 if accept_ratio < 0.1:
                     γ = max(adapt["minγ"], γ * 0.5)
                 elif accept_ratio > 0.5:

@@ -140,6 +140,15 @@ int32_t demcz_get_history(demcz_handle* h, int64_t g_from, int64_t g_to, double*
  * demcz_anneal.jl:50. */
 int32_t demcz_get_changed(demcz_handle* h, int64_t g_from, int64_t g_to, int64_t* changed);
 
+/* *total = sum over g in g_from..g_to of the changed[] counts above -- the acceptance count of the annealer's gamma
+ * adaptation (demcz_anneal.jl:50) and of the autostop warning (demcz.jl:42).  The window kernels count it as they
+ * go: one wavefront ballot of "this chain's log_obj changed" per generation, popcount into a scalar register, two
+ * words per wave per launch (no atomics, no second pass over log_obj); when g_from..g_to is covered by whole
+ * launches (it is, for the drivers' windows) the answer is the sum of those words and *from_ballots = 1; otherwise
+ * it is counted from the history like demcz_get_changed (*from_ballots = 0).  from_ballots may be NULL.
+ * Works on handles without a history window (Gcap = 0) in the first case. */
+int32_t demcz_get_changed_total(demcz_handle* h, int64_t g_from, int64_t g_to, int64_t* total, int32_t* from_ballots);
+
 /* Split-chain Gelman-Rubin statistic over generations g_from..g_to of the on-device history:
  * Rhat_gelman(chain[:, :, g_from:g_to], N, g_to-g_from+1, d), src/utils.jl:2-20, as called by
  * the autostop at demcz.jl:41.  rhat receives d values.  On a sharded handle the partial

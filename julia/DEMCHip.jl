@@ -98,6 +98,11 @@ function changed(h, g_from, g_to)
     c = zeros(Int64, g_to - g_from + 1)
     chk(ccall((:demcz_get_changed, libdemcz), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}), h, g_from, g_to, c), h); c
 end
+# sum(changed(h, g_from, g_to)) from the window kernels' ballot counters (no pass over the history)
+function changed_total(h, g_from, g_to)
+    t = Ref{Int64}(0)
+    chk(ccall((:demcz_get_changed_total, libdemcz), Int32, (Ptr{Cvoid}, Int64, Int64, Ref{Int64}, Ptr{Int32}), h, g_from, g_to, t, C_NULL), h); t[]
+end
 function accept_ratio(h, g_from, g_to, N)
     a = zeros(N)
     chk(ccall((:demcz_accept_ratio, libdemcz), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}), h, g_from, g_to, a), h); a
@@ -224,7 +229,7 @@ function demcz_anneal(t::LogObj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, b
             temps = Float64[temperaturefun(g, Ngeneration, T0, TN) for g in ig+1:nxt]   # demcz_anneal.jl:69
             advance!(h, t, N, d, Nblocks, ig + 1, nxt, γ, temps); ig = nxt
             if adaptγ["adapt"] && ig % ae == 0                                         # demcz_anneal.jl:48-57
-                accept = (ae > 1 ? sum(changed(h, ig - ae + 2, ig)) : 0) / (N * ae)
+                accept = (ae > 1 ? changed_total(h, ig - ae + 2, ig) : 0) / (N * ae)
                 if accept < 0.1; γ = max(adaptγ["minγ"], γ * 0.5) elseif accept > 0.5; γ = min(adaptγ["maxγ"], γ * 1.5) end
             end
         end

@@ -57,6 +57,9 @@ class OracleEngine:
     def get_changed(self, g_from, g_to):
         return self.changed[g_from - 1:g_to].copy()
 
+    def changed_total(self, g_from, g_to):
+        return int(self.changed[g_from - 1:g_to].sum())
+
     def rhat(self, g_from, g_to):
         return O.rhat_gelman(self.chain[:, :, g_from - 1:g_to])
 

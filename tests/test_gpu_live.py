@@ -140,3 +140,54 @@ def test_sharded_scatter_kernels_for_R_ranks(demc, R, cnt, batched):
     assert np.array_equal(Z[:M0], w["Zinit"])
     assert np.array_equal(Z[M0:M0 + R * cnt * n_loc], want)
     assert np.array_equal(Z[M0 + R * cnt * n_loc:], 2.0 * want)
+
+
+@pytest.mark.parametrize("kind,d,N,blocks,lanes", [
+    ("mvn", 5, 100, None, 0), ("mvn", 5, 100, None, 8), ("mvn", 5, 100, None, 1), ("mvn", 20, 40, None, 0), ("mvn", 20, 40, None, 16),
+    ("mvn", 6, 50, [[0], [1, 2], [5, 3, 4]], 0), ("mvn", 6, 50, [[0], [1, 2], [5, 3, 4]], 8), ("mvn", 6, 50, [[0], [1, 2], [5, 3, 4]], 1),
+    ("mvn", 7, 30, None, 1), ("linreg", 10, 70, None, 0), ("linreg", 10, 70, None, 16), ("iso", 10, 33, None, 0)])
+def test_ballot_accept_counts_equal_history_counts(demc, oracle, kind, d, N, blocks, lanes):
+    """The accept mask by wavefront ballot (north star): every window kernel counts "log_obj changed" per generation with one
+    ballot + popcount into a scalar register; demcz_get_changed_total sums those words for ranges made of whole launches.
+    Checker: the counts taken from the history (demcz_get_changed) and the oracle's."""
+    G, K, seed = 90, 10, 5
+    w = (demc.workloads.iso_quad_problem(d, N) if kind == "iso" else
+         demc.workloads.linreg_problem(d, N, nobs=70) if kind == "linreg" else demc.workloads.mvnormal_problem(d, N))
+    bl = blocks or [range(d)]
+    M0 = w["Zinit"].shape[0]
+    e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K + 1), Gcap=G, blockindex=bl, eps_scale=w["eps_scale"], seed=seed,
+                       target=w["target"], lanes_per_chain=lanes)
+    e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+    T = np.linspace(3.0, 0.01, G) if kind != "mvn" else None
+    cuts = [(1, 30), (31, 37), (38, 38), (39, 90)]                        # calls cut anywhere
+    for a, b in cuts:
+        e.run(a, b, w["gamma"], None if T is None else T[a - 1:b])
+    hist = e.get_changed(1, G)
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, [list(b) for b in bl] if blocks else None, w["eps_scale"],
+                        w["gamma"], seed, temperature=T)
+    assert np.array_equal(hist, ref["changed"])
+    for a, b in [(1, 30), (1, 90), (31, 38), (2, 30), (32, 90), (39, 90), (40, 90)]:     # whole launches (-1st generation)
+        tot, from_ballots = e.changed_total(a, b, with_source=True)
+        assert tot == int(hist[a - 1:b].sum()), (a, b)
+        assert from_ballots, (a, b)
+    for a, b in [(5, 20), (1, 89), (3, 90)]:                              # not launch-aligned: counted from the history
+        tot, from_ballots = e.changed_total(a, b, with_source=True)
+        assert tot == int(hist[a - 1:b].sum()) and not from_ballots, (a, b)
+    e.close()
+
+
+def test_ballot_counts_without_a_history_window(demc, oracle):
+    """Gcap = 0: no history on the device, the gamma adaptation's count still comes out of the kernels."""
+    N, d, K, G = 64, 10, 10, 100
+    w = demc.workloads.iso_quad_problem(d, N)
+    M0 = w["Zinit"].shape[0]
+    e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K + 1), Gcap=0, blockindex=[range(d)], eps_scale=w["eps_scale"], seed=2,
+                       target=w["target"])
+    e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+    T = np.linspace(2.0, 0.1, G)
+    e.run(1, 50, 2.38, T[:50])
+    e.run(51, 100, 2.38, T[50:])
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], 2.38, 2, temperature=T)
+    assert e.changed_total(52, 100, with_source=True) == (int(ref["changed"][51:].sum()), True)
+    assert e.changed_total(1, 100) == int(ref["changed"].sum())
+    e.close()
