@@ -1174,8 +1174,8 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     P.next_rows = 0; P.next_boff = 0; P.rec_stride = 0;
 #ifdef DEMCZ_STAMPS
     if (!h->d_stamps) {
-        HIPCHK(h, hipMalloc((void**)&h->d_stamps, (size_t)DEMCZ_STAMP_WGS * 8 * sizeof(unsigned long long)));
-        HIPCHK(h, hipMemset(h->d_stamps, 0, (size_t)DEMCZ_STAMP_WGS * 8 * sizeof(unsigned long long)));
+        HIPCHK(h, hipMalloc((void**)&h->d_stamps, (size_t)DEMCZ_STAMP_WGS * 16 * sizeof(unsigned long long)));
+        HIPCHK(h, hipMemset(h->d_stamps, 0, (size_t)DEMCZ_STAMP_WGS * 16 * sizeof(unsigned long long)));
     }
     P.stamps = h->d_stamps;
 #endif
@@ -1996,12 +1996,12 @@ extern "C" int32_t demcz_selftest_draws(int32_t device_id, uint64_t seed, uint64
 }
 
 #ifdef DEMCZ_STAMPS
-// Diagnostic build only: the stamps of the last split-layout launch (8 per workgroup, first `n_wg` workgroups).
+// Diagnostic build only: the stamps of the last split-layout launch (16 per workgroup, first `n_wg` workgroups).
 extern "C" int32_t demcz_debug_read_stamps(demcz_handle* h, unsigned long long* out, int64_t n_wg)
 {
     if (!h || !out || n_wg < 0 || n_wg > DEMCZ_STAMP_WGS || !h->d_stamps) return DEMCZ_ERR_INVALID_ARGUMENT;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(out, h->d_stamps, (size_t)n_wg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(out, h->d_stamps, (size_t)n_wg * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return DEMCZ_OK;
 }
 #endif

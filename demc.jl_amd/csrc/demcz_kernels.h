@@ -18,7 +18,7 @@
 // Diagnostic build (-DDEMCZ_STAMPS, never the shipped library): lane 0 of a workgroup records the
 // shader clock at a few points of the split-layout kernel.
 #ifdef DEMCZ_STAMPS
-#define DEMCZ_STAMP(P, i) do { if ((P).stamps && threadIdx.x == 0 && blockIdx.x < 65536u) (P).stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define DEMCZ_STAMP(P, i) do { if ((P).stamps && threadIdx.x == 0 && blockIdx.x < 65536u) (P).stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define DEMCZ_STAMP(P, i) do { } while (0)
 #endif
@@ -95,7 +95,7 @@ struct WindowParams {
     // once, at the end, to acc_out[2 * wave] -- no atomics, no second pass over log_obj (nullptr: not wanted).
     unsigned int* acc_out;
 #ifdef DEMCZ_STAMPS
-    unsigned long long* stamps;   // diagnostic build only (scripts/stamps.py): 8 s_memtime values per workgroup
+    unsigned long long* stamps;   // diagnostic build only (scripts/stamps.py): 16 values per workgroup (8 stamps, 8 sums)
 #endif
 };
 

@@ -80,6 +80,7 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
     int to_b = P.to_boundary;
     int64_t nb = 0;
     unsigned int cnt_total = 0, cnt_first = 0;             // accept mask by ballot (WindowParams::acc_out)
+    const bool speaks_mask = (r == 0) && live;             // the lane that speaks for its chain in the ballot
     // What a lane stores every generation: its own element(s) of the history row -- tracked beside the
     // replicated state (own' = own + its increment: the same addition on the same values) -- and, where
     // the group has a lane to spare (D < 8), lane D stores log_obj in the same instruction.  Pointers
@@ -127,12 +128,26 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
     constexpr int HW = (D + 1) / 2;                       // 16-byte pieces of a row
     static_assert(2 * HW <= ZSC, "a row's last 16-byte piece stays inside the row");
     const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.Z), 0, 0xffffffffu, 0x00020000);
-    constexpr int ZAUX = LIVE ? 16 : 0;                   // sc1: served past the CU's L1 (demcz_kernels_rec.h)
+    // The prefetch reads every row through the ordinary cached path, also in a LIVE launch.  A row this launch appends
+    // is published by write-through (sc1) stores, so memory always holds its final doubles or the sentinel; what an
+    // ordinary load can add to that is a STALE copy from this XCD's L2 / the CU's L1 -- which, each double of a row being
+    // written once, can only show the sentinel where the final value is not yet seen, never a wrong value.  Slots that
+    // show a sentinel are asked for again with sc1 loads (served past L1 and L2, demcz_kernels_rec.h) at the start of
+    // their chunk.  sc1 loads are kept out of the prefetch because they are slow to ISSUE: measured on the same
+    // gathers, 2.31 -> 2.78 us per 10 generations when every row goes through them (they queue behind the wave's own
+    // outstanding stores), and even a few lanes' worth per instruction costs the same.
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    auto row_piece = [&](uint32_t byte_off, double& lo, double& hi) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, (int)byte_off, 0, ZAUX);
+    auto piece_to = [&](const u32x4 v, double& lo, double& hi) {
         lo = __longlong_as_double((long long)(((uint64_t)v.y << 32) | v.x));
         hi = __longlong_as_double((long long)(((uint64_t)v.w << 32) | v.z));
+    };
+    auto row_piece_sc1 = [&](uint32_t byte_off, double& lo, double& hi) {
+        piece_to(__builtin_amdgcn_raw_buffer_load_b128(zrsrc, (int)byte_off, 0, 16), lo, hi);
+    };
+    // one whole archive row (HW 16-byte pieces)
+    auto row_fetch = [&](uint32_t off, double (&dst)[2 * HW]) {
+#pragma unroll
+        for (int j = 0; j < HW; ++j) piece_to(__builtin_amdgcn_raw_buffer_load_b128(zrsrc, (int)(off + 16u * j), 0, 0), dst[2 * j], dst[2 * j + 1]);
     };
     const double* rec_n[D];                                // normals of this chain, parameter p
 #pragma unroll
@@ -159,6 +174,13 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
         if (__hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     }
     [[maybe_unused]] const int stamp_g0 = (P.ngen > 5 * CH) ? 5 * CH : 0;      // diagnostic build: the chunk that is timed
+#ifdef DEMCZ_STAMPS
+    // diagnostic build: shader-clock sums over ALL chunks of the launch (consumer workgroup's slots 8..15 of its stamp row)
+    unsigned long long sa_front = 0, sa_issue = 0, sa_gen = 0, sa_tail = 0, sa_waits = 0, sa_polls = 0, sa_chunks = 0, sa_t = 0;
+#define DEMCZ_TICK(acc) do { const unsigned long long t_ = __builtin_readcyclecounter(); (acc) += t_ - sa_t; sa_t = t_; } while (0)
+#else
+#define DEMCZ_TICK(acc) do { } while (0)
+#endif
     // in flight for the chunk to come: this lane's generations u = rd * 8 + r
     double za[ROUNDS][2 * HW], zb[ROUNDS][2 * HW], zt[ROUNDS][D], lgv[ROUNDS];
     uint32_t o1[ROUNDS], o2[ROUNDS];
@@ -174,11 +196,8 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
             const uint64_t ii = (uint64_t)__double_as_longlong(ixn[rd]);
             o1[rd] = (u < len) ? (uint32_t)ii << ZSHIFT : 0u;
             o2[rd] = (u < len) ? (uint32_t)(ii >> 32) << ZSHIFT : 0u;
-#pragma unroll
-            for (int j = 0; j < HW; ++j) {
-                row_piece(o1[rd] + 16u * j, za[rd][2 * j], za[rd][2 * j + 1]);
-                row_piece(o2[rd] + 16u * j, zb[rd][2 * j], zb[rd][2 * j + 1]);
-            }
+            row_fetch(o1[rd], za[rd]);
+            row_fetch(o2[rd], zb[rd]);
             const int gu = g0 + ((u < len) ? u : len - 1);
 #pragma unroll
             for (int p = 0; p < ((D == 1) ? 1 : D); ++p) zt[rd][p] = rec_n[p][gu];
@@ -187,25 +206,126 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) ixn[rd] = rec_ix[g0 + len + rd * L + r];      // (the buffers are padded for the overshoot)
     };
-    // PIPE: the prefetch across chunks.  Not in LIVE launches: a K-window's time there is set by the hand-off of the
-    // appended rows (which an early read cannot see), and they keep the chunk's LDS rows in registers instead.
-    constexpr bool PIPE = !LIVE;
+    // Every launch prefetches across chunks (above).  In a LIVE launch the rows the last boundaries appended may not be
+    // there yet when the prefetch reads them -- they read as the sentinel; such a slot is asked for again at the start
+    // of its chunk until the row is there.  Every other row's latency has been taken off the chunk by the prefetch.
+    auto slot_bad = [&](int rd) {
+        bool b = false;
+#pragma unroll
+        for (int p = 0; p < D; ++p) b |= is_sentinel(za[rd][p]) | is_sentinel(zb[rd][p]);
+        return b;
+    };
+    auto refetch = [&](int rd) {      // a row is written by one wave, 8 bytes at a time: re-read whole rows that still hold a sentinel
+        bool ba = false, bb = false;
+#pragma unroll
+        for (int p = 0; p < D; ++p) { ba |= is_sentinel(za[rd][p]); bb |= is_sentinel(zb[rd][p]); }
+        if (ba) {
+#pragma unroll
+            for (int j = 0; j < HW; ++j) row_piece_sc1(o1[rd] + 16u * j, za[rd][2 * j], za[rd][2 * j + 1]);
+        }
+        if (bb) {
+#pragma unroll
+            for (int j = 0; j < HW; ++j) row_piece_sc1(o2[rd] + 16u * j, zb[rd][2 * j], zb[rd][2 * j + 1]);
+        }
+    };
+    // this lane's generation of round rd: increments and log u into the LDS row of (chain, generation)
+    auto form_row = [&](int rd) {
+        const int u = rd * L + r;
+        double dv[DPL];
+#pragma unroll
+        for (int p = 0; p < DP; ++p) {
+            if (p < D) {
+                const double diff = za[rd][p] - zb[rd][p];
+                const double t1 = scale * diff;
+                const double t2 = epsall[p] * zt[rd][(D == 1) ? 0 : p];
+                dv[p] = t1 + t2;
+            } else {
+                dv[p] = 0.0;
+            }
+        }
+        dv[DP] = lgv[rd];
+        dv[DP + 1] = 0.0;
+        if (u < CH) {
+#pragma unroll
+            for (int j = 0; j < DPL / 2; ++j)
+                reinterpret_cast<double2*>(sdelta + (gq * CH + u) * DPL)[j] = make_double2(dv[2 * j], dv[2 * j + 1]);
+        }
+    };
+    auto read_row = [&](int u, double (&dd)[DPL], double (&mm)[NP]) {
+        const double* row = sdelta + (gq * CH + u) * DPL;
+#pragma unroll
+        for (int j = 0; j < DPL / 2; ++j) {
+            const double2 t = reinterpret_cast<const double2*>(row)[j];
+            dd[2 * j] = t.x;
+            dd[2 * j + 1] = t.y;
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) mm[k] = row[pk[k]];              // this lane's own element(s)
+    };
+    // one generation (gi: its index in the launch) from its LDS row (increments, log u), this lane's own increment(s)
+    // and, tempered, its temperature
+    auto generation = [&](int gi, const double (&dd)[DPL], const double (&mm)[NP], [[maybe_unused]] double temp) {
+        double xp[D];
+#pragma unroll
+        for (int p = 0; p < D; ++p) xp[p] = x[p] + dd[p];
+        double lpp;
+        if constexpr (TARGET == TARGET_MVNORMAL) {
+            double q = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double acc = Wc[(i * (i + 1)) / 2] * (xp[0] - muc[0]);
+#pragma unroll
+                for (int j = 1; j <= i; ++j) acc = fma(Wc[(i * (i + 1)) / 2 + j], xp[j] - muc[j], acc);
+                q = (i == 0) ? acc * acc : fma(acc, acc, q);
+            }
+            lpp = fma(-0.5, q, c0c);
+        } else {
+            double q = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const double rr = xp[i] - muc[i];
+                q = (i == 0) ? rr * rr : fma(rr, rr, q);
+            }
+            lpp = -q;
+        }
+        double dlt = lpp - lp;
+        if constexpr (TEMPER) dlt = dlt / temp;
+        const bool acc = dd[DP] < dlt;
+#pragma unroll
+        for (int p = 0; p < D; ++p) x[p] = acc ? xp[p] : x[p];
+        {
+            const double lp_new = acc ? lpp : lp;
+            const unsigned int kc = wave_count_changed(lp_new, lp, speaks_mask);
+            cnt_total += kc;
+            cnt_first = (gi == 0) ? kc : cnt_first;
+            lp = lp_new;
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const double ownp = own[k] + mm[k];
+            own[k] = acc ? ownp : own[k];
+            const double val = (LP_MERGED && k == 0 && lp_lane) ? lp : own[k];
+            if (son[k]) *sptr[k] = val;
+            sptr[k] += sstride[k];       // next generation's slab: a stride, no per-lane multiply
+        }
+        if constexpr (!LP_MERGED) {
+            if (hist_on && lp_lane) *lobj = lp;
+            lobj += P.N;
+        }
+    };
     int len = chunk_len(0, to_b);
-    if constexpr (PIPE) issue(0, len);
+    issue(0, len);
     for (int g0 = 0; g0 < P.ngen; g0 += len) {
         if (g0 == stamp_g0) DEMCZ_STAMP(P, 5);
 #ifdef DEMCZ_STAMPS
-        if (P.stamps && threadIdx.x == 0) P.stamps[(size_t)blockIdx.x * 8 + 6] = 1000000ull + (unsigned long long)g0;   // progress
+        if (P.stamps && threadIdx.x == 0) P.stamps[(size_t)blockIdx.x * 16 + 6] = 1000000ull + (unsigned long long)g0;   // progress
+        sa_t = __builtin_readcyclecounter();
+        ++sa_chunks;
 #endif
         if (g0 > 0) len = chunk_len(g0, to_b);
-        if constexpr (!PIPE) {
-            issue(g0, len);
-            __builtin_amdgcn_sched_barrier(0);      // nothing that waits for a record in front of the gather's issue
-        }
         if constexpr (LIVE) {
-            // rows another wave has not published yet read as the sentinel: ask again.  Cheap filter first:
-            // the sentinel's high word is that of a negative NaN, above every finite value's, -inf's and
-            // the canonical NaN's -- a max per value instead of a 64-bit compare
+            // Cheap filter first: the sentinel's high word is that of a negative NaN, above every finite value's, -inf's
+            // and the canonical NaN's -- a max per value instead of a 64-bit compare
             uint32_t hmax = 0u;
 #pragma unroll
             for (int rd = 0; rd < ROUNDS; ++rd)
@@ -215,161 +335,71 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
                     const uint32_t hb = (uint32_t)((uint64_t)__double_as_longlong(zb[rd][p]) >> 32);
                     hmax = max(hmax, max(ha, hb));
                 }
-            bool bad = false;
             if (__builtin_amdgcn_ballot_w64(hmax >= (uint32_t)(LIVE_SENTINEL >> 32)) != 0ull) {
+                // some slot of the wave holds a row that had not been published when the prefetch read it: ask again
+                // until it is there (the prefetch has taken the ordinary latency off every other row already)
+                bool bad = false;
 #pragma unroll
-                for (int rd = 0; rd < ROUNDS; ++rd)
+                for (int rd = 0; rd < ROUNDS; ++rd) bad |= slot_bad(rd);
+                int spins = 0;
+#ifdef DEMCZ_STAMPS
+                if (__builtin_amdgcn_ballot_w64(bad) != 0ull) ++sa_waits;
+#endif
+                while (__builtin_amdgcn_ballot_w64(bad) != 0ull) {           // wave-uniform
+#ifdef DEMCZ_STAMPS
+                    ++sa_polls;
+#endif
+                    unsigned waiting_row = 0;
 #pragma unroll
-                    for (int p = 0; p < D; ++p) bad |= is_sentinel(za[rd][p]) | is_sentinel(zb[rd][p]);
-            }
-            int spins = 0;
-            while (__builtin_amdgcn_ballot_w64(bad) != 0ull) {           // wave-uniform
-                unsigned waiting_row = 0;
+                    for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
-                for (int rd = 0; rd < ROUNDS; ++rd)
-#pragma unroll
-                    for (int p = 0; p < D; ++p) {
-                        if (is_sentinel(za[rd][p])) waiting_row = o1[rd] >> ZSHIFT;
-                        if (is_sentinel(zb[rd][p])) waiting_row = o2[rd] >> ZSHIFT;
+                        for (int p = 0; p < D; ++p) {
+                            if (is_sentinel(za[rd][p])) waiting_row = o1[rd] >> ZSHIFT;
+                            if (is_sentinel(zb[rd][p])) waiting_row = o2[rd] >> ZSHIFT;
+                        }
+                    if (spins > 0) {
+                        if (live_poll_abandon(P, spins, bad, waiting_row, g0)) return;      // wave-uniform
+                        __builtin_amdgcn_s_sleep(1);
+                    } else {
+                        spins = 1;
                     }
-                if (live_poll_abandon(P, spins, bad, waiting_row, g0)) return;      // wave-uniform
-                __builtin_amdgcn_s_sleep(1);
-                bad = false;
+                    bad = false;
 #pragma unroll
-                for (int rd = 0; rd < ROUNDS; ++rd) {
-                    // a row is written by one wave, 8 bytes at a time: re-read whole rows that still hold a sentinel
-                    bool ba = false, bb = false;
-#pragma unroll
-                    for (int p = 0; p < D; ++p) { ba |= is_sentinel(za[rd][p]); bb |= is_sentinel(zb[rd][p]); }
-                    if (ba) {
-#pragma unroll
-                        for (int j = 0; j < HW; ++j) row_piece(o1[rd] + 16u * j, za[rd][2 * j], za[rd][2 * j + 1]);
+                    for (int rd = 0; rd < ROUNDS; ++rd) {
+                        refetch(rd);
+                        bad |= slot_bad(rd);
                     }
-                    if (bb) {
-#pragma unroll
-                        for (int j = 0; j < HW; ++j) row_piece(o2[rd] + 16u * j, zb[rd][2 * j], zb[rd][2 * j + 1]);
-                    }
-#pragma unroll
-                    for (int p = 0; p < D; ++p) bad |= is_sentinel(za[rd][p]) | is_sentinel(zb[rd][p]);
                 }
             }
         }
-        // this lane's generations: increments and log u into the LDS rows of the chain
 #pragma unroll
-        for (int rd = 0; rd < ROUNDS; ++rd) {
-            const int u = rd * L + r;
-            double dv[DPL];
-#pragma unroll
-            for (int p = 0; p < DP; ++p) {
-                if (p < D) {
-                    const double diff = za[rd][p] - zb[rd][p];
-                    const double t1 = scale * diff;
-                    const double t2 = epsall[p] * zt[rd][(D == 1) ? 0 : p];
-                    dv[p] = t1 + t2;
-                } else {
-                    dv[p] = 0.0;
-                }
-            }
-            dv[DP] = lgv[rd];
-            dv[DP + 1] = 0.0;
-            if (u < CH) {
-#pragma unroll
-                for (int j = 0; j < DPL / 2; ++j)
-                    reinterpret_cast<double2*>(sdelta + (gq * CH + u) * DPL)[j] = make_double2(dv[2 * j], dv[2 * j + 1]);
-            }
-        }
+        for (int rd = 0; rd < ROUNDS; ++rd) form_row(rd);
         if (g0 == stamp_g0) DEMCZ_STAMP(P, 3);
         wave_lds_handoff();
+        DEMCZ_TICK(sa_front);
         // the chunk after this one: its loads fly during this chunk's generations
         {
             const int tb_n = (to_b - len == 0) ? P.K : to_b - len;
             const int g0n = g0 + len;
-            if constexpr (PIPE) { if (g0n < P.ngen) issue(g0n, chunk_len(g0n, tb_n)); }
+            if (g0n < P.ngen) issue(g0n, chunk_len(g0n, tb_n));
             __builtin_amdgcn_sched_barrier(0);      // the generation code below must not be scheduled in front of the issue
         }
         if (g0 == stamp_g0) DEMCZ_STAMP(P, 2);
-        // generations of the chunk: the LDS row of generation u + 1 is read while generation u computes
-        [[maybe_unused]] double tmpr[CH];
-        if constexpr (TEMPER) {
+        DEMCZ_TICK(sa_issue);
+        {
+            // generations of the chunk: the LDS row of generation u + 1 is read while generation u computes
+            [[maybe_unused]] double tmpr[CH];
+            if constexpr (TEMPER) {
 #pragma unroll
-            for (int u = 0; u < CH; ++u) tmpr[u] = P.temperature[g0 + ((u < len) ? u : len - 1)];
-        }
-        auto read_row = [&](int u, double (&dd)[DPL], double (&mm)[NP]) {
-            const double* row = sdelta + (gq * CH + u) * DPL;
-#pragma unroll
-            for (int j = 0; j < DPL / 2; ++j) {
-                const double2 t = reinterpret_cast<const double2*>(row)[j];
-                dd[2 * j] = t.x;
-                dd[2 * j + 1] = t.y;
+                for (int u = 0; u < CH; ++u) tmpr[u] = P.temperature[g0 + ((u < len) ? u : len - 1)];
             }
-#pragma unroll
-            for (int k = 0; k < NP; ++k) mm[k] = row[pk[k]];              // this lane's own element(s)
-        };
-        // one generation from its LDS row (increments, log u) and this lane's own increment(s)
-        auto generation = [&](int u, const double (&dd)[DPL], const double (&mm)[NP]) {
-            double xp[D];
-#pragma unroll
-            for (int p = 0; p < D; ++p) xp[p] = x[p] + dd[p];
-            double lpp;
-            if constexpr (TARGET == TARGET_MVNORMAL) {
-                double q = 0.0;
-#pragma unroll
-                for (int i = 0; i < D; ++i) {
-                    double acc = Wc[(i * (i + 1)) / 2] * (xp[0] - muc[0]);
-#pragma unroll
-                    for (int j = 1; j <= i; ++j) acc = fma(Wc[(i * (i + 1)) / 2 + j], xp[j] - muc[j], acc);
-                    q = (i == 0) ? acc * acc : fma(acc, acc, q);
-                }
-                lpp = fma(-0.5, q, c0c);
-            } else {
-                double q = 0.0;
-#pragma unroll
-                for (int i = 0; i < D; ++i) {
-                    const double rr = xp[i] - muc[i];
-                    q = (i == 0) ? rr * rr : fma(rr, rr, q);
-                }
-                lpp = -q;
-            }
-            double dlt = lpp - lp;
-            if constexpr (TEMPER) dlt = dlt / tmpr[u];
-            const bool acc = dd[DP] < dlt;
-#pragma unroll
-            for (int p = 0; p < D; ++p) x[p] = acc ? xp[p] : x[p];
-            {
-                const double lp_new = acc ? lpp : lp;
-                const unsigned int kc = wave_count_changed(lp_new, lp, r == 0 && live);
-                cnt_total += kc;
-                cnt_first = (g0 + u == 0) ? kc : cnt_first;
-                lp = lp_new;
-            }
-#pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                const double ownp = own[k] + mm[k];
-                own[k] = acc ? ownp : own[k];
-                const double val = (LP_MERGED && k == 0 && lp_lane) ? lp : own[k];
-                if (son[k]) *sptr[k] = val;
-                sptr[k] += sstride[k];       // next generation's slab: a stride, no per-lane multiply
-            }
-            if constexpr (!LP_MERGED) {
-                if (hist_on && lp_lane) *lobj = lp;
-                lobj += P.N;
-            }
-        };
-        if constexpr (!PIPE) {
-            double dall[CH][DPL], mall[CH][NP];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) read_row(u, dall[u], mall[u]);
-#pragma unroll
-            for (int u = 0; u < CH; ++u)
-                if (u < len) generation(u, dall[u], mall[u]);       // wave-uniform
-        } else {
             double dcur[DPL], dnxt[DPL], mcur[NP], mnxt[NP];
             read_row(0, dcur, mcur);
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 if (u < len) {       // wave-uniform
                     if (u + 1 < CH) read_row(u + 1, dnxt, mnxt);
-                    generation(u, dcur, mcur);
+                    generation(g0 + u, dcur, mcur, TEMPER ? tmpr[u] : 0.0);
 #pragma unroll
                     for (int p = 0; p < DPL; ++p) dcur[p] = dnxt[p];
 #pragma unroll
@@ -377,6 +407,7 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
                 }
             }
         }
+        DEMCZ_TICK(sa_gen);
         to_b -= len;
         if (to_b == 0) {         // the chunk ended on a generation divisible by K: runchain!'s append, demcz.jl:88-91
 #pragma unroll
@@ -395,7 +426,14 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
         }
         if (g0 == stamp_g0) DEMCZ_STAMP(P, 4);
         wave_lds_handoff();      // sdelta is rewritten by the next chunk
+        DEMCZ_TICK(sa_tail);
     }
+#ifdef DEMCZ_STAMPS
+    if (P.stamps && threadIdx.x == 0 && blockIdx.x < 65536u) {
+        unsigned long long* o = P.stamps + (size_t)blockIdx.x * 16 + 8;
+        o[0] = sa_front; o[1] = sa_issue; o[2] = sa_gen; o[3] = sa_tail; o[4] = sa_waits; o[5] = sa_polls; o[6] = sa_chunks;
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int p = r + L * k;

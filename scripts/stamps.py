@@ -38,7 +38,7 @@ lib = _lib.load()
 ncons = (N + 7) // 8
 nprod = ((N + 63) // 64) * 4 * (K * max(lag, 1))      # (rough: producer workgroups of the launch's successor)
 nwg = ncons + nprod
-buf = np.zeros((nwg, 8), dtype=np.uint64)
+buf = np.zeros((nwg, 16), dtype=np.uint64)
 lib.demcz_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 rc = lib.demcz_debug_read_stamps(e._h, buf.ctypes.data_as(C.c_void_p), nwg)
 assert rc == 0, rc
@@ -53,6 +53,17 @@ print(f"  timed chunk starts at +{np.mean(c[:,5]-c[:,0]):.0f} (mean); chunk-rela
 for i in (3, 2, 4, 7):
     dt = c[:, i] - (c[:, 0] if i == 7 else c[:, 5])
     print(f"  consumer +{np.mean(dt):8.0f} mean  {np.min(dt):6d} min {np.max(dt):6d} max   {names[i]}")
+nch = c[:, 14].astype(float)
+if nch.min() > 0:
+    print("  sums over all chunks of the launch, ticks per chunk (mean over consumers / slowest consumer):")
+    for j, nm in ((8, "chunk start -> rows there, increments in LDS (waits for unpublished rows included)"),
+                  (9, "-> next chunk's loads issued"), (10, "-> generations done"), (11, "-> append + LDS hand-off")):
+        v = c[:, j] / nch
+        print(f"    {v.mean():8.0f} {v.max():8.0f}   {nm}")
+    tot = (c[:, 8] + c[:, 9] + c[:, 10] + c[:, 11]) / nch
+    print(f"    {tot.mean():8.0f} {tot.max():8.0f}   per chunk in all; chunks per launch {nch.mean():.0f}")
+    print(f"    chunks that had to ask again for a row: {100 * (c[:, 12] / nch).mean():.1f} % (mean over consumers), polls per such chunk "
+          f"{(c[:, 13].sum() / max(c[:, 12].sum(), 1)):.1f}")
 p = s[ncons:nwg]
 ok = p[:, 7] > 0
 print(f"  producer: {ok.sum()} workgroups wrote; body {np.mean((p[ok,7]-p[ok,0])):.0f} mean {np.max(p[ok,7]-p[ok,0])} max; last exit at {np.max(p[ok,7])-t00} after the first entry")
