@@ -313,6 +313,10 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
             lobj += P.N;
         }
     };
+    // Everything loaded so far (state, target constants, eps, the first row indices) is in registers before the pipeline
+    // starts: a constant still in flight at the loop's entry can make its first use inside the loop wait for "everything
+    // outstanding" on every trip -- the prefetched loads of the next chunk included (seen: 2.25 -> 2.97 us per chunk).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int len = chunk_len(0, to_b);
     issue(0, len);
     for (int g0 = 0; g0 < P.ngen; g0 += len) {
