@@ -55,9 +55,7 @@ def measured_traffic(n_loc, d, K, lanes, gens_per_launch):
     if abs(float(shape.get("generations_per_launch", -1)) - gens_per_launch) > 1e-9:
         return None
     for k, v in prof["kernels"].items():
-        if k.startswith(shape.get("kernel_prefix", "window_kernel")):
-            if abs(v.get("launches_per_run_mean_gens", gens_per_launch) - gens_per_launch) > 1e-9:
-                continue
+        if k.startswith(shape.get("kernel_prefix", "void demcz::window_kernel")):
             return v.get("bytes_per_launch_raw"), v.get("bytes_per_launch_fetch_x2"), f"profiles/{prof.get('tag')}_traffic.json"
     return None
 

@@ -183,13 +183,11 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
                 const int p = r + L * k;
                 const int pc = (p < D) ? p : 0;
                 zt[k] = rq_z[k][gi];
-                if constexpr (LIVE) {
-                    za[k] = live_load(&P.Z[(int64_t)ra * P.ZS + pc]);
-                    zb[k] = live_load(&P.Z[(int64_t)rb * P.ZS + pc]);
-                } else {
-                    za[k] = P.Z[(int64_t)ra * P.ZS + pc];
-                    zb[k] = P.Z[(int64_t)rb * P.ZS + pc];
-                }
+                // (also in a LIVE launch the first read takes the ordinary cached path: a stale copy can only show the
+                //  sentinel where the row's final doubles are not yet seen, and a sentinel is asked for again with sc1
+                //  loads below -- sc1 loads are slow to issue, demcz_kernels_pc.h)
+                za[k] = P.Z[(int64_t)ra * P.ZS + pc];
+                zb[k] = P.Z[(int64_t)rb * P.ZS + pc];
             }
             return;
         }
@@ -541,13 +539,9 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
                 tslot[k] = ts;
                 const int zi = (b == 1 || ts < 0) ? 0 : ts;
                 zt[k] = reinterpret_cast<const double*>(rec)[(gq * L + 1 + zi / 2) * 2 + (zi & 1)];
-                if constexpr (LIVE) {
-                    za[k] = (ts >= 0) ? live_load(&P.Z[row1_n * P.ZS + pc]) : 0.0;
-                    zb[k] = (ts >= 0) ? live_load(&P.Z[row2_n * P.ZS + pc]) : 0.0;
-                } else {
-                    za[k] = (ts >= 0) ? P.Z[row1_n * P.ZS + pc] : 0.0;
-                    zb[k] = (ts >= 0) ? P.Z[row2_n * P.ZS + pc] : 0.0;
-                }
+                // (LIVE launches too: ordinary cached first read, sc1 only when a sentinel shows -- see window_kernel_ml)
+                za[k] = (ts >= 0) ? P.Z[row1_n * P.ZS + pc] : 0.0;
+                zb[k] = (ts >= 0) ? P.Z[row2_n * P.ZS + pc] : 0.0;
             }
             wave_lds_handoff();
             return;
