@@ -669,12 +669,12 @@ constexpr size_t REC_PAD = 32;       // chains per consumer workgroup: 8 lanes p
 template <int TARGET, int D>
 static void launch_pc(const demcz_handle* h, const WindowParams& P, int64_t blocks, bool live)
 {
-    const dim3 grid((unsigned)blocks), wg(64);
+    const dim3 grid((unsigned)blocks), wg(64), wgl(64 * PC8_LIVE_WAVES);     // LIVE: chains wave + publisher wave
     if (P.temperature) {      // tempered accept (demcz_anneal.jl:172-178): its own instantiation, no branch per generation
-        if (live) hipLaunchKernelGGL((window_kernel_pc8<TARGET, D, true, true>), grid, wg, 0, h->stream, P);
+        if (live) hipLaunchKernelGGL((window_kernel_pc8<TARGET, D, true, true>), grid, wgl, 0, h->stream, P);
         else hipLaunchKernelGGL((window_kernel_pc8<TARGET, D, false, true>), grid, wg, 0, h->stream, P);
     } else {
-        if (live) hipLaunchKernelGGL((window_kernel_pc8<TARGET, D, true, false>), grid, wg, 0, h->stream, P);
+        if (live) hipLaunchKernelGGL((window_kernel_pc8<TARGET, D, true, false>), grid, wgl, 0, h->stream, P);
         else hipLaunchKernelGGL((window_kernel_pc8<TARGET, D, false, false>), grid, wg, 0, h->stream, P);
     }
 }
@@ -685,7 +685,9 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
     const int64_t nbc = (P.N + 63) / 64;
     const bool lr_split = h->split_kind == 2 && h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE;
     const int64_t units = nbc * rec_roles(h) * P.next_ngen;               // 64-lane producer units
-    const int64_t blocks = P.consumer_blocks + (lr_split ? (units + ML_LR_WAVES - 1) / ML_LR_WAVES : units);
+    // producer units per workgroup = waves per workgroup of the instantiation that is launched
+    const int upw = lr_split ? ML_LR_WAVES : (h->split_kind == 1 && live) ? PC8_LIVE_WAVES : 1;
+    const int64_t blocks = P.consumer_blocks + (units + upw - 1) / upw;
     if (blocks <= 0) return DEMCZ_OK;
     if (h->split_kind == 3) {
         const dim3 grid((unsigned)blocks), wg(64);
@@ -1033,8 +1035,8 @@ template <int TARGET, int D>
 static int pc_live_blocks_per_cu()
 {
     int a = 0, b = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&window_kernel_pc8<TARGET, D, true, false>), 64, 0) != hipSuccess) a = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(&window_kernel_pc8<TARGET, D, true, true>), 64, 0) != hipSuccess) b = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&window_kernel_pc8<TARGET, D, true, false>), 64 * PC8_LIVE_WAVES, 0) != hipSuccess) a = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(&window_kernel_pc8<TARGET, D, true, true>), 64 * PC8_LIVE_WAVES, 0) != hipSuccess) b = 0;
     return std::min(a, b);
 }
 

@@ -43,21 +43,74 @@ namespace demcz {
 // ------------------------------------------------------------------------------------------------
 constexpr int PC8_CHUNK = 10;
 
+// LIVE launches: a workgroup is TWO waves.  Wave 0 runs the chains; wave 1 is the PUBLISHER: at a K boundary wave 0
+// leaves its eight chains' rows in LDS and goes on, wave 1 picks them up and writes them through to the archive (sc1
+// stores) for the other waves to find.  Why a second wave: a wave's vector-memory instructions behind one of its own
+// write-through stores wait for that store's round trip to memory (measured: ~0.4 us of every K-window, wherever the
+// next load or store of the wave happened to be) -- the publisher has nothing behind its store.
+constexpr int PC8_LIVE_WAVES = 2;
+
 template <int TARGET, int D, bool LIVE, bool TEMPER>
-__global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
+__global__ void __launch_bounds__(LIVE ? 64 * PC8_LIVE_WAVES : 64) window_kernel_pc8(const WindowParams P)
 {
     static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "split layout: MvNormal / isotropic targets");
     constexpr int L = 8, G = 64 / L, DP = ((D + 1) / 2) * 2;
     constexpr int NP = (D + L - 1) / L;                    // history elements a lane stores: r, r+8, ...
     constexpr int CH = (D <= 5) ? PC8_CHUNK : PC8_CHUNK / 2;      // (LIVE launches hold a chunk's CH x D increments in registers)
+    constexpr int WAVES = LIVE ? PC8_LIVE_WAVES : 1;
     DEMCZ_STAMP(P, 0);
-    if ((int64_t)blockIdx.x >= P.consumer_blocks) {
-        pc_produce<D>(P, (int64_t)blockIdx.x - P.consumer_blocks);
+    if ((int64_t)blockIdx.x >= P.consumer_blocks) {        // every wave of a producer workgroup is one 64-lane producer unit
+        pc_produce<D>(P, ((int64_t)blockIdx.x - P.consumer_blocks) * WAVES + (int64_t)(threadIdx.x >> 6), (int)(threadIdx.x & 63));
         DEMCZ_STAMP(P, 7);
         return;
     }
     constexpr int DPL = DP + 2;                            // LDS row of a (chain, generation): DP increments, log u, pad
     __shared__ __attribute__((aligned(16))) double sdelta[G * CH * DPL];
+    // LIVE: the rows of a boundary on their way from wave 0 to the publisher (two boundaries' worth), and the hand-shake:
+    // pub_seq = boundaries wave 0 has left here, pub_done = boundaries the publisher has written out, pub_exit = wave 0 is leaving
+    __shared__ double pub_rows[LIVE ? 2 * G * D : 1];
+    __shared__ unsigned int pub_seq, pub_done, pub_exit;
+    if constexpr (LIVE) {
+        if (threadIdx.x == 0) { pub_seq = 0u; pub_done = 0u; pub_exit = 0u; }
+        __syncthreads();
+        if (threadIdx.x >= 64) {
+            const int l = (int)threadIdx.x - 64;
+            const int64_t c0 = (int64_t)blockIdx.x * G;
+            unsigned int done = 0u, idle = 0u;
+            while (true) {
+                const unsigned int seq = __hip_atomic_load(&pub_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (seq != done) {
+                    const double* rows = pub_rows + (done & 1u) * (G * D);
+                    for (int e = l; e < G * D; e += 64) {
+                        const int g = e / D, p = e % D;
+                        const double v = rows[e];
+                        if (c0 + g < P.N && P.do_append) live_store(&P.Zw[(P.M_append + (int64_t)done * P.N + c0 + g) * P.ZS + p], v);
+                    }
+                    asm volatile("" ::: "memory");
+                    ++done;
+                    if (l == 0) __hip_atomic_store(&pub_done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    idle = 0u;
+                    continue;
+                }
+                if (__hip_atomic_load(&pub_exit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {
+                    // (pub_seq is written before pub_exit: what is read now is final)
+                    if (__hip_atomic_load(&pub_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == done) break;
+                    continue;
+                }
+                // safety net: a launch that is being abandoned drains even if wave 0 could not say so
+                if ((++idle & 4095u) == 0u && __hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            return;
+        }
+    }
+    // wave 0 tells the publisher that nothing more is coming (every way out of a LIVE launch passes here)
+    auto leave = [&]() {
+        if constexpr (LIVE) {
+            asm volatile("" ::: "memory");
+            if (threadIdx.x == 0) __hip_atomic_store(&pub_exit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
     const int lane = threadIdx.x, r = lane % L, gq = lane / L;
     // groups beyond the last chain shadow chain N-1 and store nothing
     const int64_t c_own = (int64_t)blockIdx.x * G + gq;
@@ -171,7 +224,7 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
     // reads its increments from LDS one generation ahead instead of holding the whole chunk in registers --
     // that is what frees the registers the prefetch lives in.
     if constexpr (LIVE) {       // an earlier launch of the run already failed: do not wait again
-        if (__hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+        if (__hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { leave(); return; }
     }
     [[maybe_unused]] const int stamp_g0 = (P.ngen > 5 * CH) ? 5 * CH : 0;      // diagnostic build: the chunk that is timed
 #ifdef DEMCZ_STAMPS
@@ -362,7 +415,7 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
                             if (is_sentinel(zb[rd][p])) waiting_row = o2[rd] >> ZSHIFT;
                         }
                     if (spins > 0) {
-                        if (live_poll_abandon(P, spins, bad, waiting_row, g0)) return;      // wave-uniform
+                        if (live_poll_abandon(P, spins, bad, waiting_row, g0)) { leave(); return; }      // wave-uniform
                         __builtin_amdgcn_s_sleep(1);
                     } else {
                         spins = 1;
@@ -414,14 +467,24 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
         DEMCZ_TICK(sa_gen);
         to_b -= len;
         if (to_b == 0) {         // the chunk ended on a generation divisible by K: runchain!'s append, demcz.jl:88-91
+            if constexpr (LIVE) {
+                // the rows go to the publisher through LDS (the half of pub_rows it emptied two boundaries ago)
+                while (__hip_atomic_load(&pub_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 2u <= (unsigned int)nb)
+                    __builtin_amdgcn_s_sleep(1);
+                double* rows = pub_rows + ((unsigned int)nb & 1u) * (G * D);
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const int p = r + L * k;
+                    if (p < D) rows[gq * D + p] = own[k];
+                }
+                asm volatile("" ::: "memory");                 // (one wave's LDS operations execute in order)
+                if (threadIdx.x == 0) __hip_atomic_store(&pub_seq, (unsigned int)nb + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const int p = r + L * k;
                 if (p < D && live) {
-                    if (P.do_append) {
-                        if constexpr (LIVE) live_store(&P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p], own[k]);
-                        else P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p] = own[k];
-                    }
+                    if constexpr (!LIVE) { if (P.do_append) P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p] = own[k]; }
                     if (P.snap) P.snap[nb * P.N * D + c + P.N * p] = own[k];
                 }
             }
@@ -445,6 +508,7 @@ __global__ void __launch_bounds__(64) window_kernel_pc8(const WindowParams P)
     }
     if (r == 0 && live) P.lpcur[c] = lp;
     wave_store_counts(P, blockIdx.x, cnt_total, cnt_first);
+    leave();
     DEMCZ_STAMP(P, 7);
 }
 
