@@ -99,11 +99,13 @@ struct WindowParams {
 #endif
 };
 
-// Chains of this wave whose log_obj changed in a generation: ballot of the lanes that speak for a chain.
-__device__ __forceinline__ unsigned int wave_count_changed(double lp_after, double lp_before, bool speaks)
+// Chains of this wave whose log_obj changed in a generation: a vector compare straight into a lane mask (the wavefront
+// ballot), AND the mask of the lanes that speak for a chain (wave-uniform, computed once), popcount.
+__device__ __forceinline__ unsigned int wave_count_changed(double lp_after, double lp_before, unsigned long long speak64)
 {
     const double df = lp_after - lp_before;          // NaN (from +-Inf - +-Inf, or NaN) counts, as in Julia's diff(.) .!= 0
-    return (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(speaks && (df != 0.0)));
+    const unsigned long long m = __builtin_amdgcn_fcmp(df, 0.0, 14 /* UNE: unordered or not equal */);
+    return (unsigned int)__builtin_popcountll(m & speak64);
 }
 __device__ __forceinline__ void wave_store_counts(const WindowParams& P, int64_t wave, unsigned int total, unsigned int first)
 {
@@ -228,6 +230,7 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel(const WindowParams P)
     int to_b = P.to_boundary;            // countdown to the next K boundary
     int64_t nb = 0;                      // boundaries passed inside this launch
     unsigned int cnt_total = 0, cnt_first = 0;
+    const unsigned long long speak64 = __builtin_amdgcn_ballot_w64(true);      // every lane still here runs a chain
 
     for (int gi = 0; gi < P.ngen; ++gi) {
         const int nblocks = FULL ? 1 : P.Nblocks;
@@ -298,7 +301,7 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel(const WindowParams P)
             lp = acc ? lpp : lp;
         }
         {
-            const unsigned int k = wave_count_changed(lp, lp_gen0, true);
+            const unsigned int k = wave_count_changed(lp, lp_gen0, speak64);
             cnt_total += k;
             cnt_first = (gi == 0) ? k : cnt_first;
         }
@@ -347,6 +350,7 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel_generic(const WindowP
     int to_b = P.to_boundary;            // countdown to the next K boundary
     int64_t nb = 0;                      // boundaries passed inside this launch
     unsigned int cnt_total = 0, cnt_first = 0;
+    const unsigned long long speak64 = __builtin_amdgcn_ballot_w64(true);      // every lane still here runs a chain
 
     for (int gi = 0; gi < P.ngen; ++gi) {
         const double lp_gen0 = lp;
@@ -392,7 +396,7 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel_generic(const WindowP
             }
         }
         {
-            const unsigned int k = wave_count_changed(lp, lp_gen0, true);
+            const unsigned int k = wave_count_changed(lp, lp_gen0, speak64);
             cnt_total += k;
             cnt_first = (gi == 0) ? k : cnt_first;
         }

@@ -170,6 +170,7 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
     int to_b = P.to_boundary;            // countdown to the next K boundary
     int64_t nb = 0;                      // boundaries passed inside this launch
     unsigned int cnt_total = 0, cnt_first = 0;      // accept mask by ballot (WindowParams::acc_out)
+    const unsigned long long speak64 = __builtin_amdgcn_ballot_w64(r == 0 && active);     // one lane speaks for a chain
     auto issue_draws = [&](int gi) {
         if constexpr (REC) {
             const uint64_t ii = ix_next;
@@ -377,7 +378,7 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
         const bool acc = logu < dlt;
         {
             const double lp_new = acc ? lpp : lp;
-            const unsigned int kc = wave_count_changed(lp_new, lp, r == 0 && active);
+            const unsigned int kc = wave_count_changed(lp_new, lp, speak64);
             cnt_total += kc;
             cnt_first = (gi == 0) ? kc : cnt_first;
             lp = lp_new;
@@ -585,6 +586,7 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
     int to_b = P.to_boundary;
     int64_t nb = 0;
     unsigned int cnt_total = 0, cnt_first = 0;             // accept mask by ballot (WindowParams::acc_out)
+    const unsigned long long speak64 = __builtin_amdgcn_ballot_w64(r == 0);
     for (int gi = 0; gi < P.ngen; ++gi) {
         const double lp_gen0 = lp;
         for (int ib = 0; ib < NB; ++ib) {
@@ -678,7 +680,7 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
             wave_lds_handoff();
         }
         {
-            const unsigned int kc = wave_count_changed(lp, lp_gen0, r == 0);
+            const unsigned int kc = wave_count_changed(lp, lp_gen0, speak64);
             cnt_total += kc;
             cnt_first = (gi == 0) ? kc : cnt_first;
         }

@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(LIVE ? 64 * PC8_LIVE_WAVES : 64) window_kernel
     int to_b = P.to_boundary;
     int64_t nb = 0;
     unsigned int cnt_total = 0, cnt_first = 0;             // accept mask by ballot (WindowParams::acc_out)
-    const bool speaks_mask = (r == 0) && live;             // the lane that speaks for its chain in the ballot
+    const unsigned long long speaks_mask = __builtin_amdgcn_ballot_w64((r == 0) && live);   // the lanes that speak for a chain in the ballot
     // What a lane stores every generation: its own element(s) of the history row -- tracked beside the
     // replicated state (own' = own + its increment: the same addition on the same values) -- and, where
     // the group has a lane to spare (D < 8), lane D stores log_obj in the same instruction.  Pointers
@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(LIVE ? 64 * PC8_LIVE_WAVES : 64) window_kernel
             const double ownp = own[k] + mm[k];
             own[k] = acc ? ownp : own[k];
             const double val = (LP_MERGED && k == 0 && lp_lane) ? lp : own[k];
-            if (son[k]) *sptr[k] = val;
+            if (son[k]) *sptr[k] = val;      // (tried: idle lanes storing to a scrap word instead of the exec mask -- 2.24 -> 2.37 us per chunk)
             sptr[k] += sstride[k];       // next generation's slab: a stride, no per-lane multiply
         }
         if constexpr (!LP_MERGED) {
@@ -450,6 +450,8 @@ __global__ void __launch_bounds__(LIVE ? 64 * PC8_LIVE_WAVES : 64) window_kernel
 #pragma unroll
                 for (int u = 0; u < CH; ++u) tmpr[u] = P.temperature[g0 + ((u < len) ? u : len - 1)];
             }
+            // (tried: ping-pong buffers named at compile time instead of the copies below -- four instructions fewer per
+            //  generation and 7 % SLOWER, 2.17 -> 2.33 us per chunk: the copies keep the next row's LDS reads early)
             double dcur[DPL], dnxt[DPL], mcur[NP], mnxt[NP];
             read_row(0, dcur, mcur);
 #pragma unroll
