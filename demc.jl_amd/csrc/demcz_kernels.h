@@ -211,6 +211,16 @@ __device__ __forceinline__ double target_logp(const TargetParams& tp, int d, XF 
 // DEMC.jl:41) -- no LDS, no branches.  Otherwise blocks come from the CSR tables and the normals
 // of a block-step are staged per lane in LDS (uniform runtime index).
 // ------------------------------------------------------------------------------------------------
+// A wave-uniform double held in scalar registers (two v_readfirstlane: the compiler then keeps it in SGPRs for the
+// whole kernel instead of reloading it through the vector memory path every generation).
+__device__ __forceinline__ double uniform_double(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)b);
+    const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 template <int TARGET, int D, bool FULL>
 // (forcing 5/6/8 waves per SIMD through __launch_bounds__ spills and measured 0.72x/0.91x/0.81x: not used)
 __global__ void __launch_bounds__(WINDOW_BS) window_kernel(const WindowParams P)
@@ -224,6 +234,44 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel(const WindowParams P)
 #pragma unroll
     for (int p = 0; p < D; ++p) x[p] = P.Xcur[c + P.N * p];
     double lp = P.lpcur[c];
+    // target constants of the quadratic-form targets: wave-uniform, read once, kept in scalar registers (they used to be
+    // re-read through the vector memory path every generation: the stores to the history may alias them as far as the
+    // compiler knows)
+    constexpr bool LOCAL_TARGET = (TARGET == TARGET_MVNORMAL && D <= 10) || TARGET == TARGET_ISO_QUAD;
+    [[maybe_unused]] double muc[LOCAL_TARGET ? D : 1], Wc[(LOCAL_TARGET && TARGET == TARGET_MVNORMAL) ? D * (D + 1) / 2 : 1], epsc[LOCAL_TARGET ? D : 1];
+    if constexpr (LOCAL_TARGET) {
+#pragma unroll
+        for (int p = 0; p < D; ++p) { muc[p] = uniform_double(P.tp.mu[p]); epsc[p] = uniform_double(P.eps[p]); }
+        if constexpr (TARGET == TARGET_MVNORMAL) {
+#pragma unroll
+            for (int i = 0; i < D * (D + 1) / 2; ++i) Wc[i] = uniform_double(P.tp.Wp[i]);
+        }
+    }
+    [[maybe_unused]] const double c0c = P.tp.c0;
+    // the log-density of a point, from the local constants where they exist (the same operation sequence as target_logp)
+    auto logp_of = [&](const double (&xq)[D]) -> double {
+        if constexpr (LOCAL_TARGET && TARGET == TARGET_MVNORMAL) {
+            double q = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double acc = Wc[(i * (i + 1)) / 2] * (xq[0] - muc[0]);
+#pragma unroll
+                for (int j = 1; j <= i; ++j) acc = fma(Wc[(i * (i + 1)) / 2 + j], xq[j] - muc[j], acc);
+                q = (i == 0) ? acc * acc : fma(acc, acc, q);
+            }
+            return fma(-0.5, q, c0c);
+        } else if constexpr (LOCAL_TARGET) {
+            double q = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const double rr = xq[i] - muc[i];
+                q = (i == 0) ? rr * rr : fma(rr, rr, q);
+            }
+            return -q;
+        } else {
+            return target_logp<TARGET, D>(P.tp, D, [&](int j) { return xq[j]; });
+        }
+    };
 
     rng_state st;
     rng_seek(st, P.seed, (uint64_t)(P.chain_id0 + c), (uint64_t)(P.g_first - 1) * (uint64_t)P.S);
@@ -241,6 +289,12 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel(const WindowParams P)
             draw_rows(r1, r2, (uint64_t)P.M, i1, i2);
             double xp[D];
             if constexpr (FULL) {
+                // the two archive rows are asked for as soon as their indices exist: the gather's latency runs beside
+                // the ~600 instructions of the normals and log u below instead of in front of the proposal
+                double za[D], zb[D];
+                load_row<D>(P.Z + (int64_t)i1 * P.ZS, za);
+                load_row<D>(P.Z + (int64_t)i2 * P.ZS, zb);
+                __builtin_amdgcn_sched_barrier(0);
                 double zn[(D == 1) ? 2 : ((D + 1) / 2) * 2];
                 constexpr int NPAIRS = (D == 1) ? 1 : (D + 1) / 2;
 #pragma unroll
@@ -249,14 +303,11 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel(const WindowParams P)
                     normal_pair(r1, r2, zn[2 * pr], zn[2 * pr + 1]);
                 }
                 const double scale = (D == 1) ? P.gamma : P.gamma / sqrt((double)(2 * D));
-                double za[D], zb[D];
-                load_row<D>(P.Z + (int64_t)i1 * P.ZS, za);
-                load_row<D>(P.Z + (int64_t)i2 * P.ZS, zb);
 #pragma unroll
                 for (int p = 0; p < D; ++p) {
                     double diff = za[p] - zb[p];
                     double t1 = scale * diff;
-                    double t2 = P.eps[p] * zn[(D == 1) ? 0 : p];
+                    double t2 = (LOCAL_TARGET ? epsc[p] : P.eps[p]) * zn[(D == 1) ? 0 : p];
                     double delta = t1 + t2;
                     xp[p] = x[p] + delta;
                 }
@@ -292,7 +343,7 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel(const WindowParams P)
             }
             rng_next(st, r1, r2);
             const double logu = dm_log(u_open(r1));
-            const double lpp = target_logp<TARGET, D>(P.tp, D, [&](int j) { return xp[j]; });
+            const double lpp = logp_of(xp);
             double dlt = lpp - lp;
             if (P.temperature) dlt = dlt / P.temperature[gi];
             const bool acc = logu < dlt;
