@@ -6,6 +6,7 @@
 #include "demcz_kernels.h"
 #include "demcz_kernels_ml.h"
 #include "demcz_kernels_pc.h"
+#include "demcz_kernels_lr.h"
 
 #include <rccl/rccl.h>
 
@@ -321,7 +322,7 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
                          : (!h->full_block && cfg->target_kind == DEMCZ_TARGET_MVNORMAL && L > 1) ? 3 : 0;
         h->split_lanes = (kind == 2) ? 16 : (kind == 3) ? L : 0;
         // chains per consumer workgroup
-        h->split_per_wg = (kind == 1) ? PC_CONSUMER_CHAINS : (kind == 2) ? ((cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? ML_LR_WAVES * 4 : 4)
+        h->split_per_wg = (kind == 1) ? PC_CONSUMER_CHAINS : (kind == 2) ? ((cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? LR16_CHAINS : 4)
                           : (kind == 3) ? 64 / L : 1;
         const bool split_ok = kind != 0;
         h->split_kind = 0;
@@ -406,12 +407,11 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         int64_t waves;
         if (h->lanes == DEMCZ_LAYOUT_SPLIT) {
             const int64_t wgs = (N + h->split_per_wg - 1) / h->split_per_wg;
-            waves = wgs * ((h->split_kind == 2 && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? ML_LR_WAVES : 1);
+            waves = wgs * ((h->split_kind == 2 && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? LR16_WAVES : 1);
         } else if (h->lanes > 1) {
             const int per_wave = 64 / h->lanes;
             const bool lr = h->full_block && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE;
-            waves = lr ? ((N + (int64_t)ML_LR_WAVES * per_wave - 1) / ((int64_t)ML_LR_WAVES * per_wave)) * ML_LR_WAVES
-                       : (N + per_wave - 1) / per_wave;
+            waves = lr ? ((N + LR16_CHAINS - 1) / LR16_CHAINS) * LR16_WAVES : (N + per_wave - 1) / per_wave;
         } else {
             waves = (N + WINDOW_BS - 1) / WINDOW_BS;
         }
@@ -626,7 +626,7 @@ static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t n
         return 0;
     }
     if (target_kind == DEMCZ_TARGET_LINREG_SSE && d == 10 &&
-        ml_dynamic_lds<TARGET_LINREG_SSE, 10, 16>(nobs) <= ML_MAX_DYNAMIC_LDS)
+        lr16_dynamic_lds<10>(nobs) <= ML_MAX_DYNAMIC_LDS)
         return 16;      // design + y resident in LDS
     if (target_kind == DEMCZ_TARGET_MVNORMAL) {
         if (d == 2 || d == 3 || d == 4 || d == 5 || d == 8 || d == 10) return 8;
@@ -653,7 +653,7 @@ static bool split_ml_available(int target_kind, int d, bool full_block, int64_t 
 {
     if (!full_block) return false;
     if (target_kind == DEMCZ_TARGET_MVNORMAL) return d == 20;
-    return target_kind == DEMCZ_TARGET_LINREG_SSE && d == 10 && ml_dynamic_lds<TARGET_LINREG_SSE, 10, 16>(nobs) <= ML_MAX_DYNAMIC_LDS;
+    return target_kind == DEMCZ_TARGET_LINREG_SSE && d == 10 && lr16_dynamic_lds<10>(nobs) <= ML_MAX_DYNAMIC_LDS;
 }
 
 static int pc_roles(int d) { return ((d == 1) ? 1 : (d + 1) / 2) + 2; }
@@ -686,7 +686,7 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
     const bool lr_split = h->split_kind == 2 && h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE;
     const int64_t units = nbc * rec_roles(h) * P.next_ngen;               // 64-lane producer units
     // producer units per workgroup = waves per workgroup of the instantiation that is launched
-    const int upw = lr_split ? ML_LR_WAVES : (h->split_kind == 1 && live) ? PC8_LIVE_WAVES : 1;
+    const int upw = lr_split ? LR16_WAVES : (h->split_kind == 1 && live) ? PC8_LIVE_WAVES : 1;
     const int64_t blocks = P.consumer_blocks + (units + upw - 1) / upw;
     if (blocks <= 0) return DEMCZ_OK;
     if (h->split_kind == 3) {
@@ -705,15 +705,15 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
         }
 #undef DEMCZ_LAUNCH_MLB_REC
     } else if (lr_split) {
-        const dim3 grid((unsigned)blocks), wg(64 * ML_LR_WAVES);
-        const size_t dyn = ml_dynamic_lds<TARGET_LINREG_SSE, 10, 16>(P.tp.nobs);
+        const dim3 grid((unsigned)blocks), wg(64 * LR16_WAVES);
+        const size_t dyn = lr16_dynamic_lds<10>(P.tp.nobs);
         if (!h->lds_raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_ml<TARGET_LINREG_SSE, 10, 16, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_ml<TARGET_LINREG_SSE, 10, 16, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_lr16<10, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_lr16<10, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
             h->lds_raised = true;
         }
-        if (live) hipLaunchKernelGGL((window_kernel_ml<TARGET_LINREG_SSE, 10, 16, true, true>), grid, wg, dyn, h->stream, P);
-        else hipLaunchKernelGGL((window_kernel_ml<TARGET_LINREG_SSE, 10, 16, true, false>), grid, wg, dyn, h->stream, P);
+        if (live) hipLaunchKernelGGL((window_kernel_lr16<10, true, true>), grid, wg, dyn, h->stream, P);
+        else hipLaunchKernelGGL((window_kernel_lr16<10, true, false>), grid, wg, dyn, h->stream, P);
     } else if (h->split_kind == 2) {
         const dim3 grid((unsigned)blocks), wg(64);
         if (live) hipLaunchKernelGGL((window_kernel_ml<TARGET_MVNORMAL, 20, 16, true, true>), grid, wg, 0, h->stream, P);
@@ -827,7 +827,15 @@ static bool try_launch_ml(const demcz_handle* h, const WindowParams& P)
         launch_window_ml<TARGET_ISO_QUAD, 10, 8>(h, P);
         return true;
     } else if (h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE && d == 10) {
-        launch_window_ml<TARGET_LINREG_SSE, 10, 16>(h, P);
+        {   // the regression target: 16 chains per workgroup of four waves on the 16x16x4 FP64 matrix instruction
+            const size_t dyn = lr16_dynamic_lds<10>(P.tp.nobs);
+            if (!h->lds_raised) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_lr16<10, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
+                h->lds_raised = true;
+            }
+            hipLaunchKernelGGL((window_kernel_lr16<10, false, false>), dim3((unsigned)((P.N + LR16_CHAINS - 1) / LR16_CHAINS)), dim3(64 * LR16_WAVES),
+                               dyn, h->stream, P);
+        }
         return true;
     }
     return false;
@@ -1054,9 +1062,9 @@ static int64_t live_wg_capacity(demcz_handle* h)
         }
         if (!f || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 64, 0) != hipSuccess) per_cu = 0;
     } else if (h->split_kind == 2 && h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE) {
-        const size_t dyn = ml_dynamic_lds<TARGET_LINREG_SSE, 10, 16>(h->cfg.nobs);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_ml<TARGET_LINREG_SSE, 10, 16, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&window_kernel_ml<TARGET_LINREG_SSE, 10, 16, true, true>), 64 * ML_LR_WAVES, dyn) != hipSuccess) per_cu = 0;
+        const size_t dyn = lr16_dynamic_lds<10>(h->cfg.nobs);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_lr16<10, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&window_kernel_lr16<10, true, true>), 64 * LR16_WAVES, dyn) != hipSuccess) per_cu = 0;
     } else if (h->split_kind == 2) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&window_kernel_ml<TARGET_MVNORMAL, 20, 16, true, true>), 64, 0) != hipSuccess) per_cu = 0;
     } else if (h->cfg.target_kind == DEMCZ_TARGET_ISO_QUAD) {

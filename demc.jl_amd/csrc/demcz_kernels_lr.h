@@ -1,0 +1,385 @@
+// demcz_kernels_lr.h -- K1b'': the regression target (-0.5 * sum((y - X b)^2), test/example_linreg.jl:32) on the
+// FP64 matrix core at its full rate: v_mfma_f64_16x16x4_f64, sixteen chains per workgroup, four waves per workgroup.
+//
+// The arithmetic spec sums the squared residuals into 16 interleaved partials -- observation o
+// goes to partial o mod 16, in increasing o -- and combines them by a fixed tree.  A 16x16x4 instruction produces
+// 16 observations x 16 chains.  Fed with one tile of 16 consecutive observations it needs 16 chains in ONE wave to
+// be busy, and a 2048-chain population is then 128 waves on 1024 SIMDs (100 us per K-window, round 1).  Here the
+// sixteen chains of a workgroup are shared by FOUR waves instead, split by RESIDUE: wave w owns the partials
+// 4w .. 4w+3, and one of its instructions covers those four residues of FOUR consecutive tiles -- its 16 output
+// rows are (tile 4T+tt, residue 4w+ii), row = 4 tt + ii.  The instruction's result lane l holds rows
+// (l >> 4) + 4 reg, reg = 0..3, of chain l & 15: residue 4w + (l >> 4) of the tiles 4T + reg -- so a lane squares and
+// adds its four results in reg order and that IS the partial's own order (tiles ascending).  Nothing about the spec
+// changes; the results are bit-identical to every other layout and to the oracle (the instruction accumulates like the
+// sequential chain fma(a_k, b_k, .), k ascending, from C: scripts/probes/mfma_f64_order.hip).
+//
+// Per chain-update a wave issues ceil(nobs/64) x ceil(d/4) instructions of 64 cycles -- 48 at nobs = 1000, d = 10 --
+// against 189 of the 4x4x4 form (about 50 cycles each), and a row of the design is fetched from LDS once for sixteen
+// chains instead of four.  The 16 partials of a chain meet in LDS (one workgroup barrier per generation), every lane
+// runs the tree and the accept test redundantly, wave 0 writes the history.
+//
+// Restates the same reference functions as window_kernel (src/demcz.jl:80-93,167-203, demcz_anneal.jl:172-178).
+#pragma once
+
+#include "demcz_kernels_ml.h"
+
+#pragma clang fp contract(off)
+
+namespace demcz {
+
+constexpr int LR16_WAVES = 4;        // waves per workgroup = residue quarters
+constexpr int LR16_CHAINS = 16;      // chains per workgroup = columns of the instruction
+
+// dynamic LDS: the design in A-operand order per (tile group, wave, k-step), y per (tile group, wave, lane quarter, reg),
+// the partials of two generations (ping-pong, rows padded to 18 doubles), the draws of a generation (fused form), two flag words
+template <int D>
+__host__ __device__ constexpr size_t lr16_dynamic_lds(int64_t nobs)
+{
+    constexpr int NMF = (D + 3) / 4, NPAIRS = (D == 1) ? 1 : (D + 1) / 2, S = NPAIRS + 2;
+    const size_t ngrp = (size_t)((nobs + 63) / 64);
+    return ngrp * LR16_WAVES * NMF * 64 * 8 + ngrp * LR16_WAVES * 16 * 8 + 2 * LR16_CHAINS * 18 * 8 + LR16_CHAINS * S * 16 + 16;
+}
+
+typedef double lr_d4 __attribute__((ext_vector_type(4)));
+
+// Workgroup barrier for data that travels through LDS only: wait for this wave's LDS operations, then s_barrier.
+// (__syncthreads() also waits for every outstanding GLOBAL access of the wave -- here that is the next generation's
+//  prefetched records and archive rows, asked for a moment earlier precisely so that they can take a generation to
+//  arrive: 2.5 us of a 4.3 us generation went into that wait.)
+__device__ __forceinline__ void wg_barrier_lds()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int D, bool REC, bool LIVE>
+__global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr16(const WindowParams P)
+{
+    static_assert(!LIVE || REC, "LIVE launches are a property of the split form");
+    constexpr int NMF = (D + 3) / 4;                       // k-steps of 4 per dot product
+    constexpr int NPAIRS = (D == 1) ? 1 : (D + 1) / 2;
+    constexpr int S = NPAIRS + 2;                          // Philox blocks per generation (full block)
+    if constexpr (REC) {
+        if ((int64_t)blockIdx.x >= P.consumer_blocks) {    // every wave of a producer workgroup is one 64-lane producer unit
+            pc_produce<D>(P, ((int64_t)blockIdx.x - P.consumer_blocks) * LR16_WAVES + (int64_t)(threadIdx.x >> 6), (int)(threadIdx.x & 63));
+            return;
+        }
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char lr_dyn_lds[];
+    const int64_t nobs = P.tp.nobs;
+    const int ngrp = (int)((nobs + 63) / 64);              // groups of four tiles of 16 observations
+    double* A_l = reinterpret_cast<double*>(lr_dyn_lds);
+    double* y_l = A_l + (size_t)ngrp * LR16_WAVES * NMF * 64;
+    double* part_l = y_l + (size_t)ngrp * LR16_WAVES * 16;
+    double2* draw_l = reinterpret_cast<double2*>(part_l + 2 * LR16_CHAINS * 18);
+    unsigned int* flag_l = reinterpret_cast<unsigned int*>(draw_l + LR16_CHAINS * S);
+    const int tid = threadIdx.x;
+    // A_l[((T 4 + w) NMF + m) 64 + l] = X[16 (4T + tt) + 4w + ii][4m + kk], row i = l & 15 = 4 tt + ii, kk = l >> 4 (zero outside
+    // the data: a padded observation then adds fma(0, 0, .) to its partial, a padded column fma(0, 0, .) to the dot product)
+    for (int i = tid; i < ngrp * LR16_WAVES * NMF * 64; i += 64 * LR16_WAVES) {
+        const int ll = i & 63;
+        int rest = i >> 6;
+        const int m = rest % NMF;
+        rest /= NMF;
+        const int ww = rest & 3, T = rest >> 2;
+        const int row = ll & 15, kk = ll >> 4;
+        const int64_t o = 16 * (int64_t)(4 * T + (row >> 2)) + 4 * ww + (row & 3);
+        const int col = 4 * m + kk;
+        A_l[i] = (o < nobs && col < D) ? P.tp.design[o * D + col] : 0.0;
+    }
+    // y_l[((T 4 + w) 4 + q) 4 + reg] = y[16 (4T + reg) + 4w + q]
+    for (int i = tid; i < ngrp * LR16_WAVES * 16; i += 64 * LR16_WAVES) {
+        const int reg = i & 3, qq = (i >> 2) & 3, ww = (i >> 4) & 3, T = i >> 6;
+        const int64_t o = 16 * (int64_t)(4 * T + reg) + 4 * ww + qq;
+        y_l[i] = (o < nobs) ? P.tp.yobs[o] : 0.0;
+    }
+    if (tid == 0) {
+        flag_l[0] = 0u;
+        flag_l[1] = 0u;
+        if constexpr (LIVE) flag_l[0] = __hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // an earlier launch failed
+    }
+    __syncthreads();
+    if (flag_l[0] != 0u) return;                           // (workgroup-uniform: nobody is left at a barrier)
+
+    const int w = tid >> 6, l = tid & 63, q = l >> 4, j = l & 15;
+    const int64_t c_raw = (int64_t)blockIdx.x * LR16_CHAINS + j;
+    const bool active = c_raw < P.N;                       // idle columns of the last workgroup shadow chain N-1
+    const int64_t c = active ? c_raw : P.N - 1;
+    const bool writer = (w == 0) && active;                // the four waves hold the same state; wave 0 writes it out
+    const uint64_t chain = (uint64_t)(P.chain_id0 + c);
+
+    // this lane's parameters: k = 4m + q, m = 0..NMF-1 -- the k the B operand of k-step m wants from this lane
+    double x[NMF], epsv[NMF];
+    bool own[NMF];
+#pragma unroll
+    for (int m = 0; m < NMF; ++m) {
+        const int k = 4 * m + q;
+        own[m] = k < D;
+        x[m] = own[m] ? P.Xcur[c + P.N * k] : 0.0;
+        epsv[m] = P.eps[own[m] ? k : 0];
+    }
+    double lp = P.lpcur[c];
+    const double scale = (D == 1) ? P.gamma : P.gamma / sqrt((double)(2 * D));
+    [[maybe_unused]] philox_blocks rng;
+    [[maybe_unused]] const double* rq_z[NMF];
+    [[maybe_unused]] const double* rq_lg = nullptr;
+    [[maybe_unused]] const double* rq_ix = nullptr;
+    [[maybe_unused]] uint64_t ix_next = 0;
+    if constexpr (REC) {
+#pragma unroll
+        for (int m = 0; m < NMF; ++m) rq_z[m] = P.rec_in + ((int64_t)(own[m] ? 4 * m + q : 0) * P.N + c) * P.rec_stride;
+        rq_lg = P.rec_in + ((int64_t)D * P.N + c) * P.rec_stride;
+        rq_ix = P.rec_in + ((int64_t)(D + 1) * P.N + c) * P.rec_stride;
+        ix_next = (uint64_t)__double_as_longlong(rq_ix[0]);
+    }
+
+    // Draws and archive gathers do not depend on the chain state: generation g+1's are asked for while generation g
+    // computes.  Program order inside a generation is CONSUME FIRST, THEN REFILL: the wait in front of the consumption
+    // ("everything outstanding is back", which is all the compiler can ask for across the loop's back edge) then only
+    // covers loads that have had a whole generation to arrive.  (With the refill in front of the consumption that wait
+    // covered the loads just issued -- 0.8 us of every generation; a deeper ring did not help for the same reason.)
+    double za[NMF], zb[NMF], zt[NMF], logu_next = 0.0;
+    int64_t ra = 0, rb = 0;
+    [[maybe_unused]] double ixn = 0.0;                     // REC: packed row indices of the generation after the one in flight
+    auto gather = [&]() {
+#pragma unroll
+        for (int m = 0; m < NMF; ++m) {
+            const int k = own[m] ? 4 * m + q : 0;
+            // (LIVE too: the first read takes the ordinary cached path; a sentinel is asked for again with sc1 loads)
+            za[m] = P.Z[ra * P.ZS + k];
+            zb[m] = P.Z[rb * P.ZS + k];
+        }
+    };
+    // REC: generation g of this launch's records (past the end: a harmless repeat of the last generation's loads, so
+    // that every trip of the loop issues the same memory operations)
+    auto fill_rec = [&](int g) {
+        const uint64_t ii = (uint64_t)__double_as_longlong(ixn);
+        const int gn = (g + 1 < P.ngen) ? g + 1 : P.ngen - 1;
+        ixn = rq_ix[gn];
+        g = (g < P.ngen) ? g : P.ngen - 1;
+        logu_next = rq_lg[g];
+        ra = (int64_t)(uint32_t)ii;
+        rb = (int64_t)(uint32_t)(ii >> 32);
+#pragma unroll
+        for (int m = 0; m < NMF; ++m) zt[m] = rq_z[m][g];
+        gather();
+    };
+    // Fused: the workgroup makes the 16 x S Philox blocks of generation g once, in LDS (thread t < 16 S: chain t / S, role
+    // t % S); a barrier later every lane takes what it needs.
+    auto make_draws = [&](int g) {
+        if (tid < LR16_CHAINS * S) {
+            const int jj = tid / S, role = tid % S;
+            const int64_t cc_raw = (int64_t)blockIdx.x * LR16_CHAINS + jj;
+            const uint64_t cch = (uint64_t)(P.chain_id0 + ((cc_raw < P.N) ? cc_raw : P.N - 1));
+            uint64_t r1, r2;
+            rng.block(P.seed, cch, (uint64_t)(P.g_first + g - 1) * (uint64_t)S + (uint64_t)role, r1, r2);
+            double2 e;
+            if (role == 0) {
+                uint64_t i1, i2;
+                draw_rows(r1, r2, (uint64_t)P.M, i1, i2);
+                e.x = __longlong_as_double((long long)i1);
+                e.y = __longlong_as_double((long long)i2);
+            } else {
+                const double lg = dm_log(u_open(r1));
+                if (role == S - 1) {
+                    e.x = lg;
+                    e.y = 0.0;
+                } else {
+                    const double R = sqrt(-2.0 * lg);
+                    double cs, sn;
+                    dm_sincos2pi(r2 >> 11, cs, sn);
+                    e.x = R * cs;
+                    e.y = R * sn;
+                }
+            }
+            draw_l[jj * S + role] = e;
+        }
+    };
+    auto take_draws = [&]() {
+        const double2 ii = draw_l[j * S];
+        logu_next = draw_l[j * S + S - 1].x;
+        ra = __double_as_longlong(ii.x);
+        rb = __double_as_longlong(ii.y);
+#pragma unroll
+        for (int m = 0; m < NMF; ++m) {
+            const int k = own[m] ? 4 * m + q : 0;
+            const int zi = (D == 1) ? 0 : k;
+            zt[m] = reinterpret_cast<const double*>(draw_l)[(j * S + 1 + zi / 2) * 2 + (zi & 1)];
+        }
+        gather();
+    };
+    if constexpr (REC) {
+        ixn = rq_ix[0];
+        fill_rec(0);
+    } else {
+        make_draws(0);
+        wg_barrier_lds();
+        take_draws();
+        wg_barrier_lds();                                  // draw_l is rewritten in the first generation
+    }
+
+    int to_b = P.to_boundary;            // countdown to the next K boundary
+    int64_t nb = 0;                      // boundaries passed inside this launch
+    unsigned int cnt_total = 0, cnt_first = 0;
+    const unsigned long long speak64 = __builtin_amdgcn_ballot_w64(q == 0 && (w == LR16_WAVES - 1) && active);
+#ifdef DEMCZ_STAMPS
+    unsigned long long sa[6] = {0, 0, 0, 0, 0, 0}, sa_t = __builtin_readcyclecounter();
+#define LR_TICK(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); sa[i] += t_ - sa_t; sa_t = t_; } while (0)
+#else
+#define LR_TICK(i) do { } while (0)
+#endif
+    constexpr int PROW = 18;             // doubles between two chains' partials in LDS: 16 + 2, so that the sixteen chains'
+                                         // rows fall into different banks (a stride of 16 doubles is a 16-way conflict)
+    for (int gi = 0; gi < P.ngen; ++gi) {
+        LR_TICK(5);
+        // ---- consume what was asked for a generation ago ------------------------------------------------------------
+        const double logu = logu_next;
+        [[maybe_unused]] const int64_t ra_c = ra, rb_c = rb;
+        [[maybe_unused]] bool failed = false;
+        if constexpr (LIVE) {
+            // rows appended since the gather was issued read as the sentinel until they are published: ask again (sc1)
+            bool bad = false;
+#pragma unroll
+            for (int m = 0; m < NMF; ++m) bad |= is_sentinel(za[m]) | is_sentinel(zb[m]);
+            int spins = 0;
+            while (__builtin_amdgcn_ballot_w64(bad) != 0ull) {       // wave-uniform
+                if (live_poll_abandon(P, spins, bad, (unsigned)(is_sentinel(za[0]) ? ra_c : rb_c), gi)) { failed = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+                bad = false;
+#pragma unroll
+                for (int m = 0; m < NMF; ++m) {
+                    const int k = own[m] ? 4 * m + q : 0;
+                    if (is_sentinel(za[m])) za[m] = live_load(&P.Z[ra_c * P.ZS + k]);
+                    if (is_sentinel(zb[m])) zb[m] = live_load(&P.Z[rb_c * P.ZS + k]);
+                    bad |= is_sentinel(za[m]) | is_sentinel(zb[m]);
+                }
+            }
+        }
+        // proposal (update_demcz_chain_block, demcz.jl:180-188) for this lane's parameters = the B operands
+        double xp[NMF], bop[NMF];
+#pragma unroll
+        for (int m = 0; m < NMF; ++m) {
+            const double diff = za[m] - zb[m];
+            const double t1 = scale * diff;
+            const double t2 = epsv[m] * zt[m];
+            const double delta = t1 + t2;
+            xp[m] = x[m] + delta;
+            bop[m] = own[m] ? xp[m] : 0.0;
+        }
+        const double temp = P.temperature ? P.temperature[gi] : 1.0;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- ask for the next generation's (unconditionally: the same memory operations on every trip) --------------
+        if constexpr (REC) fill_rec(gi + 1);
+        else make_draws((gi + 1 < P.ngen) ? gi + 1 : gi);        // (taken behind the generation's barrier, below)
+        __builtin_amdgcn_sched_barrier(0);
+        LR_TICK(0);
+        // residuals of this wave's residues, four tiles per instruction chain; TF chains in flight
+        double sacc = 0.0;
+        {
+            constexpr int TF = 4;
+            const double* Aw = A_l + (size_t)w * NMF * 64 + l;
+            const double* yw = y_l + (size_t)(w * 4 + q) * 4;
+            auto finish = [&](const lr_d4& a, int T) {
+                const double2 y01 = reinterpret_cast<const double2*>(yw + (size_t)T * 64)[0];
+                const double2 y23 = reinterpret_cast<const double2*>(yw + (size_t)T * 64)[1];
+                double e;
+                e = y01.x - a[0]; sacc = fma(e, e, sacc);
+                e = y01.y - a[1]; sacc = fma(e, e, sacc);
+                e = y23.x - a[2]; sacc = fma(e, e, sacc);
+                e = y23.y - a[3]; sacc = fma(e, e, sacc);
+            };
+            int T = 0;
+            for (; T + TF <= ngrp; T += TF) {
+                lr_d4 a[TF];
+#pragma unroll
+                for (int i = 0; i < TF; ++i) a[i] = lr_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int m = 0; m < NMF; ++m)
+#pragma unroll
+                    for (int i = 0; i < TF; ++i)
+                        a[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aw[((size_t)(T + i) * LR16_WAVES * NMF + m) * 64], bop[m], a[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TF; ++i) finish(a[i], T + i);
+            }
+            for (; T < ngrp; ++T) {
+                lr_d4 a = lr_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int m = 0; m < NMF; ++m)
+                    a = __builtin_amdgcn_mfma_f64_16x16x4f64(Aw[((size_t)T * LR16_WAVES * NMF + m) * 64], bop[m], a, 0, 0, 0);
+                finish(a, T);
+            }
+        }
+        // the 16 partials of a chain meet in LDS; every lane combines them by the spec's tree
+        double* part = part_l + (size_t)(gi & 1) * LR16_CHAINS * PROW;
+        part[j * PROW + 4 * w + q] = sacc;
+        LR_TICK(1);
+        if constexpr (LIVE) { if (failed) flag_l[1] = 1u; }
+        wg_barrier_lds();
+        LR_TICK(2);
+        if constexpr (LIVE) { if (flag_l[1] != 0u) return; }           // workgroup-uniform: the launch is being abandoned
+        if constexpr (!REC) take_draws();                              // the next generation's draws, made above
+        double pt[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double2 t = reinterpret_cast<const double2*>(part + j * PROW)[i];
+            pt[2 * i] = t.x;
+            pt[2 * i + 1] = t.y;
+        }
+#pragma unroll
+        for (int h = 8; h >= 1; h >>= 1) {
+#pragma unroll
+            for (int i = 0; i < h; ++i) pt[i] = pt[i] + pt[i + h];
+        }
+        const double lpp = -0.5 * pt[0];
+        double dlt = lpp - lp;
+        if (P.temperature) dlt = dlt / temp;
+        const bool acc = logu < dlt;                        // demcz.jl:197-203 / demcz_anneal.jl:172-178
+        {
+            const double lp_new = acc ? lpp : lp;
+            const unsigned int kc = wave_count_changed(lp_new, lp, speak64);
+            cnt_total += kc;
+            cnt_first = (gi == 0) ? kc : cnt_first;
+            lp = lp_new;
+        }
+        // the four waves hold the same state; writing it out is shared: wave m stores parameter group m (k = 4m + q),
+        // the last wave log_obj
+        const int64_t slot = P.slot_first + gi;
+#pragma unroll
+        for (int m = 0; m < NMF; ++m) {
+            x[m] = acc ? xp[m] : x[m];
+            if (P.chain && own[m] && active && w == m) P.chain[c + P.N * ((4 * m + q) + (int64_t)D * slot)] = x[m];    // demcz.jl:84
+        }
+        if (P.chain && q == 0 && active && w == LR16_WAVES - 1) P.logobj[c + P.N * slot] = lp;                     // demcz.jl:85
+        if (--to_b == 0) {                  // generation divisible by K: runchain!'s append, demcz.jl:88-91
+            to_b = P.K;
+#pragma unroll
+            for (int m = 0; m < NMF; ++m) {
+                if (own[m] && active && w == m) {
+                    const int k = 4 * m + q;
+                    if (P.do_append) {
+                        if constexpr (LIVE) live_store(&P.Zw[(P.M_append + nb * P.N + c) * P.ZS + k], x[m]);
+                        else P.Zw[(P.M_append + nb * P.N + c) * P.ZS + k] = x[m];
+                    }
+                    if (P.snap) P.snap[nb * P.N * D + c + P.N * k] = x[m];
+                }
+            }
+            ++nb;
+        }
+        if constexpr (!REC) wg_barrier_lds();               // draw_l is rewritten in the next generation
+        LR_TICK(3);
+    }
+#pragma unroll
+    for (int m = 0; m < NMF; ++m)
+        if (own[m] && writer) P.Xcur[c + P.N * (4 * m + q)] = x[m];
+    if (q == 0 && writer) P.lpcur[c] = lp;
+    static_assert(NMF < LR16_WAVES, "parameter groups and log_obj each have a wave to write them");
+    wave_store_counts(P, (int64_t)blockIdx.x * LR16_WAVES + w, cnt_total, cnt_first);
+#ifdef DEMCZ_STAMPS
+    if (P.stamps && (tid & 63) == 0 && blockIdx.x < 16384u) {      // per wave: [refill+wait+poll, proposal+matrix, barrier, tail, -, between steps]
+        unsigned long long* o = P.stamps + ((size_t)blockIdx.x * LR16_WAVES + w) * 16;
+        for (int i = 0; i < 6; ++i) o[8 + i] = sa[i];
+        o[14] = (unsigned long long)P.ngen;
+    }
+#endif
+}
+
+}  // namespace demcz

@@ -1,0 +1,40 @@
+"""Where a generation of the regression kernel (window_kernel_lr16) goes: shader-clock sums per wave from a -DDEMCZ_STAMPS build.
+usage: python scripts/lr_stamps.py [nobs] [N]"""
+import ctypes as C, os, subprocess, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+so = ROOT / "build_ab" / "stamps.so"
+if not so.exists():
+    so.parent.mkdir(exist_ok=True)
+    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-pass-failed",
+                    "-DDEMCZ_STAMPS", "-o", str(so), str(ROOT / "demc.jl_amd" / "csrc" / "demcz_capi.hip"), "-lrccl"], check=True)
+os.environ["DEMCZ_LIB"] = str(so)
+sys.path.insert(0, str(ROOT))
+import numpy as np
+import demc_jl_amd as demc
+from demc_jl_amd import _lib
+nobs = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+d, G = 10, 682
+w = demc.workloads.linreg_problem(d, N, nobs=nobs)
+M0 = w["Zinit"].shape[0]
+e = demc.HipEngine(N=N, d=d, K=10, Mcap=M0 + N * (G // 10 + 1), Gcap=G, blockindex=[range(d)], eps_scale=w["eps_scale"], seed=1, target=w["target"])
+e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+T = np.array([demc.tempbaseline(g, G, 3, 1e-3) for g in range(1, G + 1)])
+e.run(1, G, w["gamma"], T); e.synchronize()
+lib = _lib.load()
+nw = (N // 16) * 4
+buf = np.zeros((nw, 16), dtype=np.uint64)
+lib.demcz_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+assert lib.demcz_debug_read_stamps(e._h, buf.ctypes.data_as(C.c_void_p), nw) == 0
+s = buf.astype(np.float64)
+ng = s[:, 14]
+names = ["refill issue + wait for the slot + sentinel poll", "proposal + matrix instructions + partial to LDS", "workgroup barrier",
+         "partials read, tree, accept, history stores, append", "-", "between steps"]
+print(f"nobs={nobs} N={N}: last launch {int(ng[0])} generations; ticks per generation, mean over waves / wave 0 of the workgroups / max")
+for i in (0, 1, 2, 3, 5):
+    v = s[:, 8 + i] / ng
+    print(f"  {v.mean():8.0f} {v[0::4].mean():8.0f} {v.max():8.0f}   {names[i]}")
+tot = s[:, 8:14].sum(axis=1) / ng
+print(f"  {tot.mean():8.0f} ticks per generation in all")
+e.close()
