@@ -1182,6 +1182,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     P.acc_out = nullptr; P.live_err = h->d_live_err; P.live_spin_limit = LIVE_SPIN_LIMIT;
     P.rec_in = nullptr; P.rec_out = nullptr; P.next_g_first = 0; P.next_M = 0; P.next_ngen = 0; P.consumer_blocks = 0;
     P.next_rows = 0; P.next_boff = 0; P.rec_stride = 0;
+    P.rec_fields = (h->lanes == DEMCZ_LAYOUT_SPLIT && h->split_kind == 2) ? h->cfg.d + 2 : 0;    // lane-per-parameter consumers: record-major
 #ifdef DEMCZ_STAMPS
     if (!h->d_stamps) {
         HIPCHK(h, hipMalloc((void**)&h->d_stamps, (size_t)DEMCZ_STAMP_WGS * 16 * sizeof(unsigned long long)));

@@ -80,6 +80,10 @@ struct WindowParams {
     const double* rec_in;
     double* rec_out;
     int64_t rec_stride;      // generations each (field, chain) row of a record buffer holds
+    int32_t rec_fields;      // 0: records are generation-major per (field, chain) -- what the replicated consumer reads, a lane
+                             // per generation.  F > 0: one record of F doubles per (generation, chain), fields contiguous --
+                             // what the lane-per-parameter consumers read (all lanes at the same generation): their loads
+                             // then touch a few cache lines instead of one per lane
     const int32_t* slot_role; // block-structured split runs: what Philox block s of a generation is (0 rows, 1 normal pair, 2 log u)
     int64_t next_g_first;    // stream generation index of the next launch's first generation
     int64_t next_M;          // rows its first generation draws from

@@ -120,17 +120,11 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr16(const Wind
     double lp = P.lpcur[c];
     const double scale = (D == 1) ? P.gamma : P.gamma / sqrt((double)(2 * D));
     [[maybe_unused]] philox_blocks rng;
-    [[maybe_unused]] const double* rq_z[NMF];
-    [[maybe_unused]] const double* rq_lg = nullptr;
-    [[maybe_unused]] const double* rq_ix = nullptr;
-    [[maybe_unused]] uint64_t ix_next = 0;
-    if constexpr (REC) {
-#pragma unroll
-        for (int m = 0; m < NMF; ++m) rq_z[m] = P.rec_in + ((int64_t)(own[m] ? 4 * m + q : 0) * P.N + c) * P.rec_stride;
-        rq_lg = P.rec_in + ((int64_t)D * P.N + c) * P.rec_stride;
-        rq_ix = P.rec_in + ((int64_t)(D + 1) * P.N + c) * P.rec_stride;
-        ix_next = (uint64_t)__double_as_longlong(rq_ix[0]);
-    }
+    // REC: the record of (generation g, this chain): D normals, log u, the packed row indices -- D + 2 contiguous doubles
+    constexpr int F = D + 2;
+    [[maybe_unused]] const double* rq0 = nullptr;
+    [[maybe_unused]] const int64_t rq_gen = (int64_t)P.N * F;             // doubles from one generation's records to the next
+    if constexpr (REC) rq0 = P.rec_in + c * F;
 
     // Draws and archive gathers do not depend on the chain state: generation g+1's are asked for while generation g
     // computes.  Program order inside a generation is CONSUME FIRST, THEN REFILL: the wait in front of the consumption
@@ -154,13 +148,14 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr16(const Wind
     auto fill_rec = [&](int g) {
         const uint64_t ii = (uint64_t)__double_as_longlong(ixn);
         const int gn = (g + 1 < P.ngen) ? g + 1 : P.ngen - 1;
-        ixn = rq_ix[gn];
+        ixn = rq0[rq_gen * gn + (D + 1)];
         g = (g < P.ngen) ? g : P.ngen - 1;
-        logu_next = rq_lg[g];
+        const double* rg = rq0 + rq_gen * g;
+        logu_next = rg[D];
         ra = (int64_t)(uint32_t)ii;
         rb = (int64_t)(uint32_t)(ii >> 32);
 #pragma unroll
-        for (int m = 0; m < NMF; ++m) zt[m] = rq_z[m][g];
+        for (int m = 0; m < NMF; ++m) zt[m] = rg[own[m] ? 4 * m + q : 0];
         gather();
     };
     // Fused: the workgroup makes the 16 x S Philox blocks of generation g once, in LDS (thread t < 16 S: chain t / S, role
@@ -208,7 +203,7 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr16(const Wind
         gather();
     };
     if constexpr (REC) {
-        ixn = rq_ix[0];
+        ixn = rq0[D + 1];
         fill_rec(0);
     } else {
         make_draws(0);
@@ -227,6 +222,16 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr16(const Wind
 #else
 #define LR_TICK(i) do { } while (0)
 #endif
+    // history row and log_obj of generation `g` of the launch (runchain!, demcz.jl:84-85), from the current state.  The
+    // four waves hold the same state; writing it out is shared: wave m stores parameter group m (k = 4m + q), the last
+    // wave log_obj.
+    auto write_hist = [&](int g) {
+        const int64_t slot = P.slot_first + g;
+#pragma unroll
+        for (int m = 0; m < NMF; ++m)
+            if (P.chain && own[m] && active && w == m) P.chain[c + P.N * ((4 * m + q) + (int64_t)D * slot)] = x[m];    // demcz.jl:84
+        if (P.chain && q == 0 && active && w == LR16_WAVES - 1) P.logobj[c + P.N * slot] = lp;                         // demcz.jl:85
+    };
     constexpr int PROW = 18;             // doubles between two chains' partials in LDS: 16 + 2, so that the sixteen chains'
                                          // rows fall into different banks (a stride of 16 doubles is a 16-way conflict)
     for (int gi = 0; gi < P.ngen; ++gi) {
@@ -254,6 +259,7 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr16(const Wind
                 }
             }
         }
+        LR_TICK(4);
         // proposal (update_demcz_chain_block, demcz.jl:180-188) for this lane's parameters = the B operands
         double xp[NMF], bop[NMF];
 #pragma unroll
@@ -271,11 +277,18 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr16(const Wind
         if constexpr (REC) fill_rec(gi + 1);
         else make_draws((gi + 1 < P.ngen) ? gi + 1 : gi);        // (taken behind the generation's barrier, below)
         __builtin_amdgcn_sched_barrier(0);
+        // ---- the history row of the generation BEFORE this one (x, lp still hold it) ------------------------------------
+        // Here rather than at that generation's end: the wait in front of the next consumption covers every outstanding
+        // access of the wave, stores included, and a store issued a moment before it costs its whole round trip.  (The
+        // APPEND of a boundary generation stays at its generation's end: a wave must publish its rows before it waits for
+        // other waves' rows of the same boundary.)
+        if (gi > 0) write_hist(gi - 1);
+        __builtin_amdgcn_sched_barrier(0);
         LR_TICK(0);
         // residuals of this wave's residues, four tiles per instruction chain; TF chains in flight
         double sacc = 0.0;
         {
-            constexpr int TF = 4;
+            constexpr int TF = 4;       // (8: 3.48 vs 3.42 us per generation)
             const double* Aw = A_l + (size_t)w * NMF * 64 + l;
             const double* yw = y_l + (size_t)(w * 4 + q) * 4;
             auto finish = [&](const lr_d4& a, int T) {
@@ -288,6 +301,9 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr16(const Wind
                 e = y23.y - a[3]; sacc = fma(e, e, sacc);
             };
             int T = 0;
+            // (tried: software-pipelining the batches so that the vector pipe squares batch b-1 while the matrix pipe runs
+            //  batch b, order forced with sched_group_barrier -- 5300 -> 6200 cycles: on this chip the FP64 matrix
+            //  instruction and the FP64 vector instructions share their multipliers, there is nothing to overlap)
             for (; T + TF <= ngrp; T += TF) {
                 lr_d4 a[TF];
 #pragma unroll
@@ -340,15 +356,8 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr16(const Wind
             cnt_first = (gi == 0) ? kc : cnt_first;
             lp = lp_new;
         }
-        // the four waves hold the same state; writing it out is shared: wave m stores parameter group m (k = 4m + q),
-        // the last wave log_obj
-        const int64_t slot = P.slot_first + gi;
 #pragma unroll
-        for (int m = 0; m < NMF; ++m) {
-            x[m] = acc ? xp[m] : x[m];
-            if (P.chain && own[m] && active && w == m) P.chain[c + P.N * ((4 * m + q) + (int64_t)D * slot)] = x[m];    // demcz.jl:84
-        }
-        if (P.chain && q == 0 && active && w == LR16_WAVES - 1) P.logobj[c + P.N * slot] = lp;                     // demcz.jl:85
+        for (int m = 0; m < NMF; ++m) x[m] = acc ? xp[m] : x[m];
         if (--to_b == 0) {                  // generation divisible by K: runchain!'s append, demcz.jl:88-91
             to_b = P.K;
 #pragma unroll
@@ -367,6 +376,7 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr16(const Wind
         if constexpr (!REC) wg_barrier_lds();               // draw_l is rewritten in the next generation
         LR_TICK(3);
     }
+    write_hist(P.ngen - 1);
 #pragma unroll
     for (int m = 0; m < NMF; ++m)
         if (own[m] && writer) P.Xcur[c + P.N * (4 * m + q)] = x[m];

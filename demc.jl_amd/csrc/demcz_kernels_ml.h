@@ -150,12 +150,13 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
     [[maybe_unused]] uint32_t ra = 0, rb = 0, ra_c = 0, rb_c = 0;     // rows of the gather in flight / being consumed
     if constexpr (REC) {
 #pragma unroll
+        // (record-major: the record of (generation, chain) is D + 2 contiguous doubles, WindowParams::rec_fields)
         for (int k = 0; k < NP; ++k) {
             const int p = r + L * k;
-            rq_z[k] = P.rec_in + ((int64_t)((D == 1) ? 0 : ((p < D) ? p : 0)) * P.N + c) * P.rec_stride;
+            rq_z[k] = P.rec_in + c * (D + 2) + ((D == 1) ? 0 : ((p < D) ? p : 0));
         }
-        rq_lg = P.rec_in + ((int64_t)D * P.N + c) * P.rec_stride;
-        rq_ix = P.rec_in + ((int64_t)(D + 1) * P.N + c) * P.rec_stride;
+        rq_lg = P.rec_in + c * (D + 2) + D;
+        rq_ix = P.rec_in + c * (D + 2) + (D + 1);
         ix_next = (uint64_t)__double_as_longlong(rq_ix[0]);
         if constexpr (LIVE) {       // an earlier launch of the run already failed: do not wait again
             if (__hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
@@ -175,15 +176,16 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
         if constexpr (REC) {
             const uint64_t ii = ix_next;
             const int gn = (gi + 1 < P.ngen) ? gi + 1 : gi;
-            ix_next = (uint64_t)__double_as_longlong(rq_ix[gn]);
-            logu_next = rq_lg[gi];
+            const int64_t rgen = (int64_t)P.N * (D + 2);               // doubles from one generation's records to the next
+            ix_next = (uint64_t)__double_as_longlong(rq_ix[rgen * gn]);
+            logu_next = rq_lg[rgen * gi];
             ra = (uint32_t)ii;
             rb = (uint32_t)(ii >> 32);
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const int p = r + L * k;
                 const int pc = (p < D) ? p : 0;
-                zt[k] = rq_z[k][gi];
+                zt[k] = rq_z[k][rgen * gi];
                 // (also in a LIVE launch the first read takes the ordinary cached path: a stale copy can only show the
                 //  sentinel where the row's final doubles are not yet seen, and a sentinel is asked for again with sc1
                 //  loads below -- sc1 loads are slow to issue, demcz_kernels_pc.h)

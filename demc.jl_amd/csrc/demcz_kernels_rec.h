@@ -39,6 +39,8 @@ __device__ __forceinline__ void wave_lds_handoff()
 // WindowParams::rec_stride generations.  The generations of one (field, chain) are contiguous: a
 // consumer lane fetches a chunk of ten with five 16-byte loads off one address.
 __device__ __forceinline__ size_t rec_index(int64_t N, int64_t GS, int g, int f, int64_t c) { return ((size_t)f * (size_t)N + (size_t)c) * (size_t)GS + (size_t)g; }
+// record-major layout (WindowParams::rec_fields = F > 0): rec[(g * N + c) * F + f]
+__device__ __forceinline__ size_t rec_index_rm(int64_t N, int F, int g, int f, int64_t c) { return ((size_t)g * (size_t)N + (size_t)c) * (size_t)F + (size_t)f; }
 
 // (`lane`: position in the 64-wide producer unit -- a workgroup of one wave, or one wave of a larger workgroup)
 template <int D>
@@ -56,24 +58,27 @@ __device__ __forceinline__ void pc_produce(const WindowParams& P, int64_t pb, in
     uint64_t r1, r2;
     rng.block(P.seed, (uint64_t)(P.chain_id0 + c), (uint64_t)(P.next_g_first + gi - 1) * (uint64_t)S + (uint64_t)role, r1, r2);
     double* rec = P.rec_out;
+    auto at = [&](int g, int f) -> size_t {
+        return P.rec_fields ? rec_index_rm(P.N, P.rec_fields, g, f, c) : rec_index(P.N, P.rec_stride, g, f, c);
+    };
     if (role == 0) {
         // rows generation gi of the next launch draws from: those it starts with plus, where appended rows
         // are visible at once, N per K boundary it has passed by then (update_demcz_chain_block, demcz.jl:176-179)
         const int64_t Mg = P.next_M + (int64_t)((gi + P.next_boff) / P.K) * P.next_rows;
         uint64_t i1, i2;
         draw_rows(r1, r2, (uint64_t)Mg, i1, i2);
-        rec[rec_index(P.N, P.rec_stride, gi, D + 1, c)] = __longlong_as_double((long long)(i1 | (i2 << 32)));
+        rec[at(gi, D + 1)] = __longlong_as_double((long long)(i1 | (i2 << 32)));
     } else {
         const double lg = dm_log(u_open(r1));
         if (role == S - 1) {
-            rec[rec_index(P.N, P.rec_stride, gi, D, c)] = lg;
+            rec[at(gi, D)] = lg;
         } else {
             const double R = sqrt(-2.0 * lg);
             double cs, sn;
             dm_sincos2pi(r2 >> 11, cs, sn);
             const int p0 = (D == 1) ? 0 : 2 * (role - 1);
-            rec[rec_index(P.N, P.rec_stride, gi, p0, c)] = R * cs;
-            if (p0 + 1 < D) rec[rec_index(P.N, P.rec_stride, gi, p0 + 1, c)] = R * sn;
+            rec[at(gi, p0)] = R * cs;
+            if (p0 + 1 < D) rec[at(gi, p0 + 1)] = R * sn;
         }
     }
 }

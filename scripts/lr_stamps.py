@@ -29,10 +29,10 @@ lib.demcz_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 assert lib.demcz_debug_read_stamps(e._h, buf.ctypes.data_as(C.c_void_p), nw) == 0
 s = buf.astype(np.float64)
 ng = s[:, 14]
-names = ["refill issue + wait for the slot + sentinel poll", "proposal + matrix instructions + partial to LDS", "workgroup barrier",
-         "partials read, tree, accept, history stores, append", "-", "between steps"]
+names = ["proposal, next generation's loads issued, previous generation's history stored", "matrix instructions + partial to LDS", "workgroup barrier",
+         "partials read, tree, accept, append", "wait for this generation's rows and records, sentinel poll", "between steps"]
 print(f"nobs={nobs} N={N}: last launch {int(ng[0])} generations; ticks per generation, mean over waves / wave 0 of the workgroups / max")
-for i in (0, 1, 2, 3, 5):
+for i in (4, 0, 1, 2, 3, 5):
     v = s[:, 8 + i] / ng
     print(f"  {v.mean():8.0f} {v[0::4].mean():8.0f} {v.max():8.0f}   {names[i]}")
 tot = s[:, 8:14].sum(axis=1) / ng
