@@ -602,15 +602,8 @@ static void launch_window_generic(const demcz_handle* h, const WindowParams& P, 
 template <int TARGET, int D, int L>
 static void launch_window_ml(const demcz_handle* h, const WindowParams& P)
 {
-    constexpr int NG = ml_waves<TARGET>() * (64 / L);      // chains per workgroup
-    const size_t dyn = ml_dynamic_lds<TARGET, D, L>(P.tp.nobs);
-    if (dyn > 48 * 1024 && !h->lds_raised) {               // once per handle: the attribute belongs to the device
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_ml<TARGET, D, L>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
-        h->lds_raised = true;
-    }
-    hipLaunchKernelGGL((window_kernel_ml<TARGET, D, L>), dim3((unsigned)((P.N + NG - 1) / NG)), dim3(64 * ml_waves<TARGET>()),
-                       dyn, h->stream, P);
+    constexpr int NG = 64 / L;      // chains per workgroup (one wave)
+    hipLaunchKernelGGL((window_kernel_ml<TARGET, D, L>), dim3((unsigned)((P.N + NG - 1) / NG)), dim3(64), 0, h->stream, P);
 }
 
 // which multi-lane layout is compiled for (target, d, full single block): 0 = none

@@ -26,100 +26,43 @@
 
 namespace demcz {
 
-// Workgroup geometry: MvNormal / isotropic targets run one wave per workgroup (small N spreads
-// over as many CUs as there are waves).  The regression target keeps the whole design matrix and
-// y in LDS, shared by ML_LR_WAVES waves (= 4 * 64/L chains) of one workgroup.
-// (measured on C5: 4 waves/workgroup 64.7 us per K-window, 8 waves 78.0, 16 waves 133.1, 2 waves 68.9)
-constexpr int ML_LR_WAVES = 4;
-
-template <int TARGET>
-constexpr int ml_waves() { return TARGET == TARGET_LINREG_SSE ? ML_LR_WAVES : 1; }
-
-// bytes of dynamic LDS the regression layout needs (0 for the other targets): the per-chain staging rows, y
-// padded to whole 16-observation tiles, and the design in the A-operand order of v_mfma_f64_4x4x4_f64
-template <int TARGET, int D, int L>
-__host__ __device__ constexpr size_t ml_dynamic_lds(int64_t nobs)
-{
-    if (TARGET != TARGET_LINREG_SSE) return 0;
-    constexpr int G = 64 / L, NPAIRS = (D == 1) ? 1 : (D + 1) / 2, S = NPAIRS + 2, DP = ((D + 1) / 2) * 2;
-    constexpr int NG = ML_LR_WAVES * G;
-    const size_t ntile = (size_t)((nobs + 15) / 16), nm = (size_t)((D + 3) / 4);
-    return (size_t)NG * S * 16 + (size_t)NG * DP * 8 + (size_t)NG * L * 8 + ntile * 16 * 8 + ntile * nm * 64 * 8;
-}
-
+// Workgroup geometry: one wave per workgroup (small N spreads over as many CUs as there are waves).  (The regression
+// target has its own kernel on the FP64 matrix instruction, demcz_kernels_lr.h.)
 // REC: the split form of this layout (demcz_kernels_rec.h) -- workgroups beyond consumer_blocks are the
 // producer half (draw records for the next launch), the others read this launch's records instead of
 // drawing: what is left per generation is the state-dependent part.  LIVE: the launch runs through K
 // boundaries and takes appended rows from other waves through the archive itself (sentinel + sc1).
-// Used where the eight-replicated-lanes consumer does not fit (d = 20: 210 whitening coefficients) and for the
-// regression target.
+// Used where the eight-replicated-lanes consumer does not fit (d = 20: 210 whitening coefficients).
 template <int TARGET, int D, int L, bool REC = false, bool LIVE = false>
-__global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(const WindowParams P)
+__global__ void __launch_bounds__(64) window_kernel_ml(const WindowParams P)
 {
-    constexpr bool LR = (TARGET == TARGET_LINREG_SSE);
+    static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "lane-cooperative layout: MvNormal / isotropic targets");
     static_assert(!LIVE || REC, "LIVE launches are a property of the split form");
     if constexpr (REC) {
-        if ((int64_t)blockIdx.x >= P.consumer_blocks) {       // every wave of a producer workgroup is one 64-lane producer unit
-            pc_produce<D>(P, ((int64_t)blockIdx.x - P.consumer_blocks) * ml_waves<TARGET>() + (int64_t)(threadIdx.x >> 6),
-                          (int)(threadIdx.x & 63));
+        if ((int64_t)blockIdx.x >= P.consumer_blocks) {
+            pc_produce<D>(P, (int64_t)blockIdx.x - P.consumer_blocks);
             return;
         }
     }
-    constexpr int WAVES = ml_waves<TARGET>();
-    constexpr int G = 64 / L;                              // chains per wave
-    constexpr int NG = WAVES * G;                          // chains per workgroup
+    constexpr int G = 64 / L;                              // chains per wave = per workgroup
+    constexpr int NG = G;
     constexpr int NPAIRS = (D == 1) ? 1 : (D + 1) / 2;
     constexpr int S = NPAIRS + 2;                          // Philox blocks per generation (full block)
     static_assert(S <= L, "one Philox block per lane");
-    static_assert(!LR || L == LINREG_PARTIALS, "regression: one partial sum per lane of the group");
     constexpr int NP = (D + L - 1) / L;                    // parameters owned per lane
     constexpr int DP = ((D + 1) / 2) * 2;                  // staging row, 16-byte multiple
-    constexpr int YP = LR ? L : DP;                        // second staging row: y components / SSE partials
+    constexpr int YP = DP;                                 // second staging row: y components
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char ml_dyn_lds[];
-    __shared__ double2 rec_s[LR ? 1 : NG * S];
-    __shared__ __attribute__((aligned(16))) double rvec_s[LR ? 2 : NG * DP];
-    __shared__ __attribute__((aligned(16))) double yvec_s[LR ? 2 : NG * YP];
-    double2* rec = rec_s;
-    double* rvec = rvec_s;
-    double* yvec = yvec_s;
-    const double* y_l = nullptr;
-    const double* design_l = nullptr;
-    if constexpr (LR) {
-        // everything is carved from the dynamic region (no static LDS in front of it: 16-byte base)
-        unsigned char* q = ml_dyn_lds;
-        rec = reinterpret_cast<double2*>(q);   q += (size_t)NG * S * 16;
-        rvec = reinterpret_cast<double*>(q);   q += (size_t)NG * DP * 8;
-        yvec = reinterpret_cast<double*>(q);   q += (size_t)NG * YP * 8;
-        // y padded with zeros to whole tiles, the design in the A-operand order of v_mfma_f64_4x4x4_f64:
-        // Am[(t NM + m) 64 + l] = X[16 t + l % 16][4 m + l / 16], zero outside the data (a padded observation
-        // then adds fma(0, 0, .) to its partial: nothing)
-        const int64_t ntile_f = (P.tp.nobs + 15) / 16;
-        constexpr int NMF = (D + 3) / 4;
-        double* yl = reinterpret_cast<double*>(q);   q += (size_t)ntile_f * 16 * 8;
-        double* dl = reinterpret_cast<double*>(q);
-        for (int64_t i = threadIdx.x; i < ntile_f * NMF * 64; i += 64 * WAVES) {
-            const int ll = (int)(i % 64);
-            const int64_t tm = i / 64;
-            const int64_t o = 16 * (tm / NMF) + ll % 16;
-            const int col = 4 * (int)(tm % NMF) + ll / 16;
-            dl[i] = (o < P.tp.nobs && col < D) ? P.tp.design[o * D + col] : 0.0;
-        }
-        for (int64_t i = threadIdx.x; i < ntile_f * 16; i += 64 * WAVES) yl[i] = (i < P.tp.nobs) ? P.tp.yobs[i] : 0.0;
-        __syncthreads();
-        y_l = yl;
-        design_l = dl;
-    }
+    __shared__ double2 rec[NG * S];
+    __shared__ __attribute__((aligned(16))) double rvec[NG * DP];
+    __shared__ __attribute__((aligned(16))) double yvec[NG * YP];
 
     const int lane = threadIdx.x & 63;
-    // regression: the lane's (partial r, chain of the wave) are those of the matrix instruction's result lane
-    // 16 i + 4 blk + j = D_blk[i][j] (observation 4 blk + i of the tile, chain j): r = 4 blk + i
-    const int r = LR ? 4 * ((lane % 16) / 4) + lane / 16 : lane % L;
-    const int gq = (threadIdx.x >> 6) * G + (LR ? lane % 4 : lane / L);
-    const int64_t c_raw = (int64_t)blockIdx.x * NG + gq;
-    if (!LR && c_raw >= P.N) return;
-    const bool active = c_raw < P.N;                       // regression: idle groups of the last workgroup keep pace
-    const int64_t c = active ? c_raw : P.N - 1;
+    const int r = lane % L;
+    const int gq = lane / L;
+    const int64_t c = (int64_t)blockIdx.x * NG + gq;
+    if (c >= P.N) return;
+    constexpr bool active = true;
     const uint64_t chain = (uint64_t)(P.chain_id0 + c);
     const int role = (r < S) ? r : S - 1;
 
@@ -132,7 +75,7 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
         const int pc = own ? p : 0;
         x[k] = own ? P.Xcur[c + P.N * pc] : 0.0;
         epsv[k] = P.eps[pc];
-        muv[k] = LR ? 0.0 : P.tp.mu[pc];
+        muv[k] = P.tp.mu[pc];
         if constexpr (TARGET == TARGET_MVNORMAL) {
 #pragma unroll
             for (int j = 0; j < D; ++j) Wrow[k][j] = (own && j <= pc) ? P.tp.Wp[(pc * (pc + 1)) / 2 + j] : 0.0;
@@ -271,7 +214,7 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
         for (int k = 0; k < NP; ++k) {
             const int p = r + L * k;
             xp[k] = x[k] + delta[k];
-            if (p < D) rvec[gq * DP + p] = LR ? xp[k] : xp[k] - muv[k];
+            if (p < D) rvec[gq * DP + p] = xp[k] - muv[k];
         }
         wave_lds_handoff();
         double rj[DP];
@@ -303,77 +246,11 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
                 if (2 * j + 1 < D) q = fma(t.y, t.y, q);
             }
             lpp = fma(-0.5, q, P.tp.c0);
-        } else if constexpr (TARGET == TARGET_ISO_QUAD) {
+        } else {
             double q = 0.0;
 #pragma unroll
             for (int j = 0; j < D; ++j) q = (j == 0) ? rj[0] * rj[0] : fma(rj[j], rj[j], q);
             lpp = -q;
-        } else {
-            // SSE partial r of the chain (observations r, r + 16, ...): the residuals of a tile of 16 observations
-            // for the wave's 4 chains are three v_mfma_f64_4x4x4_f64 (k = 0..3, 4..7, 8..11; four 4x4 blocks =
-            // four observation quads x the same four chains).  The instruction accumulates like the sequential
-            // chain fma(a_k, b_k, .), k ascending, from C (probed: scripts/probes/mfma_f64_4x4x4.hip, bit-identical
-            // on 65536 random results) = the spec's dot product.  A row of the design is fetched once for the four
-            // chains -- the vector form of this loop was bound by the LDS read throughput of its SIMD.
-            constexpr int NMF = (D + 3) / 4;
-            double bop[NMF];                    // B operand: this lane provides b[4 m + lane / 16] of chain lane % 4 (its own)
-#pragma unroll
-            for (int m = 0; m < NMF; ++m) {
-                double v = 0.0;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    if (4 * m + kk < D) v = ((r & 3) == kk) ? rj[4 * m + kk] : v;
-                bop[m] = (4 * m + (r & 3) < D) ? v : 0.0;
-            }
-            const int ntile = (int)((P.tp.nobs + 15) / 16);
-            double sacc = 0.0;
-            auto tile = [&](int t) {
-                double acc = 0.0;
-#pragma unroll
-                for (int m = 0; m < NMF; ++m)
-                    acc = __builtin_amdgcn_mfma_f64_4x4x4f64(design_l[((size_t)t * NMF + m) * 64 + lane], bop[m], acc, 0, 0, 0);
-                return acc;
-            };
-            {
-                // TF tiles in flight: a tile's three instructions chain through C, and the matrix pipe wants
-                // several independent chains to stay busy
-                constexpr int TF = 6;
-                int t = 0;
-                for (; t + TF <= ntile; t += TF) {
-                    double a[TF];
-#pragma unroll
-                    for (int i = 0; i < TF; ++i) a[i] = 0.0;
-#pragma unroll
-                    for (int m = 0; m < NMF; ++m)
-#pragma unroll
-                        for (int i = 0; i < TF; ++i)
-                            a[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(design_l[((size_t)(t + i) * NMF + m) * 64 + lane], bop[m], a[i], 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < TF; ++i) {
-                        const double e = y_l[16 * (t + i) + r] - a[i];
-                        sacc = fma(e, e, sacc);
-                    }
-                }
-                for (; t < ntile; ++t) {
-                    const double e0 = y_l[16 * t + r] - tile(t);
-                    sacc = fma(e0, e0, sacc);
-                }
-            }
-            yvec[gq * YP + r] = sacc;
-            wave_lds_handoff();
-            double part[L];
-#pragma unroll
-            for (int j = 0; j < L / 2; ++j) {
-                const double2 t = reinterpret_cast<const double2*>(yvec + gq * YP)[j];
-                part[2 * j] = t.x;
-                part[2 * j + 1] = t.y;
-            }
-#pragma unroll
-            for (int h = L / 2; h >= 1; h >>= 1) {
-#pragma unroll
-                for (int l = 0; l < h; ++l) part[l] = part[l] + part[l + h];
-            }
-            lpp = -0.5 * part[0];
         }
         double dlt = lpp - lp;
         if (P.temperature) dlt = dlt / P.temperature[gi];
@@ -421,7 +298,7 @@ __global__ void __launch_bounds__(64 * ml_waves<TARGET>()) window_kernel_ml(cons
         if (p < D && active) P.Xcur[c + P.N * p] = x[k];
     }
     if (r == 0 && active) P.lpcur[c] = lp;
-    wave_store_counts(P, (int64_t)blockIdx.x * WAVES + (int64_t)(threadIdx.x >> 6), cnt_total, cnt_first);
+    wave_store_counts(P, blockIdx.x, cnt_total, cnt_first);
 }
 
 // ------------------------------------------------------------------------------------------------
