@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
         const int Sb = 2 + (nn + 1) / 2;
         const int role = (r < Sb) ? r : Sb - 1;
         const int g = (gi < P.ngen) ? gi : P.ngen - 1;
-        return rec2[((size_t)(boff_l[ib] + role) * (size_t)P.N + (size_t)c) * (size_t)P.rec_stride + (size_t)g];
+        return rec2[((size_t)g * (size_t)P.N + (size_t)c) * (size_t)P.S + (size_t)(boff_l[ib] + role)];
     };
     if constexpr (REC) {
         if constexpr (LIVE) {       // an earlier launch of the run already failed: do not wait again

@@ -86,7 +86,7 @@ __device__ __forceinline__ void pc_produce(const WindowParams& P, int64_t pb, in
 // Block-structured runs (DEMCopt.Nblocks > 1, update_blocks demcz.jl:167-172): the record of a generation is
 // one 16-byte entry per Philox block s of its S blocks -- the two row indices (as 64-bit integers), a
 // Box-Muller pair, or log u -- exactly what the cooperating lanes of the fused kernel hand each other
-// through LDS.  rec2[(s * N + c) * GS + g].
+// through LDS.  rec2[(g * N + c) * S + s].
 __device__ __forceinline__ void pcb_produce(const WindowParams& P, int64_t pb)
 {
     const int64_t nbc = (P.N + 63) / 64;
@@ -118,7 +118,9 @@ __device__ __forceinline__ void pcb_produce(const WindowParams& P, int64_t pb)
             e.y = R * sn;
         }
     }
-    reinterpret_cast<double2*>(P.rec_out)[((size_t)s * (size_t)P.N + (size_t)c) * (size_t)P.rec_stride + (size_t)gi] = e;
+    // record-major: the S entries of (generation, chain) are contiguous -- the consumer's lanes of a chain read neighbouring
+    // entries at the same generation
+    reinterpret_cast<double2*>(P.rec_out)[((size_t)gi * (size_t)P.N + (size_t)c) * (size_t)P.S + (size_t)s] = e;
 }
 
 // LIVE launches (single GPU, the reference's immediate visibility): one launch runs through several

@@ -73,7 +73,7 @@ def test_mvnormal_blocks_and_generic_d_bit_exact(demc, oracle, N, d, G, blocks, 
 
 @pytest.mark.parametrize("lanes", [1, 0])
 @pytest.mark.parametrize("kind,d,N,G", [("iso", 10, 50, 60), ("iso", 7, 20, 30), ("linreg", 10, 64, 40), ("linreg", 26, 10, 20),
-                                        ("linreg", 4, 10, 20)])
+                                        ("linreg", 4, 10, 20), ("linreg", 10, 37, 33), ("linreg", 10, 5, 12)])
 def test_anneal_targets_bit_exact(demc, oracle, kind, d, N, G, lanes):
     """Tempered accept (demcz_anneal.jl:172-178) on the isotropic quadratic and the regression SSE."""
     w = demc.workloads.iso_quad_problem(d, N) if kind == "iso" else demc.workloads.linreg_problem(d, N, nobs=120)
