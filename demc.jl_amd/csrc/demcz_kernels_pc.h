@@ -12,10 +12,10 @@
 //       record per (generation, chain): the D normals, log u of the accept test, the two row indices
 //       (against the archive size that generation will see);
 //   consumer workgroups (eight lanes per chain) read the records of THIS launch (written by the
-//       previous launch's producers) a chunk of generations at a time -- the row indices one chunk
-//       ahead, so that a chunk's archive gather starts at once and runs beside its record loads --
+//       previous launch's producers) a chunk of generations at a time -- a chunk's archive rows, normals
+//       and log u are asked for while the chunk before it computes, its row indices a chunk earlier still --
 //       form the proposal increments of the chunk up front, then run the state-dependent part --
-//       proposal, log-density, accept, history -- from registers: ~55 instructions a generation.
+//       proposal, log-density, accept, ballot, history -- from registers: ~66 instructions a generation.
 //
 // Both halves are ONE launch (workgroups [0, consumer_blocks) consume, the rest produce), so they
 // overlap on different CUs with no events or second stream; a launch boundary orders a launch's
@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(LIVE ? 64 * PC8_LIVE_WAVES : 64) window_kernel
     static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "split layout: MvNormal / isotropic targets");
     constexpr int L = 8, G = 64 / L, DP = ((D + 1) / 2) * 2;
     constexpr int NP = (D + L - 1) / L;                    // history elements a lane stores: r, r+8, ...
-    constexpr int CH = (D <= 5) ? PC8_CHUNK : PC8_CHUNK / 2;      // (LIVE launches hold a chunk's CH x D increments in registers)
+    constexpr int CH = (D <= 5) ? PC8_CHUNK : PC8_CHUNK / 2;      // (a lane holds the prefetched rows and normals of ceil(CH / 8) generations)
     constexpr int WAVES = LIVE ? PC8_LIVE_WAVES : 1;
     DEMCZ_STAMP(P, 0);
     if ((int64_t)blockIdx.x >= P.consumer_blocks) {        // every wave of a producer workgroup is one 64-lane producer unit

@@ -129,10 +129,12 @@ __device__ __forceinline__ void pcb_produce(const WindowParams& P, int64_t pb)
 //   * the unwritten part of the archive holds a sentinel (a signalling-NaN pattern no arithmetic
 //     produces: results have the quiet bit set);
 //   * a wave appends its chains' rows with write-through (sc1) 8-byte stores;
-//   * every archive gather of such a launch is an sc1 load (served past the CU's L1) and is repeated
-//     while it returns the sentinel -- each double is its own naturally aligned 8-byte granule, so
-//     nothing needs ordering, flags, fences or a grid barrier (MI355X_MICROARCH.md, inter-workgroup
-//     visibility: sc1 stores + sc1 loads, data-tagged granules).
+//   * an archive gather that returns the sentinel is repeated as an sc1 load (served past the CU's L1 and
+//     the XCD's L2) until the row is there -- each double is its own naturally aligned 8-byte granule
+//     and is written once, so nothing needs ordering, flags, fences or a grid barrier
+//     (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores + sc1 loads, data-tagged granules).
+//     The FIRST read of a row takes the ordinary cached path (sc1 loads are slow to issue, demcz_kernels_pc.h):
+//     a stale cached copy can only show the sentinel where the final double is not yet seen, never a wrong value.
 // A wave only ever waits for rows of an EARLIER boundary than the one it is working towards, so the
 // waits cannot form a cycle; all consumer workgroups are single waves and co-resident (N <= 8192:
 // at most 1024 of them on 256 CUs).  A bounded spin turns a lost row into an error word, not a hang.
