@@ -466,9 +466,16 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
     int64_t nb = 0;
     unsigned int cnt_total = 0, cnt_first = 0;             // accept mask by ballot (WindowParams::acc_out)
     const unsigned long long speak64 = __builtin_amdgcn_ballot_w64(r == 0);
+#ifdef DEMCZ_STAMPS
+    unsigned long long sb[6] = {0, 0, 0, 0, 0, 0}, sb_t = __builtin_readcyclecounter();
+#define MLB_TICK(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); sb[i] += t_ - sb_t; sb_t = t_; } while (0)
+#else
+#define MLB_TICK(i) do { } while (0)
+#endif
     for (int gi = 0; gi < P.ngen; ++gi) {
         const double lp_gen0 = lp;
         for (int ib = 0; ib < NB; ++ib) {
+            MLB_TICK(5);
             if constexpr (LIVE) {
                 // the gather was issued a block-step ago; rows appended since then by other waves read as the
                 // sentinel until they are published: ask again (demcz_kernels_rec.h)
@@ -505,7 +512,9 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
             const double logu = logu_next;
             ib_n = (ib + 1 == NB) ? 0 : ib + 1;
             gi_n = (ib + 1 == NB) ? gi + 1 : gi;
+            MLB_TICK(0);
             issue_draws(gi_n, ib_n);                       // the one past the window is unused
+            MLB_TICK(1);
 
             double xp[NP];
 #pragma unroll
@@ -557,6 +566,7 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
 #pragma unroll
             for (int k = 0; k < NP; ++k) x[k] = acc ? xp[k] : x[k];
             wave_lds_handoff();
+            MLB_TICK(2);
         }
         {
             const unsigned int kc = wave_count_changed(lp, lp_gen0, speak64);
@@ -585,6 +595,7 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
             }
             ++nb;
         }
+        MLB_TICK(3);
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
@@ -593,6 +604,13 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
     }
     if (r == 0) P.lpcur[c] = lp;
     wave_store_counts(P, blockIdx.x, cnt_total, cnt_first);
+#ifdef DEMCZ_STAMPS
+    if (P.stamps && threadIdx.x == 0 && blockIdx.x < 65536u) {     // [wait+poll+increments, next draws, dependent part, history, -, between]
+        unsigned long long* o = P.stamps + (size_t)blockIdx.x * 16;
+        for (int i = 0; i < 6; ++i) o[8 + i] = sb[i];
+        o[14] = (unsigned long long)P.ngen * (unsigned long long)NB;
+    }
+#endif
 }
 
 }  // namespace demcz
