@@ -7,6 +7,7 @@
 #include "demcz_kernels_ml.h"
 #include "demcz_kernels_pc.h"
 #include "demcz_kernels_lr.h"
+#include "demcz_kernels_ps.h"
 
 #include <rccl/rccl.h>
 
@@ -83,7 +84,7 @@ struct demcz_handle {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
     int64_t timed_launches = 0;
     int64_t live_wg_cap = -1;         // consumer workgroups a LIVE launch may have (all must be resident at once); -1: not asked yet
-    int split_kind = 0;               // lanes == DEMCZ_LAYOUT_SPLIT: 1 = eight replicated lanes per chain (pc8), 2 = 16 cooperating
+    int split_kind = 0;               // lanes == DEMCZ_LAYOUT_SPLIT: 4 = one wave per chain, speculating (ps); 1 = eight replicated lanes per chain (pc8), 2 = 16 cooperating
                                       // lanes (ml, REC), 3 = cooperating lanes with block updates (mlb, REC)
     int split_lanes = 0;              // kinds 2, 3: lanes per chain of the consumer
     int split_per_wg = 1;             // chains per consumer workgroup
@@ -173,6 +174,7 @@ constexpr int PC_CONSUMER_CHAINS = 8;       // chains per consumer workgroup of 
 static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t nobs, int max_blocklen, int nblocks);
 static bool pc_available(int target_kind, int d, bool full_block);
 static bool split_ml_available(int target_kind, int d, bool full_block, int64_t nobs);
+static bool ps_available(int target_kind, int d);
 static int32_t flush_exchanges(demcz_handle* h);
 static int32_t check_live_err(demcz_handle* h);
 static int32_t live_verify(demcz_handle* h);
@@ -238,8 +240,9 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT,
                     "demcz_create: need N>=1, 1<=d<=64, K>=1, Mcap>=2, Gcap>=0, Nblocks>=1 and block/eps tables");
     if (cfg->lanes_per_chain != 0 && cfg->lanes_per_chain != 1 && cfg->lanes_per_chain != 8 && cfg->lanes_per_chain != 16 &&
-        cfg->lanes_per_chain != DEMCZ_LAYOUT_SPLIT)
-        return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_create: lanes_per_chain must be 0 (auto), 1, 8, 16 or DEMCZ_LAYOUT_SPLIT");
+        cfg->lanes_per_chain != DEMCZ_LAYOUT_SPLIT && cfg->lanes_per_chain != DEMCZ_LAYOUT_SPLIT_WAVE)
+        return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT,
+                    "demcz_create: lanes_per_chain must be 0 (auto), 1, 8, 16, DEMCZ_LAYOUT_SPLIT or DEMCZ_LAYOUT_SPLIT_WAVE");
     const int d = cfg->d;
     // validate blocks: offsets ascending, indices within range and unique inside a block
     if (cfg->block_offsets[0] != 0) return fail(nullptr, DEMCZ_ERR_INVALID_ARGUMENT, "block_offsets[0] must be 0");
@@ -325,8 +328,19 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         h->split_per_wg = (kind == 1) ? PC_CONSUMER_CHAINS : (kind == 2) ? ((cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? LR16_CHAINS : 4)
                           : (kind == 3) ? 64 / L : 1;
         const bool split_ok = kind != 0;
+        // one wave per chain (demcz_kernels_ps.h): where the replicated consumer is built and a pass's draws fit one DMA
+        const bool ps_ok = kind == 1 && ps_available(cfg->target_kind, d);
         h->split_kind = 0;
-        if (cfg->lanes_per_chain == DEMCZ_LAYOUT_SPLIT) {
+        if (cfg->lanes_per_chain == DEMCZ_LAYOUT_SPLIT_WAVE || (cfg->lanes_per_chain == 0 && ps_ok && cfg->N <= PS_MAX_N && !getenv("DEMCZ_NO_PS"))) {
+            // (us per K-window at d=5, one wave per chain / eight replicated lanes: see DESIGN.md, K1g)
+            if (!ps_ok) {
+                h->err = "demcz_create: the wave-per-chain split layout is not built for this target / d / block structure";
+                return bail(DEMCZ_ERR_INVALID_ARGUMENT);
+            }
+            h->lanes = DEMCZ_LAYOUT_SPLIT;
+            h->split_kind = 4;
+            h->split_per_wg = PS_CHAINS;
+        } else if (cfg->lanes_per_chain == DEMCZ_LAYOUT_SPLIT) {
             if (!split_ok) {
                 h->err = "demcz_create: the split layout is not built for this target / d / block structure";
                 return bail(DEMCZ_ERR_INVALID_ARGUMENT);
@@ -407,7 +421,7 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         int64_t waves;
         if (h->lanes == DEMCZ_LAYOUT_SPLIT) {
             const int64_t wgs = (N + h->split_per_wg - 1) / h->split_per_wg;
-            waves = wgs * ((h->split_kind == 2 && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? LR16_WAVES : 1);
+            waves = wgs * ((h->split_kind == 2 && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? LR16_WAVES : (h->split_kind == 4) ? PS_CHAINS : 1);
         } else if (h->lanes > 1) {
             const int per_wave = 64 / h->lanes;
             const bool lr = h->full_block && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE;
@@ -649,6 +663,8 @@ static bool split_ml_available(int target_kind, int d, bool full_block, int64_t 
     return target_kind == DEMCZ_TARGET_LINREG_SSE && d == 10 && lr16_dynamic_lds<10>(nobs) <= ML_MAX_DYNAMIC_LDS;
 }
 
+static bool ps_available(int target_kind, int d) { return target_kind == DEMCZ_TARGET_MVNORMAL && d >= 2 && d <= 5; }
+
 static int pc_roles(int d) { return ((d == 1) ? 1 : (d + 1) / 2) + 2; }
 // doubles of draw record per (generation, chain), and producer lanes per (generation, chain)
 static int64_t rec_fields(const demcz_handle* h) { return (h->split_kind == 3) ? 2 * h->S : (int64_t)h->cfg.d + 2; }
@@ -658,6 +674,19 @@ static int64_t rec_roles(const demcz_handle* h) { return (h->split_kind == 3) ? 
 constexpr int64_t DEMCZ_STAMP_WGS = 1 << 16;
 #endif
 constexpr size_t REC_PAD = 32;       // chains per consumer workgroup: 8 lanes per chain
+
+template <int TARGET, int D>
+static void launch_ps(const demcz_handle* h, const WindowParams& P, int64_t blocks, bool live)
+{
+    const dim3 grid((unsigned)blocks), wg(64 * PS_CHAINS), wgl(64 * (PS_CHAINS + 1));     // LIVE: chain waves + publisher wave
+    if (P.temperature) {
+        if (live) hipLaunchKernelGGL((window_kernel_ps<TARGET, D, true, true>), grid, wgl, 0, h->stream, P);
+        else hipLaunchKernelGGL((window_kernel_ps<TARGET, D, false, true>), grid, wg, 0, h->stream, P);
+    } else {
+        if (live) hipLaunchKernelGGL((window_kernel_ps<TARGET, D, true, false>), grid, wgl, 0, h->stream, P);
+        else hipLaunchKernelGGL((window_kernel_ps<TARGET, D, false, false>), grid, wg, 0, h->stream, P);
+    }
+}
 
 template <int TARGET, int D>
 static void launch_pc(const demcz_handle* h, const WindowParams& P, int64_t blocks, bool live)
@@ -679,10 +708,19 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
     const bool lr_split = h->split_kind == 2 && h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE;
     const int64_t units = nbc * rec_roles(h) * P.next_ngen;               // 64-lane producer units
     // producer units per workgroup = waves per workgroup of the instantiation that is launched
-    const int upw = lr_split ? LR16_WAVES : (h->split_kind == 1 && live) ? PC8_LIVE_WAVES : 1;
+    const int upw = lr_split ? LR16_WAVES : (h->split_kind == 4) ? PS_CHAINS + (live ? 1 : 0) : (h->split_kind == 1 && live) ? PC8_LIVE_WAVES : 1;
     const int64_t blocks = P.consumer_blocks + (units + upw - 1) / upw;
     if (blocks <= 0) return DEMCZ_OK;
-    if (h->split_kind == 3) {
+    if (h->split_kind == 4) {
+        if (P.ZS != ((P.d <= 2) ? 2 : (P.d <= 4) ? 4 : 8)) return fail(h, DEMCZ_ERR_STATE, "split layout: archive row stride");
+        switch (P.d) {
+        case 2: launch_ps<TARGET_MVNORMAL, 2>(h, P, blocks, live); break;
+        case 3: launch_ps<TARGET_MVNORMAL, 3>(h, P, blocks, live); break;
+        case 4: launch_ps<TARGET_MVNORMAL, 4>(h, P, blocks, live); break;
+        case 5: launch_ps<TARGET_MVNORMAL, 5>(h, P, blocks, live); break;
+        default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
+        }
+    } else if (h->split_kind == 3) {
         const dim3 grid((unsigned)blocks), wg(64);
 #define DEMCZ_LAUNCH_MLB_REC(DD, LL)                                                                                         \
         do {                                                                                                                 \
@@ -1041,11 +1079,28 @@ static int pc_live_blocks_per_cu()
     return std::min(a, b);
 }
 
+template <int D>
+static int ps_live_blocks_per_cu()
+{
+    int a = 0, b = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&window_kernel_ps<TARGET_MVNORMAL, D, true, false>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) a = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(&window_kernel_ps<TARGET_MVNORMAL, D, true, true>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) b = 0;
+    return std::min(a, b);
+}
+
 static int64_t live_wg_capacity(demcz_handle* h)
 {
     if (h->live_wg_cap >= 0) return h->live_wg_cap;
     int per_cu = 0;
-    if (h->split_kind == 3) {
+    if (h->split_kind == 4) {
+        switch (h->cfg.d) {
+        case 2: per_cu = ps_live_blocks_per_cu<2>(); break;
+        case 3: per_cu = ps_live_blocks_per_cu<3>(); break;
+        case 4: per_cu = ps_live_blocks_per_cu<4>(); break;
+        case 5: per_cu = ps_live_blocks_per_cu<5>(); break;
+        default: per_cu = 0;
+        }
+    } else if (h->split_kind == 3) {
         const void* f = nullptr;
         switch (h->cfg.d) {
         case 5: f = reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 5, 8, true, true>); break;
@@ -1155,7 +1210,9 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
             HIPCHK(h, hipStreamSynchronize(h->stream));
             if (h->dtemp) HIPCHK(h, hipFree(h->dtemp));
             h->dtemp = nullptr; h->temp_cap = 0;
-            HIPCHK(h, hipMalloc((void**)&h->dtemp, (size_t)G * sizeof(double)));
+            // (+ 8: the wave-per-chain consumer fetches a pass's temperatures as whole 16-byte pieces, demcz_kernels_ps.h)
+            HIPCHK(h, hipMalloc((void**)&h->dtemp, (size_t)(G + 8) * sizeof(double)));
+            HIPCHK(h, hipMemsetAsync(h->dtemp, 0, (size_t)(G + 8) * sizeof(double), h->stream));
             h->temp_cap = G;
         }
         // stream-ordered behind earlier windows that still read dtemp
@@ -1969,7 +2026,7 @@ extern "C" int32_t demcz_get_info(const demcz_handle* h, int64_t* M, int64_t* la
     if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
     if (M) *M = h->M_app;
     if (launches_window) *launches_window = h->launches;
-    if (lanes_per_chain) *lanes_per_chain = h->lanes;
+    if (lanes_per_chain) *lanes_per_chain = (h->split_kind == 4) ? DEMCZ_LAYOUT_SPLIT_WAVE : h->lanes;
     return DEMCZ_OK;
 }
 

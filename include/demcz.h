@@ -88,11 +88,14 @@ typedef struct demcz_config {
                                      cooperate on a chain; DEMCZ_LAYOUT_SPLIT = producer workgroups
                                      make the state-independent draws one launch ahead, consumer
                                      lanes run the chains, and on one GPU a launch runs through many
-                                     K boundaries (small N).  Results are bit-identical.           */
+                                     K boundaries (small N); DEMCZ_LAYOUT_SPLIT_WAVE = the same with
+                                     one wavefront per chain that resolves five generations per pass
+                                     (smallest N; MvNormal, 2 <= d <= 5).  Results are bit-identical. */
     int32_t reserved0;
 } demcz_config;
 
 #define DEMCZ_LAYOUT_SPLIT 100
+#define DEMCZ_LAYOUT_SPLIT_WAVE 164
 
 /* Version of this header's ABI; demcz_abi_version() must return the same number. */
 #define DEMCZ_ABI_VERSION 1

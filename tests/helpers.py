@@ -18,3 +18,12 @@ def oracle_sample(O, target, Z0, N, K, G, blocks, eps, gamma, seed, temperature=
     M, chain, lobj, changed = O.run(prob, X, lp, Z, M0, 1, G, gamma, temperature=temperature, schedule=schedule,
                                      rng_offset=rng_offset)
     return dict(chain=chain, log_obj=lobj, X=X, logp=lp, Z=Z[:M].copy(), M=M, changed=changed, prob=prob)
+
+
+SPLIT, SPLIT_WAVE = 100, 164       # DEMCZ_LAYOUT_SPLIT, DEMCZ_LAYOUT_SPLIT_WAVE (include/demcz.h)
+
+
+def auto_split_layout(d, N):
+    """What lanes_per_chain = 0 selects where a split layout is built (MvNormal, full block): one wave per chain for the
+    smallest populations of 2 <= d <= 5, the replicated / cooperating consumers otherwise."""
+    return SPLIT_WAVE if (2 <= d <= 5 and N <= 2048) else SPLIT

@@ -9,7 +9,7 @@ the oracle's, bit for bit, all the same."""
 import numpy as np
 import pytest
 
-from helpers import oracle_sample
+from helpers import SPLIT, SPLIT_WAVE, oracle_sample
 
 pytestmark = pytest.mark.gpu
 
@@ -22,14 +22,15 @@ def _engine(demc, w, N, d, K, G, seed, lanes=0):
     return e
 
 
+@pytest.mark.parametrize("layout", [SPLIT, SPLIT_WAVE])
 @pytest.mark.parametrize("K", [1, 3])
-def test_forced_handoff_timeout_is_redone_bit_exact(demc, oracle, K):
+def test_forced_handoff_timeout_is_redone_bit_exact(demc, oracle, K, layout):
     """demcz_run + a synchronising call: poll limit 1 makes a wave give up at its first wait (K = 1: every
     generation draws from rows appended one generation earlier, so there are waits at once)."""
     N, d, G, seed = 512, 5, 120, 41
     w = demc.workloads.mvnormal_problem(d, N)
-    e = _engine(demc, w, N, d, K, G, seed)
-    assert e.info()["lanes_per_chain"] == 100
+    e = _engine(demc, w, N, d, K, G, seed, layout)
+    assert e.info()["lanes_per_chain"] == layout
     e.set_live_spin_limit(1)
     e.run(1, 50, w["gamma"])
     e.run(51, G, w["gamma"])                       # two calls in the log: both are redone
@@ -46,12 +47,13 @@ def test_forced_handoff_timeout_is_redone_bit_exact(demc, oracle, K):
     assert np.array_equal(X, ref["X"]) and np.array_equal(lp, ref["logp"]) and M == ref["M"] and np.array_equal(Z, ref["Z"])
 
 
-def test_forced_handoff_timeout_inside_run_checked(demc, oracle):
+@pytest.mark.parametrize("layout", [SPLIT, SPLIT_WAVE])
+def test_forced_handoff_timeout_inside_run_checked(demc, oracle, layout):
     """demcz_run_checked never returns statistics of a voided slab: the whole call is redone, and the trace,
     the stop decision and the state are those of a run that never used LIVE launches."""
     N, d, K, G, every, seed = 256, 5, 2, 400, 100, 43
     w = demc.workloads.mvnormal_problem(d, N)
-    a = _engine(demc, w, N, d, K, G, seed)
+    a = _engine(demc, w, N, d, K, G, seed, layout)
     a.set_live_spin_limit(1)
     ga, ta, la = a.run_checked(1, G, w["gamma"], every, 0.0)
     on, redos = a.live_status()
@@ -59,7 +61,7 @@ def test_forced_handoff_timeout_inside_run_checked(demc, oracle):
     cha, loa = a.get_history(1, G)
     Xa, lpa, Za, Ma = a.get_state()
     a.close()
-    b = _engine(demc, w, N, d, K, G, seed)          # undisturbed twin
+    b = _engine(demc, w, N, d, K, G, seed, layout)  # undisturbed twin
     gb, tb, lb = b.run_checked(1, G, w["gamma"], every, 0.0)
     onb, redosb = b.live_status()
     assert redosb == 0 and onb
@@ -143,7 +145,8 @@ def test_sharded_scatter_kernels_for_R_ranks(demc, R, cnt, batched):
 
 
 @pytest.mark.parametrize("kind,d,N,blocks,lanes", [
-    ("mvn", 5, 100, None, 0), ("mvn", 5, 100, None, 8), ("mvn", 5, 100, None, 1), ("mvn", 20, 40, None, 0), ("mvn", 20, 40, None, 16),
+    ("mvn", 5, 100, None, 0), ("mvn", 5, 100, None, SPLIT), ("mvn", 3, 37, None, SPLIT_WAVE), ("mvn-T", 5, 100, None, SPLIT_WAVE),
+    ("mvn-T", 4, 50, None, SPLIT), ("mvn", 5, 100, None, 8), ("mvn", 5, 100, None, 1), ("mvn", 20, 40, None, 0), ("mvn", 20, 40, None, 16),
     ("mvn", 6, 50, [[0], [1, 2], [5, 3, 4]], 0), ("mvn", 6, 50, [[0], [1, 2], [5, 3, 4]], 8), ("mvn", 6, 50, [[0], [1, 2], [5, 3, 4]], 1),
     ("mvn", 7, 30, None, 1), ("linreg", 10, 70, None, 0), ("linreg", 10, 70, None, 16), ("iso", 10, 33, None, 0)])
 def test_ballot_accept_counts_equal_history_counts(demc, oracle, kind, d, N, blocks, lanes):
@@ -158,7 +161,7 @@ def test_ballot_accept_counts_equal_history_counts(demc, oracle, kind, d, N, blo
     e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K + 1), Gcap=G, blockindex=bl, eps_scale=w["eps_scale"], seed=seed,
                        target=w["target"], lanes_per_chain=lanes)
     e.set_state(w["Zinit"][-N:], None, w["Zinit"])
-    T = np.linspace(3.0, 0.01, G) if kind != "mvn" else None
+    T = np.linspace(3.0, 0.01, G) if kind != "mvn" else None              # ("mvn-T": the tempered accept on the MvNormal target)
     cuts = [(1, 30), (31, 37), (38, 38), (39, 90)]                        # calls cut anywhere
     for a, b in cuts:
         e.run(a, b, w["gamma"], None if T is None else T[a - 1:b])

@@ -3,7 +3,7 @@ Bit-exact: the arithmetic spec makes every double identica
 import numpy as np
 import pytest
 
-from helpers import oracle_sample
+from helpers import SPLIT, SPLIT_WAVE, auto_split_layout, oracle_sample
 
 pytestmark = pytest.mark.gpu
 
@@ -22,23 +22,26 @@ def test_selftest_draws_bit_exact(demc, oracle):
     assert abs(normals.mean()) < 0.02 and abs(normals.std() - 1.0) < 0.02
 
 
-@pytest.mark.parametrize("lanes", [1, 0, "ml"])
+@pytest.mark.parametrize("lanes", [1, 0, "ml", SPLIT, SPLIT_WAVE])
 @pytest.mark.parametrize("N,d,G", [(4, 5, 200), (100, 5, 57), (1024, 5, 40), (64, 3, 30), (65, 8, 25), (32, 7, 25),
                                    (13, 2, 31), (77, 4, 33), (50, 10, 27), (41, 20, 23)])
 def test_mvnormal_full_block_bit_exact(demc, oracle, N, d, G, lanes):
-    """Every layout: one lane per chain fused (lanes=1), the library's choice (lanes=0: the
-    producer/consumer split for the dimensions it is built for), eight / sixteen lanes per chain."""
+    """Every layout: one lane per chain fused (lanes=1), the library's choice (lanes=0: a
+    producer/consumer split for the dimensions it is built for), eight / sixteen lanes per chain, and both
+    consumers of the split asked for by name (eight replicated lanes per chain; one wave per chain)."""
     if lanes == "ml":
         if d == 7:
             pytest.skip("no multi-lane build for d=7")
         lanes = 16 if d == 20 else 8
+    if (lanes == SPLIT and d == 7) or (lanes == SPLIT_WAVE and not 2 <= d <= 5):
+        pytest.skip("split layout not built for this d")
     w = demc.workloads.mvnormal_problem(d, N)
     seed = 99 + N
     mc, Z, runner = demc.demcz_sample(w["target"], w["Zinit"], N, w["K"], G, 1, [range(d)], w["eps_scale"], w["gamma"],
                                       verbose=False, seed=seed, lanes_per_chain=lanes, return_runner=True)
     used = runner.engines[0].info()["lanes_per_chain"]
     runner.close()
-    assert used == (1 if d == 7 else (100 if lanes == 0 else lanes))
+    assert used == (1 if d == 7 else (auto_split_layout(d, N) if lanes == 0 else lanes))
     ref = oracle_sample(oracle, w["target"], w["Zinit"], N, w["K"], G, None, w["eps_scale"], w["gamma"], seed)
     assert np.array_equal(mc.chain, ref["chain"])
     assert np.array_equal(mc.log_obj, ref["log_obj"])
@@ -427,10 +430,11 @@ def test_full_size_c5_properties(demc, oracle):
     assert np.array_equal(mc.chain[:, :, :G0], ref["chain"]) and np.array_equal(mc.log_obj[:, :G0], ref["log_obj"])
 
 
-def test_live_handoff_under_uneven_load(demc, oracle):
+@pytest.mark.parametrize("layout", [SPLIT, SPLIT_WAVE])
+def test_live_handoff_under_uneven_load(demc, oracle, layout):
     """The in-launch row hand-off of the split layout while another stream keeps the
     chip busy with a 2^18-chain population: consumer waves are dispatched late and unevenly, rows arrive
-    late -- the result must still be the oracle's, bit for bit, for K = 10, 3 and 1."""
+    late -- the result must still be the oracle's, bit for bit, for K = 10, 3 and 1 (both consumers)."""
     d, N = 5, 1024
     w = demc.workloads.mvnormal_problem(d, N)
     M0 = w["Zinit"].shape[0]
@@ -441,8 +445,8 @@ def test_live_handoff_under_uneven_load(demc, oracle):
     big.set_state(wb["Zinit"][-Nb:], None, wb["Zinit"])
     for K, G in ((10, 600), (3, 200), (1, 60)):
         e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K), Gcap=G, blockindex=[range(d)], eps_scale=w["eps_scale"],
-                           seed=11, target=w["target"])
-        assert e.info()["lanes_per_chain"] == 100
+                           seed=11, target=w["target"], lanes_per_chain=layout)
+        assert e.info()["lanes_per_chain"] == layout
         e.set_state(w["Zinit"][-N:], None, w["Zinit"])
         g = 1
         for piece in (G // 3, G // 3, G - 2 * (G // 3)):
