@@ -110,6 +110,12 @@ struct demcz_handle {
     bool replaying = false;
     int32_t live_redos = 0;
     struct RecDesc { bool valid = false; int64_t g_first = 0, M = 0, rows = 0; int32_t ngen = 0, boff = 0; } rec_desc[2];
+    // wave-per-chain split layout: the producer half of a launch is a kernel of its own on a side stream (its own, small
+    // register budget: it fills the SIMDs beside the one-wave-per-SIMD consumers instead of sharing their workgroup shape)
+    hipStream_t prod_stream = nullptr;
+    hipEvent_t prod_done[2] = {nullptr, nullptr};   // records of buffer b are complete
+    hipEvent_t prod_gate = nullptr;                 // main stream: the consumer that last read the buffer about to be refilled is done
+    bool prod_pending[2] = {false, false};          // buffer b was (or is being) filled on the side stream: wait for prod_done[b]
     // accept mask by ballot: per launch and consumer wave {changed over the launch, changed in its first generation};
     // a ring of launches, newest last (demcz_get_changed_total)
     unsigned int* d_acc = nullptr;
@@ -175,6 +181,14 @@ static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t n
 static bool pc_available(int target_kind, int d, bool full_block);
 static bool split_ml_available(int target_kind, int d, bool full_block, int64_t nobs);
 static bool ps_available(int target_kind, int d);
+// the draw records on the device no longer match what the next launch will need (or are about to be freed): nothing of
+// the side-stream producer may still be writing them
+static void rec_invalidate(demcz_handle* h)
+{
+    if (h->prod_stream) (void)hipStreamSynchronize(h->prod_stream);
+    h->prod_pending[0] = h->prod_pending[1] = false;
+    h->rec_desc[0].valid = h->rec_desc[1].valid = false;
+}
 static int32_t flush_exchanges(demcz_handle* h);
 static int32_t check_live_err(demcz_handle* h);
 static int32_t live_verify(demcz_handle* h);
@@ -216,6 +230,9 @@ static void free_all(demcz_handle* h)
         if (h->buf_done[b]) (void)hipEventDestroy(h->buf_done[b]);
     }
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+    if (h->prod_stream) { (void)hipStreamSynchronize(h->prod_stream); (void)hipStreamDestroy(h->prod_stream); }
+    for (int b = 0; b < 2; ++b) if (h->prod_done[b]) (void)hipEventDestroy(h->prod_done[b]);
+    if (h->prod_gate) (void)hipEventDestroy(h->prod_gate);
     if (h->d_stage) (void)hipHostFree(h->d_stage);
     for (auto& pr : h->timed) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (h->pinned_rhat) (void)hipHostFree(h->pinned_rhat);
@@ -534,7 +551,7 @@ extern "C" int32_t demcz_set_state(demcz_handle* h, const double* X, const doubl
     h->M_app = M0;
     h->live_log.clear();
     h->acc_log.clear();
-    h->rec_desc[0].valid = h->rec_desc[1].valid = false;
+    rec_invalidate(h);
     for (auto& pe : h->pending) if (pe.ev) (void)hipEventDestroy(pe.ev);
     h->pending.clear();
     h->batch_cnt = 0; h->batch_J = -1;
@@ -713,12 +730,56 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
     if (blocks <= 0) return DEMCZ_OK;
     if (h->split_kind == 4) {
         if (P.ZS != ((P.d <= 2) ? 2 : (P.d <= 4) ? 4 : 8)) return fail(h, DEMCZ_ERR_STATE, "split layout: archive row stride");
-        switch (P.d) {
-        case 2: launch_ps<TARGET_MVNORMAL, 2>(h, P, blocks, live); break;
-        case 3: launch_ps<TARGET_MVNORMAL, 3>(h, P, blocks, live); break;
-        case 4: launch_ps<TARGET_MVNORMAL, 4>(h, P, blocks, live); break;
-        case 5: launch_ps<TARGET_MVNORMAL, 5>(h, P, blocks, live); break;
-        default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
+        const int bin = (P.rec_in == h->d_rec[0]) ? 0 : 1, bout = (P.rec_out == h->d_rec[0]) ? 0 : 1;
+        if (units > 0) {
+            // the producer half.  With a consumer half beside it: on the side stream, behind the consumer that last read
+            // the buffer it refills (= everything enqueued on the main stream so far).  Alone (records for THIS window,
+            // needed at once): on the main stream.
+            hipStream_t ps = h->stream;
+            if (P.consumer_blocks > 0) {
+                if (!h->prod_stream) {
+                    HIPCHK(h, hipStreamCreateWithFlags(&h->prod_stream, hipStreamNonBlocking));
+                    HIPCHK(h, hipEventCreateWithFlags(&h->prod_gate, hipEventDisableTiming));
+                    for (int b = 0; b < 2; ++b) HIPCHK(h, hipEventCreateWithFlags(&h->prod_done[b], hipEventDisableTiming));
+                }
+                HIPCHK(h, hipEventRecord(h->prod_gate, h->stream));
+                HIPCHK(h, hipStreamWaitEvent(h->prod_stream, h->prod_gate, 0));
+                ps = h->prod_stream;
+            } else if (h->prod_pending[bout]) {
+                HIPCHK(h, hipStreamWaitEvent(h->stream, h->prod_done[bout], 0));      // (never two writers of one buffer)
+                h->prod_pending[bout] = false;
+            }
+            const dim3 pg((unsigned)((units + PRODUCE_WAVES - 1) / PRODUCE_WAVES)), pw(64 * PRODUCE_WAVES);
+            // Beside consumers the producers are throttled to PRODUCE_WGS_PER_CU workgroups a CU by an LDS allocation they
+            // never touch: more of them only take issue slots from the chain waves (measured); alone they
+            // take the whole chip.
+            static const size_t throttle_env = getenv("DEMCZ_PRODUCE_LDS") ? (size_t)atol(getenv("DEMCZ_PRODUCE_LDS")) : PRODUCE_THROTTLE_LDS;
+            const size_t dyn = (ps != h->stream) ? throttle_env : 0;
+            switch (P.d) {
+            case 2: hipLaunchKernelGGL((produce_kernel<2>), pg, pw, dyn, ps, P); break;
+            case 3: hipLaunchKernelGGL((produce_kernel<3>), pg, pw, dyn, ps, P); break;
+            case 4: hipLaunchKernelGGL((produce_kernel<4>), pg, pw, dyn, ps, P); break;
+            case 5: hipLaunchKernelGGL((produce_kernel<5>), pg, pw, dyn, ps, P); break;
+            default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
+            }
+            HIPCHK(h, hipGetLastError());
+            if (ps != h->stream) {
+                HIPCHK(h, hipEventRecord(h->prod_done[bout], ps));
+                h->prod_pending[bout] = true;
+            }
+        }
+        if (P.consumer_blocks > 0) {
+            if (h->prod_pending[bin]) {            // this launch's records were made on the side stream
+                HIPCHK(h, hipStreamWaitEvent(h->stream, h->prod_done[bin], 0));
+                h->prod_pending[bin] = false;
+            }
+            switch (P.d) {
+            case 2: launch_ps<TARGET_MVNORMAL, 2>(h, P, P.consumer_blocks, live); break;
+            case 3: launch_ps<TARGET_MVNORMAL, 3>(h, P, P.consumer_blocks, live); break;
+            case 4: launch_ps<TARGET_MVNORMAL, 4>(h, P, P.consumer_blocks, live); break;
+            case 5: launch_ps<TARGET_MVNORMAL, 5>(h, P, P.consumer_blocks, live); break;
+            default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
+            }
         }
     } else if (h->split_kind == 3) {
         const dim3 grid((unsigned)blocks), wg(64);
@@ -776,6 +837,8 @@ static int32_t rec_reserve(demcz_handle* h, int64_t gens)
 {
     if (gens <= h->rec_cap) return DEMCZ_OK;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->prod_stream) HIPCHK(h, hipStreamSynchronize(h->prod_stream));
+    h->prod_pending[0] = h->prod_pending[1] = false;
     for (int b = 0; b < 2; ++b) {
         if (h->d_rec[b]) HIPCHK(h, hipFree(h->d_rec[b]));
         h->d_rec[b] = nullptr;
@@ -1034,7 +1097,7 @@ static int32_t live_rollback(demcz_handle* h, std::vector<demcz_handle::RunCall>
     h->M_app = h->safe_M_app;
     h->g_done = h->safe_g_done;
     while (!h->acc_log.empty() && h->acc_log.back().g_last > h->safe_g_done) h->acc_log.pop_back();
-    h->rec_desc[0].valid = h->rec_desc[1].valid = false;
+    rec_invalidate(h);
     h->no_live = true;
     live_release(h);
     ++h->live_redos;
@@ -1942,7 +2005,7 @@ extern "C" int32_t demcz_set_append_lag(demcz_handle* h, int32_t batches)
         }
     }
     h->lag = batches;
-    h->rec_desc[0].valid = h->rec_desc[1].valid = false;
+    rec_invalidate(h);
     h->batch_cnt = 0; h->batch_buf = 0; h->batch_J = -1;
     return DEMCZ_OK;
 }
@@ -1952,7 +2015,7 @@ extern "C" int32_t demcz_set_rng_offset(demcz_handle* h, int64_t generations)
     if (!h || generations < 0) return DEMCZ_ERR_INVALID_ARGUMENT;
     if (!h->live_log.empty()) { int32_t rcv = live_verify(h); if (rcv) return rcv; }
     h->rng_offset = generations;
-    h->rec_desc[0].valid = h->rec_desc[1].valid = false;
+    rec_invalidate(h);
     return DEMCZ_OK;
 }
 
@@ -2164,7 +2227,7 @@ static int32_t run_checked_body(demcz_handle* h, int64_t g_from, int64_t g_to, d
                         h->M_app = M_before;
                         h->M = M_before;
                         h->g_done = nxt;
-                        h->rec_desc[0].valid = h->rec_desc[1].valid = false;
+                        rec_invalidate(h);
                         if (!h->live_log.empty()) h->live_log.pop_back();     // the discarded slab is not to be redone
                         while (!h->acc_log.empty() && h->acc_log.back().g_last > nxt) h->acc_log.pop_back();
                     }
@@ -2252,7 +2315,7 @@ extern "C" int32_t demcz_debug_append_slab(demcz_handle* h, const double* slab, 
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->M_app += rows;
     h->M = h->M_app;
-    h->rec_desc[0].valid = h->rec_desc[1].valid = false;
+    rec_invalidate(h);
     return DEMCZ_OK;
 }
 

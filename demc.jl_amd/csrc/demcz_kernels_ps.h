@@ -35,6 +35,7 @@ namespace demcz {
 
 constexpr int PS_CHAINS = 4;     // chain waves per workgroup
 constexpr int PS_R = 5;          // generations per pass = depth of the tree of outcomes (2^5 - 1 = 31 nodes)
+constexpr int PS_PUB = 4;        // boundaries' rows a chain wave may have waiting for the publisher
 constexpr int PS_SLOTS = 3;      // ring of raw slots: the pass being worked on + two in flight
 constexpr int PS_MAX_N = 2048;   // beyond ~2 waves per SIMD the replicated consumer (8 chains per wave) is the faster one
 
@@ -46,12 +47,23 @@ __device__ __forceinline__ void ps_dma16(const void* gsrc, unsigned lds_dst)
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// The producer half on its own (launched beside window_kernel_ps on a side stream, demcz_capi.hip): a kernel with
+// the producer's small register budget fills the SIMDs around the one-wave-per-SIMD consumers; as workgroups of the
+// consumer's kernel it inherits that kernel's registers and workgroup shape, and at five waves per workgroup
+// (LIVE) only one producer workgroup fits a CU beside a consumer workgroup -- the launch then waits for its producers.
+constexpr int PRODUCE_WAVES = 4;
+constexpr size_t PRODUCE_THROTTLE_LDS = 64 * 1024;     // of a CU's 160 KB, ~27 KB of them a consumer workgroup's: two producer workgroups fit
+template <int D>
+__global__ void __launch_bounds__(64 * PRODUCE_WAVES) produce_kernel(const WindowParams P)
+{
+    pc_produce<D>(P, (int64_t)blockIdx.x * PRODUCE_WAVES + (int64_t)(threadIdx.x >> 6), (int)(threadIdx.x & 63));
+}
+
 template <int TARGET, int D, bool LIVE, bool TEMPER>
-__global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0))) window_kernel_ps(const WindowParams P)
+__global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_kernel_ps(const WindowParams P)
 {
     static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "split layout: MvNormal / isotropic targets");
     static_assert(D >= 2 && D <= 5, "a pass's rows, normals, log u and indices are one 64-lane DMA");
-    constexpr int WAVES = PS_CHAINS + (LIVE ? 1 : 0);
     constexpr int HW = (D + 1) / 2;                        // 16-byte pieces of an archive row
     constexpr int ZSC = (D <= 2) ? 2 : (D <= 4) ? 4 : 8;   // archive row stride in doubles (demcz_create: ZS)
     constexpr int ZSH = (ZSC == 2) ? 4 : (ZSC == 4) ? 5 : 6;      // log2 of the row stride in bytes
@@ -66,47 +78,47 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0))) window_kern
     static_assert(TL0 + 3 <= 64, "one DMA instruction per pass");
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if ((int64_t)blockIdx.x >= P.consumer_blocks) {        // every wave of a producer workgroup is one 64-lane producer unit
-        pc_produce<D>(P, ((int64_t)blockIdx.x - P.consumer_blocks) * WAVES + w, lane);
-        return;
-    }
     __shared__ __attribute__((aligned(16))) unsigned char raw[PS_CHAINS][PS_SLOTS][1024];
     __shared__ __attribute__((aligned(16))) double sdelta[PS_CHAINS][(PS_R + 1) * DP];       // row PS_R: negative zeros
     __shared__ __attribute__((aligned(16))) double ctab[PS_CHAINS][2][32 * CR];
-    // LIVE: a boundary's row on its way from a chain wave to the publisher (two boundaries' worth per chain wave) and the
+    // LIVE: a boundary's row on its way from a chain wave to the publisher (PS_PUB boundaries' worth per chain wave) and the
     // hand-shake: pub_seq = boundaries the chain wave has left here, pub_done = written out by the publisher, pub_exit = leaving
-    __shared__ double pub_rows[LIVE ? PS_CHAINS * 2 * D : 1];
+    __shared__ double pub_rows[LIVE ? PS_CHAINS * PS_PUB * D : 1];
     __shared__ unsigned int pub_seq[PS_CHAINS], pub_done[PS_CHAINS], pub_exit[PS_CHAINS];
     if constexpr (LIVE) {
         if (threadIdx.x < PS_CHAINS) { pub_seq[threadIdx.x] = 0u; pub_done[threadIdx.x] = 0u; pub_exit[threadIdx.x] = 0u; }
         __syncthreads();
-        if (w == PS_CHAINS) {       // the publisher (why a wave of its own: demcz_kernels_pc.h, PC8_LIVE_WAVES)
-            unsigned int done[PS_CHAINS];
-#pragma unroll
-            for (int cw = 0; cw < PS_CHAINS; ++cw) done[cw] = 0u;
-            unsigned int idle = 0u;
+        if (w == PS_CHAINS) {
+            // The publisher (why a wave of its own: demcz_kernels_pc.h, PC8_LIVE_WAVES).  Lane (cw, p) looks after element p
+            // of chain wave cw's rows, so the rows of all chain waves that are ready go out in ONE store instruction --
+            // the publisher's own next store waits for the round trip of the one before (the same effect it exists to
+            // keep away from the chain waves): a store per chain wave could not keep up with a boundary every two passes.
+            const bool pl = lane < PS_CHAINS * D;
+            const int cw = pl ? lane / D : 0, pp = pl ? lane % D : 0;
+            const int64_t cl = (int64_t)blockIdx.x * PS_CHAINS + cw;
+            unsigned int done = 0u, idle = 0u;
             while (true) {
-                bool any = false;
-                int gone = 0;
-#pragma unroll
-                for (int cw = 0; cw < PS_CHAINS; ++cw) {
-                    const unsigned int seq = __hip_atomic_load(&pub_seq[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (seq != done[cw]) {
-                        const int64_t c = (int64_t)blockIdx.x * PS_CHAINS + cw;
-                        const double* rows = pub_rows + (cw * 2 + (int)(done[cw] & 1u)) * D;
-                        if (lane < D && c < P.N && P.do_append)
-                            live_store(&P.Zw[(P.M_append + (int64_t)done[cw] * P.N + c) * P.ZS + lane], rows[lane]);
-                        asm volatile("" ::: "memory");
-                        ++done[cw];
-                        if (lane == 0) __hip_atomic_store(&pub_done[cw], done[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        any = true;
-                    } else if (__hip_atomic_load(&pub_exit[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {
-                        // (pub_seq is written before pub_exit: what is read now is final)
-                        if (__hip_atomic_load(&pub_seq[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == done[cw]) ++gone;
+                // The chain waves reach their boundaries at different moments.  Looking for ready rows only once the
+                // store before this one is complete lets the rows that arrived during its flight leave TOGETHER (a store
+                // issued at once would sit behind the earlier one just as long, with one row in it).
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned int seq = __hip_atomic_load(&pub_seq[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const bool ready = pl && seq != done;
+                if (__builtin_amdgcn_ballot_w64(ready) != 0ull) {
+                    if (ready) {
+                        const double v = pub_rows[(cw * PS_PUB + (int)(done % PS_PUB)) * D + pp];
+                        if (cl < P.N && P.do_append) live_store(&P.Zw[(P.M_append + (int64_t)done * P.N + cl) * P.ZS + pp], v);
+                        ++done;
                     }
+                    asm volatile("" ::: "memory");
+                    if (ready && pp == 0) __hip_atomic_store(&pub_done[cw], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    idle = 0u;
+                    continue;
                 }
-                if (gone == PS_CHAINS) break;
-                if (any) { idle = 0u; continue; }
+                // (pub_seq is written before pub_exit: what is read after pub_exit shows set is final)
+                const bool gone = !pl || (__hip_atomic_load(&pub_exit[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u &&
+                                          __hip_atomic_load(&pub_seq[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == done);
+                if (__builtin_amdgcn_ballot_w64(!gone) == 0ull) break;
                 // safety net: a launch that is being abandoned drains even if a chain wave could not say so
                 if ((++idle & 4095u) == 0u && __hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                 __builtin_amdgcn_s_sleep(1);
@@ -131,6 +143,9 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0))) window_kern
     if constexpr (LIVE) {       // an earlier launch of the run already failed: do not wait again
         if (__hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { leave(); return; }
     }
+    // The chain waves are the launch's critical path, one per SIMD, and mostly waiting on their own dependent
+    // instructions; the producer kernel's waves around them are throughput work.  Whenever a chain wave can issue, it should.
+    __builtin_amdgcn_s_setprio(3);
     unsigned char* const raw_w = &raw[w][0][0];
     double* const sd_w = &sdelta[w][0];
     double* const ct_w = &ctab[w][0][0];
@@ -145,7 +160,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0))) window_kern
     const double* mrow[PS_R];
 #pragma unroll
     for (int j = 1; j <= PS_R; ++j) {
-        const bool take = (j == lev) || (j < lev && ((nn >> (lev - 1 - j)) & 1));
+        const bool take = lane != 0 && ((j == lev) || (j < lev && ((nn >> (lev - 1 - j)) & 1)));     // (lane 0: the state itself)
         mrow[j - 1] = sd_w + (take ? j - 1 : PS_R) * DP;
     }
     // the node whose candidate this node's base state is: the last accepted generation on its path (0: the state
@@ -200,27 +215,35 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0))) window_kern
 #pragma unroll
         for (int i = 0; i < D * (D + 1) / 2; ++i) Wc[i] = P.tp.Wp[i];
     }
-    const double c0c = P.tp.c0;
+    double c0v = P.tp.c0;          // (kept in a vector register: see the W entries below)
 
-    // ---- passes of the launch: first generation, length (a pass ends at a K boundary, at the launch's end or after PS_R
-    //      generations) and whether it ends on a boundary -- of the current pass and the four after it
-    int sg[5], sR[5], sB[5];
+    // ---- passes of the launch.  A pass ends at a K boundary, at the launch's end or after PS_R generations.  The current
+    //      pass and the five after it are a queue of nibbles (bits 0-2 length, bit 3 "ends on a boundary", entry k at bits
+    //      4k..4k+3); g0 / g3 / g5 are the first generations of entries 0, 3 and 5.
+    unsigned int segq = 0u;
     int cg = 0, ctb = P.to_boundary;           // where the pass after the last one in the queue starts
-    auto seg_next = [&](int& g0, int& R, int& B) {
+    auto seg_make = [&]() __attribute__((always_inline)) -> unsigned int {
         int n = P.ngen - cg;
         n = (n < 0) ? 0 : n;
         n = (n < PS_R) ? n : PS_R;
-        R = (ctb < n) ? ctb : n;
-        g0 = cg;
-        B = (R > 0 && ctb - R == 0) ? 1 : 0;
+        const int R = (ctb < n) ? ctb : n;
+        const int B = (R > 0 && ctb - R == 0) ? 1 : 0;
         cg += R;
         ctb = B ? P.K : ctb - R;
+        return (unsigned int)(R | (B << 3));
     };
 #pragma unroll
-    for (int k = 0; k < 5; ++k) seg_next(sg[k], sR[k], sB[k]);
-    auto gclamp = [&](int g) { return (g < P.ngen) ? g : P.ngen - 1; };
+    for (int k = 0; k < 6; ++k) segq |= seg_make() << (4 * k);
+    auto qR = [&](int k) __attribute__((always_inline)) -> int { return (int)((segq >> (4 * k)) & 7u); };
+    auto gclamp = [&](int g) __attribute__((always_inline)) { return (g < P.ngen) ? g : P.ngen - 1; };
+    int g0 = 0, g3 = qR(0) + qR(1) + qR(2), g5 = g3 + qR(3) + qR(4);
+    int npass;
+    {
+        const int n1 = (P.to_boundary < P.ngen) ? P.to_boundary : P.ngen, rest = P.ngen - n1;
+        npass = (n1 + PS_R - 1) / PS_R + (rest / P.K) * ((P.K + PS_R - 1) / PS_R) + (rest % P.K + PS_R - 1) / PS_R;
+    }
 
-    // state of the chain: row 0 of table 0
+    // state of the chain: wave-uniform values (x, lp) for the arithmetic, and row 0 of table 0 for whoever needs one element
     double x[D], lp;
 #pragma unroll
     for (int p = 0; p < D; ++p) x[p] = P.Xcur[c + P.N * p];
@@ -236,36 +259,77 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0))) window_kern
 
     // row indices: of this pass and the next (form lanes keep theirs for the LIVE re-reads), by ordinary loads once
     const double* rec_ix = P.rec_in + ((int64_t)(D + 1) * P.N + c) * P.rec_stride;
-    [[maybe_unused]] uint64_t ixA = (uint64_t)__double_as_longlong(rec_ix[gclamp(sg[0] + fu)]);
-    [[maybe_unused]] uint64_t ixB = (uint64_t)__double_as_longlong(rec_ix[gclamp(sg[1] + fu)]);
-    // the DMA of pass k (k = 0..4 relative to the current one) into slot s; `pack`: the row indices its row lanes use
-    auto issue = [&](int k, int slot, uint64_t pack) {
-        const int Rk = sR[k];
+    const int gq1 = qR(0), gq2 = gq1 + qR(1), gq4 = g3 + qR(3);           // first generations of entries 1, 2, 4
+    [[maybe_unused]] uint64_t ixA = (uint64_t)__double_as_longlong(rec_ix[gclamp(fu)]);
+    [[maybe_unused]] uint64_t ixB = (uint64_t)__double_as_longlong(rec_ix[gclamp(gq1 + fu)]);
+    // The DMA of a pass (length Rk, first generation gk) into a slot; `pack`: the row indices its row lanes use; gix: the
+    // first generation of the pass two after it, whose row indices come with it.
+    auto issue = [&](int Rk, int gk, int gix, int slot, uint64_t pack) __attribute__((always_inline)) {
         uint32_t idx = rwhich ? (uint32_t)(pack >> 32) : (uint32_t)pack;
         idx = (ru < Rk) ? idx : 0u;             // slots past the end of the pass read row 0 (LIVE: never wait for them)
-        const int gk = gclamp(sg[k]);
-        const int gi2 = (k + 2 < 5) ? gclamp(sg[(k + 2 < 5) ? k + 2 : 4]) : 0;
-        const uint64_t dyn = rowl ? ((uint64_t)idx << ZSH) : ixl ? (uint64_t)gi2 * 8u : (fieldl || templ) ? (uint64_t)gk * 8u : 0u;
+        const uint32_t gsel = (uint32_t)(ixl ? gclamp(gix) : gclamp(gk));
+        const uint64_t dyn = rowl ? ((uint64_t)idx << ZSH) : (uint64_t)(gsel << 3);     // (idle lanes: somewhere inside the records)
         ps_dma16(sbase + dyn, raw_lds + (unsigned)slot * 1024u);
     };
     {
-        const uint64_t p0 = (uint64_t)__double_as_longlong(rec_ix[gclamp(sg[0] + ru)]);
-        const uint64_t p1 = (uint64_t)__double_as_longlong(rec_ix[gclamp(sg[1] + ru)]);
-        // (everything loaded so far is in registers before the first DMA: the compiler's own waits must never sit behind one)
+        const uint64_t p0 = (uint64_t)__double_as_longlong(rec_ix[gclamp(ru)]);
+        const uint64_t p1 = (uint64_t)__double_as_longlong(rec_ix[gclamp(gq1 + ru)]);
+        // Everything loaded so far is in registers, and the compiler knows it (each value is an operand of an empty
+        // statement), before the first DMA: a wait of the compiler's own for one of these, placed inside the loop,
+        // would wait for the DMAs in flight as well -- every pass.  (The W entries stay in vector registers: as scalars
+        // they and the state crowd the scalar file into spills.)
+#pragma unroll
+        for (int p = 0; p < D; ++p) asm volatile("" :: "v"(x[p]), "v"(muc[p]));
+        if constexpr (TARGET == TARGET_MVNORMAL) {
+#pragma unroll
+            for (int i = 0; i < D * (D + 1) / 2; ++i) asm volatile("" : "+v"(Wc[i]));
+        }
+        asm volatile("" : "+v"(c0v));
+        asm volatile("" :: "v"(lp), "v"(eps_p), "v"(ixA), "v"(ixB), "v"(p0), "v"(p1));
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        issue(0, 0, p0);
-        issue(1, 1, p1);
+        issue(qR(0), 0, gq2, 0, p0);
+        issue(qR(1), gq1, g3, 1, p1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    auto uniform = [&](double v) __attribute__((always_inline)) {          // a wave-uniform double as a scalar value
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)b);
+        const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(b >> 32));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    auto from_lane = [&](double v, unsigned int l) __attribute__((always_inline)) {       // lane l's v (l wave-uniform)
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)b, (int)l);
+        const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(b >> 32), (int)l);
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+#pragma unroll
+    for (int p = 0; p < D; ++p) x[p] = uniform(x[p]);
+    lp = uniform(lp);
 
-    // history: one buffer descriptor per array, re-based every pass (offsets stay small); no history = nothing in range
-    const double* hx_base = hist ? P.chain + (int64_t)P.N * D * P.slot_first : P.Z;
-    const double* hl_base = hist ? P.logobj + (int64_t)P.N * P.slot_first : P.Z;
-    const uint32_t hx_off = (hl && hp < D) ? (uint32_t)((((int64_t)hj * D + hp) * P.N + c) * 8) : 0xffffffffu;
-    const uint32_t hl_off = (hl && hp == D) ? (uint32_t)(((int64_t)hj * P.N + c) * 8) : 0xffffffffu;
-    const uint32_t hx_span = (uint32_t)((int64_t)D * P.N * 8), hl_span = (uint32_t)(P.N * 8);      // one generation of each
+    // history: one buffer descriptor per array, moved on every pass (offsets stay small); no history = nothing in range
+    const unsigned char* hx_ptr = reinterpret_cast<const unsigned char*>(hist ? P.chain + (int64_t)P.N * D * P.slot_first : P.Z);
+    const unsigned char* hl_ptr = reinterpret_cast<const unsigned char*>(hist ? P.logobj + (int64_t)P.N * P.slot_first : P.Z);
+    const uint32_t hx_off = (hl && hp < D) ? (uint32_t)((((int64_t)hj * D + hp) * P.N + c) * 8) : 0x7fffff00u;
+    const uint32_t hl_off = (hl && hp == D) ? (uint32_t)(((int64_t)hj * P.N + c) * 8) : 0x7fffff00u;
+    const uint32_t hx_span = hist ? (uint32_t)((int64_t)D * P.N * 8) : 0u, hl_span = hist ? (uint32_t)(P.N * 8) : 0u;      // one generation of each
+    // the history rows of a pass leave one pass later (their LDS reads then have a whole pass to come back): value and
+    // length of the pass they belong to
+    double hv = 0.0;
+    uint32_t hR = 0;
+    auto store_history = [&]() __attribute__((always_inline)) {
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const unsigned long long vb = (unsigned long long)__double_as_longlong(hv);
+        const u32x2 vv = {(unsigned int)vb, (unsigned int)(vb >> 32)};
+        const uint32_t lim_x = hR * hx_span, lim_l = hR * hl_span;      // generations beyond the pass: out of range
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hx_ptr), 0, (int)lim_x, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hl_ptr), 0, (int)lim_l, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b64(vv, rx, (int)hx_off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(vv, rl, (int)hl_off, 0, 0);
+        hx_ptr += lim_x;
+        hl_ptr += lim_l;
+    };
 
-    int slot = 0;
     int64_t nb = 0;
     unsigned int cnt_total = 0, cnt_first = 0;
 #ifdef DEMCZ_STAMPS
@@ -274,74 +338,117 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0))) window_kern
 #else
 #define PS_TICK(i) do { } while (0)
 #endif
-    while (true) {
-        const int g = sg[0], R = sR[0];
-        if (R == 0) break;
+
+    // ---- front end of a pass (raw slot `slot`): everything about it that does not depend on the chain's state --
+    //      increments into LDS, the DMA of the pass two after it, then each node's rows of increments, its log u and
+    //      temperature into registers.  It runs INSIDE the pass before (software pipeline: its LDS and issue time hides
+    //      behind that pass's dependent arithmetic); rows that still show the sentinel are only flagged here.
+    double m[PS_R][D];                               // the node's rows (of the pass at hand, then of the next one)
+    double logu = 0.0;
+    [[maybe_unused]] double temp = 1.0;
+    double za_f = 0.0, zb_f = 0.0, zt_f = 0.0;       // what the form lane read (kept for the LIVE re-reads)
+    uint64_t pf_f = 0;
+    auto load_rows = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < PS_R; ++j)
+#pragma unroll
+            for (int q = 0; q < DP / 2; ++q) {
+                const double2 t = reinterpret_cast<const double2*>(mrow[j])[q];
+                m[j][2 * q] = t.x;
+                if (2 * q + 1 < D) m[j][2 * q + 1] = t.y;
+            }
+    };
+    auto write_increment = [&]() __attribute__((always_inline)) {
+        const double diff = za_f - zb_f;
+        const double t1 = scale * diff;
+        const double t2 = eps_p * zt_f;
+        if (fl) sd_w[fu * DP + fp] = t1 + t2;
+    };
+    // Rn: length of the front end's pass; (R2, g2, gix): the pass two after it (the DMA it issues)
+    auto front = [&](int slot, int Rn, int R2, int g2, int gix, bool counted) __attribute__((always_inline)) -> bool {
         const unsigned char* rw = raw_w + slot * 1024;
-        // ---- 1. this pass's slot: behind it in program order are the DMA of the next pass and two passes' history
-        //         stores (two instructions each): everything older has landed when at most those five are outstanding
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        double za = *reinterpret_cast<const double*>(rw + zao);
-        double zb = *reinterpret_cast<const double*>(rw + zbo);
-        const double zt = *reinterpret_cast<const double*>(rw + zto);
+        // behind this slot's DMA in program order: the DMA of the pass after it and two passes' history stores (two
+        // instructions each) -- it has landed when at most those five are outstanding
+        if (counted) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        za_f = *reinterpret_cast<const double*>(rw + zao);
+        zb_f = *reinterpret_cast<const double*>(rw + zbo);
+        zt_f = *reinterpret_cast<const double*>(rw + zto);
         const uint64_t pr = *reinterpret_cast<const uint64_t*>(rw + ixo + ru * 8);      // row indices of the pass two after this one
-        const uint64_t pf = *reinterpret_cast<const uint64_t*>(rw + ixo + fu * 8);
-        if constexpr (LIVE) {
-            // rows appended by other waves since the DMA read them show the sentinel until they are published: ask again
-            bool bad = fl && fu < R && (is_sentinel(za) | is_sentinel(zb));
-            if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
+        pf_f = *reinterpret_cast<const uint64_t*>(rw + ixo + fu * 8);
+        logu = *reinterpret_cast<const double*>(rw + lgo);
+        if constexpr (TEMPER) temp = *reinterpret_cast<const double*>(rw + tko);
+        bool bad = false;
+        if constexpr (LIVE) bad = fl && fu < Rn && (is_sentinel(za_f) | is_sentinel(zb_f));
+        write_increment();
+        const int s2 = (slot + 2 >= PS_SLOTS) ? slot + 2 - PS_SLOTS : slot + 2;
+        issue(R2, g2, gix, s2, pr);
+        wave_lds_handoff();
+        load_rows();
+        return bad;
+    };
+    // LIVE: rows of the front end's pass that other waves had not published when the DMA read them -- asked for again
+    // (sc1 loads) until they are there, increments and node rows redone.  Returns true when the wait was abandoned.
+    auto reread = [&](bool bad, int gpass) __attribute__((always_inline)) -> bool {
 #ifdef DEMCZ_STAMPS
-                ++sa_bad;
+        ++sa_bad;
 #endif
-                const uint32_t i1 = (uint32_t)ixA, i2 = (uint32_t)(ixA >> 32);
-                int spins = 0;
-                while (__builtin_amdgcn_ballot_w64(bad) != 0ull) {       // wave-uniform
-                    if (spins > 0) {
-                        if (live_poll_abandon(P, spins, bad, is_sentinel(za) ? i1 : i2, g)) { leave(); return; }
-                        __builtin_amdgcn_s_sleep(1);
-                    } else {
-                        spins = 1;
-                    }
-                    if (bad) {
-                        if (is_sentinel(za)) za = live_load(&P.Z[(int64_t)i1 * ZSC + fp]);
-                        if (is_sentinel(zb)) zb = live_load(&P.Z[(int64_t)i2 * ZSC + fp]);
-                        bad = is_sentinel(za) | is_sentinel(zb);
-                    }
-                }
+        const uint32_t i1 = (uint32_t)ixA, i2 = (uint32_t)(ixA >> 32);
+        int spins = 0;
+        while (__builtin_amdgcn_ballot_w64(bad) != 0ull) {       // wave-uniform
+            if (spins > 0) {
+                if (live_poll_abandon(P, spins, bad, is_sentinel(za_f) ? i1 : i2, gpass)) return true;
+                __builtin_amdgcn_s_sleep(1);
+            } else {
+                spins = 1;
+            }
+            if (bad) {
+                if (is_sentinel(za_f)) za_f = live_load(&P.Z[(int64_t)i1 * ZSC + fp]);
+                if (is_sentinel(zb_f)) zb_f = live_load(&P.Z[(int64_t)i2 * ZSC + fp]);
+                bad = is_sentinel(za_f) | is_sentinel(zb_f);
             }
         }
-        {
-            const double diff = za - zb;
-            const double t1 = scale * diff;
-            const double t2 = eps_p * zt;
-            if (fl) sd_w[fu * DP + fp] = t1 + t2;
-        }
-        PS_TICK(0);
-        // ---- 2. the DMA of the pass two after this one (its row indices came with this slot)
-        {
-            const int s2 = (slot + 2 >= PS_SLOTS) ? slot + 2 - PS_SLOTS : slot + 2;
-            issue(2, s2, pr);
-            ixA = ixB;
-            ixB = pf;
-        }
-        PS_TICK(1);
         wave_lds_handoff();
-        // ---- 3. every node's candidate and its log-density
+        write_increment();
+        wave_lds_handoff();
+        load_rows();
+        return false;
+    };
+
+    {
+        // the first pass's front end, on its own; at the start of a launch every row it may draw is published
+        // (slot 0; the DMA it issues is the third pass's)
+        const bool bad0 = front(0, qR(0), qR(2), gq2, gq4, false);
+        if constexpr (LIVE) {
+            if (__builtin_amdgcn_ballot_w64(bad0) != 0ull) {
+                if (reread(bad0, 0)) { leave(); return; }
+            }
+        }
+        ixA = ixB;
+        ixB = pf_f;
+    }
+    int slot = 1;                     // the raw slot the next front end consumes
+    for (int ip = 0; ip < npass; ++ip) {
+        const int R = qR(0);
+        // a pass that ends on a boundary asks early how far the publisher is (the answer only grows)
+        [[maybe_unused]] unsigned int pub_seen = 0u;
+        if constexpr (LIVE) {
+            if (segq & 8u) pub_seen = __hip_atomic_load(&pub_done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        const double logu_c = logu;
+        [[maybe_unused]] const double temp_c = temp;
+        // every node's candidate: state + its rows in order
         double cand[D];
 #pragma unroll
         for (int p = 0; p < D; ++p) cand[p] = x[p];
 #pragma unroll
-        for (int j = 0; j < PS_R; ++j) {
-            double m[DP];
+        for (int j = 0; j < PS_R; ++j)
 #pragma unroll
-            for (int q = 0; q < DP / 2; ++q) {
-                const double2 t = reinterpret_cast<const double2*>(mrow[j])[q];
-                m[2 * q] = t.x;
-                m[2 * q + 1] = t.y;
-            }
-#pragma unroll
-            for (int p = 0; p < D; ++p) cand[p] = cand[p] + m[p];
-        }
+            for (int p = 0; p < D; ++p) cand[p] = cand[p] + m[j][p];
+        PS_TICK(0);
+        // the pass before's history leaves; the next pass's front end
+        store_history();
+        const bool bad_n = front(slot, qR(1), qR(3), g3, g5, true);
+        PS_TICK(1);
         double lpp;
         if constexpr (TARGET == TARGET_MVNORMAL) {
             double q = 0.0;
@@ -352,7 +459,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0))) window_kern
                 for (int j = 1; j <= i; ++j) acc = fma(Wc[(i * (i + 1)) / 2 + j], cand[j] - muc[j], acc);
                 q = (i == 0) ? acc * acc : fma(acc, acc, q);
             }
-            lpp = fma(-0.5, q, c0c);
+            lpp = fma(-0.5, q, c0v);
         } else {
             double q = 0.0;
 #pragma unroll
@@ -362,9 +469,9 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0))) window_kern
             }
             lpp = -q;
         }
-        // the candidates go to the table the current state is NOT in
+        // the candidates go to the table the current state is NOT in (for whoever needs single elements: history, append)
         double* const tnew = ct_w + (cur_tab ^ 1) * (32 * CR);
-        if (lane >= 1 && lane < 32) {
+        if (nodel) {
             double row[CR];
 #pragma unroll
             for (int p = 0; p < CR; ++p) row[p] = (p < D) ? cand[p] : ((p == D) ? lpp : 0.0);
@@ -372,18 +479,17 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0))) window_kern
             for (int q = 0; q < CR / 2; ++q) reinterpret_cast<double2*>(tnew + lane * CR)[q] = make_double2(row[2 * q], row[2 * q + 1]);
         }
         PS_TICK(2);
-        // ---- 4. all accept tests at once; the path taken, from the lane mask
+        // all accept tests at once
         unsigned long long mask, chg_a, chg_r;
         {
             const unsigned long long lb = (unsigned long long)__double_as_longlong((lane == 0) ? lp : lpp);
             const unsigned int blo = (unsigned int)__builtin_amdgcn_ds_bpermute(anc4, (int)(unsigned int)lb);
             const unsigned int bhi = (unsigned int)__builtin_amdgcn_ds_bpermute(anc4, (int)(unsigned int)(lb >> 32));
             const double lpb = __longlong_as_double((long long)(((unsigned long long)bhi << 32) | blo));     // log-density of the node's base state
-            const double logu = *reinterpret_cast<const double*>(rw + lgo);
             const double d0 = lpp - lpb;
             double dlt = d0;
-            if constexpr (TEMPER) dlt = dlt / *reinterpret_cast<const double*>(rw + tko);
-            mask = __builtin_amdgcn_ballot_w64(logu < dlt);
+            if constexpr (TEMPER) dlt = dlt / temp_c;
+            mask = __builtin_amdgcn_ballot_w64(logu_c < dlt);
             // "log_obj changed" (WindowParams::acc_out): after an accept lp' - lp, after a reject lp - lp (NaN for an infinite lp)
             chg_a = __builtin_amdgcn_fcmp(d0, 0.0, 14 /* UNE */);
             chg_r = __builtin_amdgcn_fcmp(lpb - lpb, 0.0, 14);
@@ -399,42 +505,40 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0))) window_kern
         {
             const unsigned int chm = (accp & (unsigned int)chg_a) | (path & ~m32 & (unsigned int)chg_r);
             cnt_total += (unsigned int)__builtin_popcount(chm);
-            if (g == 0) cnt_first = (chm >> 1) & 1u;
+            if (g0 == 0) cnt_first = (chm >> 1) & 1u;
+        }
+        // the new state, straight from the winner's registers (lane 0 shadows the starting state: all its rows are
+        // negative zeros, its candidate IS x)
+#pragma unroll
+        for (int p = 0; p < D; ++p) x[p] = from_lane(cand[p], win);
+        {
+            const double lw = from_lane(lpp, win);
+            lp = win ? lw : lp;
         }
         PS_TICK(3);
         wave_lds_handoff();
-        // ---- 5. history rows of the pass, the new state
+        // history rows of the pass: read now, stored during the next pass
         {
             const unsigned int wa = accp & hmask;
             const unsigned int wj = wa ? 31u - (unsigned int)__builtin_clz(wa) : 0u;
             const double* src = (wj == 0u) ? cur : tnew + wj * CR;
-            const double v = src[hp];
-            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-            const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
-            const u32x2 vv = {(unsigned int)vb, (unsigned int)(vb >> 32)};
-            const uint32_t lim_x = hist ? (uint32_t)R * hx_span : 0u, lim_l = hist ? (uint32_t)R * hl_span : 0u;
-            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(hx_base) + (int64_t)g * D * P.N, 0, (int)lim_x, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(hl_base) + (int64_t)g * P.N, 0, (int)lim_l, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b64(vv, rx, (int)hx_off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(vv, rl, (int)hl_off, 0, 0);
+            hv = src[hp];
+            hR = (uint32_t)R;
         }
         if (win != 0u) { cur = tnew + win * CR; cur_tab ^= 1; }
+        // a generation divisible by K ended the pass: runchain!'s append, demcz.jl:88-91
+        if (segq & 8u) {
+            double v = x[0];               // lane p: element p of the new state (x is wave-uniform)
 #pragma unroll
-        for (int q = 0; q < CR / 2; ++q) {
-            const double2 t = reinterpret_cast<const double2*>(cur)[q];
-            if (2 * q < D) x[2 * q] = t.x;
-            if (2 * q == D) lp = t.x;
-            if (2 * q + 1 < D) x[2 * q + 1] = t.y;
-            if (2 * q + 1 == D) lp = t.y;
-        }
-        PS_TICK(4);
-        // ---- 6. a generation divisible by K ended the pass: runchain!'s append, demcz.jl:88-91
-        if (sB[0]) {
-            const double v = cur[(lane < D) ? lane : 0];
+            for (int p = 1; p < D; ++p) v = (lane == p) ? x[p] : v;
             if constexpr (LIVE) {
-                while (__hip_atomic_load(&pub_done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 2u <= (unsigned int)nb)
+                // the slot of pub_rows this boundary uses was emptied PS_PUB boundaries ago -- almost always
+                asm volatile("" : "+v"(pub_seen));          // (not looked at before this point: the read has had the whole pass)
+                while (pub_seen + (unsigned int)PS_PUB <= (unsigned int)nb) {
                     __builtin_amdgcn_s_sleep(1);
-                if (lane < D) pub_rows[(w * 2 + (int)((unsigned int)nb & 1u)) * D + lane] = v;
+                    pub_seen = __hip_atomic_load(&pub_done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (lane < D) pub_rows[(w * PS_PUB + (int)((unsigned int)nb % PS_PUB)) * D + lane] = v;
                 asm volatile("" ::: "memory");                 // (one wave's LDS operations execute in order)
                 if (lane == 0) __hip_atomic_store(&pub_seq[w], (unsigned int)nb + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
@@ -443,17 +547,28 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0))) window_kern
             if (lane < D && P.snap) P.snap[nb * P.N * D + c + P.N * lane] = v;
             ++nb;
         }
+        PS_TICK(4);
+        if constexpr (LIVE) {
+            // only now -- this wave's own row is on its way -- may it wait for rows of other waves
+            if (__builtin_amdgcn_ballot_w64(bad_n) != 0ull) {
+                if (reread(bad_n, g0 + R)) { leave(); return; }
+            }
+        }
         wave_lds_handoff();      // sdelta and the other candidate table are rewritten by the next pass
-        // next pass
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { sg[k] = sg[k + 1]; sR[k] = sR[k + 1]; sB[k] = sB[k + 1]; }
-        seg_next(sg[4], sR[4], sB[4]);
+        // the queue moves on
+        g0 += R;
+        g3 += qR(3);
+        g5 += qR(5);
+        segq = (segq >> 4) | (seg_make() << 20);
         slot = (slot + 1 == PS_SLOTS) ? 0 : slot + 1;
+        ixA = ixB;
+        ixB = pf_f;
         PS_TICK(5);
 #ifdef DEMCZ_STAMPS
         ++sa_n;
 #endif
     }
+    store_history();          // the last pass's
     {
         const double v = cur[(lane < D) ? lane : 0];
         if (lane < D) P.Xcur[c + P.N * lane] = v;
@@ -461,7 +576,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0))) window_kern
     }
     wave_store_counts(P, c, cnt_total, cnt_first);
 #ifdef DEMCZ_STAMPS
-    if (P.stamps && lane == 0 && c < 65536) {      // [wait + increments, DMA issue, candidates + log-density, accept + path, history + state, boundary + bookkeeping]
+    if (P.stamps && lane == 0 && c < 65536) {      // scripts/ps_stamps.py names the six sums
         unsigned long long* o = P.stamps + (size_t)c * 16;
         for (int i = 0; i < 6; ++i) o[8 + i] = sa[i];
         o[14] = sa_n;

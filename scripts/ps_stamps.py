@@ -1,6 +1,6 @@
 """Where a pass of the wave-per-chain consumer (demcz_kernels_ps.h) spends its time: shader-clock sums written by a
 diagnostic build (-DDEMCZ_STAMPS, build_ab/stamps.so; never the shipped library).
-usage: python scripts/ps_stamps.py [N] [K] [generations]   (run on the GPU box)"""
+usage: python scripts/ps_stamps.py [N] [K] [generations] [M0]   (run on the GPU box; M0: rows of a synthetic initial archive)"""
 import ctypes as C
 import os
 import subprocess
@@ -21,8 +21,11 @@ from demc_jl_amd import _lib
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 G = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
+M0big = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 d = 5
 w = demc.workloads.mvnormal_problem(d, N)
+if M0big:
+    w["Zinit"] = np.asfortranarray(w["mu"] + 0.1 * np.random.default_rng(0).standard_normal((M0big, d)))
 M0 = w["Zinit"].shape[0]
 e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K + 1), Gcap=G, blockindex=[range(d)], eps_scale=w["eps_scale"], seed=1,
                    target=w["target"])
@@ -38,9 +41,10 @@ rc = lib.demcz_debug_read_stamps(e._h, buf.ctypes.data_as(C.c_void_p), N)
 assert rc == 0, rc
 s = buf.astype(np.float64)
 n = s[:, 14]
-names = ["wait for the pass's slot, (LIVE re-reads,) increments -> LDS", "DMA of the pass two ahead issued",
-         "candidates + log-density of all nodes, candidates -> LDS", "accept tests, path from the lane mask",
-         "history stores, new state from LDS", "boundary (append hand-off), bookkeeping of the passes"]
+names = ["candidates: state + the node's rows (and whatever the loop's top waits for)",
+         "previous pass's history stores; front end of the next pass: slot wait, increments -> LDS, DMA, node rows <- LDS",
+         "log-density of all nodes, candidates -> LDS", "accept tests, path from the lane mask, new state from the winner's registers",
+         "history values <- LDS, boundary (append hand-off)", "LIVE re-reads, bookkeeping of the passes"]
 print(f"N={N} K={K}: last launch, {n.mean():.0f} passes per chain wave; shader-clock ticks per pass, mean / max over chains")
 tot = 0
 for i, nm in enumerate(names):
