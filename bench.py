@@ -54,10 +54,20 @@ def measured_traffic(n_loc, d, K, lanes, gens_per_launch):
         return None
     if abs(float(shape.get("generations_per_launch", -1)) - gens_per_launch) > 1e-9:
         return None
-    for k, v in prof["kernels"].items():
-        if k.startswith(shape.get("kernel_prefix", "void demcz::window_kernel")):
-            return v.get("bytes_per_launch_raw"), v.get("bytes_per_launch_fetch_x2"), f"profiles/{prof.get('tag')}_traffic.json"
-    return None
+    # (the wave-per-chain layout's window launch is two kernels -- consumer, and producer half on a side stream: their sum)
+    prefixes = shape.get("kernel_prefixes") or [shape.get("kernel_prefix", "void demcz::window_kernel")]
+    raw = x2 = 0.0
+    found = 0
+    for pre in prefixes:
+        for k, v in prof["kernels"].items():
+            if k.startswith(pre):
+                raw += v.get("bytes_per_launch_raw") or 0.0
+                x2 += v.get("bytes_per_launch_fetch_x2") or 0.0
+                found += 1
+                break
+    if found != len(prefixes):
+        return None
+    return raw, x2, f"profiles/{prof.get('tag')}_traffic.json"
 
 
 def throughput_point(demc, N, d, K, seed, gens, device_id):
@@ -287,7 +297,9 @@ def main():
             "value_window_kernels_only": N * gens / (ev_ms / 1e3) if ev_ms > 0 else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic[0], "traffic_fetch_x2": traffic[1], "traffic_source": traffic[2],
-                         "kernel": (f"demcz::window_kernel_pc8<MVNORMAL, {d}, LIVE={'true' if live_on else 'false'}>" if split
+                         "kernel": (f"demcz::window_kernel_ps<MVNORMAL, {d}, LIVE={'true' if live_on else 'false'}> (+ demcz::produce_kernel<{d}> beside it)"
+                                    if lanes == 164 else
+                                    f"demcz::window_kernel_pc8<MVNORMAL, {d}, LIVE={'true' if live_on else 'false'}>" if split
                                     else "demcz::window_kernel"),
                          "launches": launches, "generations_per_launch": gens_per_launch,
                          "avg_launch_us": avg_launch_s * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch,

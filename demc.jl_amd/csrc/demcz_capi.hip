@@ -731,8 +731,13 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
     if (h->split_kind == 4) {
         if (P.ZS != ((P.d <= 2) ? 2 : (P.d <= 4) ? 4 : 8)) return fail(h, DEMCZ_ERR_STATE, "split layout: archive row stride");
         const int bin = (P.rec_in == h->d_rec[0]) ? 0 : 1, bout = (P.rec_out == h->d_rec[0]) ? 0 : 1;
-        if (units > 0) {
-            // the producer half.  With a consumer half beside it: on the side stream, behind the consumer that last read
+        const bool one_launch = !live && P.consumer_blocks > 0;     // a short launch: producer workgroups ride in the consumer's grid
+        if (units > 0 && one_launch && h->prod_pending[bout]) {
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->prod_done[bout], 0));      // (never two writers of one buffer)
+            h->prod_pending[bout] = false;
+        }
+        if (units > 0 && !one_launch) {
+            // the producer half.  Beside a LIVE consumer: on the side stream, behind the consumer that last read
             // the buffer it refills (= everything enqueued on the main stream so far).  Alone (records for THIS window,
             // needed at once): on the main stream.
             hipStream_t ps = h->stream;
@@ -773,11 +778,12 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
                 HIPCHK(h, hipStreamWaitEvent(h->stream, h->prod_done[bin], 0));
                 h->prod_pending[bin] = false;
             }
+            const int64_t grid = P.consumer_blocks + (one_launch ? (units + PS_CHAINS - 1) / PS_CHAINS : 0);
             switch (P.d) {
-            case 2: launch_ps<TARGET_MVNORMAL, 2>(h, P, P.consumer_blocks, live); break;
-            case 3: launch_ps<TARGET_MVNORMAL, 3>(h, P, P.consumer_blocks, live); break;
-            case 4: launch_ps<TARGET_MVNORMAL, 4>(h, P, P.consumer_blocks, live); break;
-            case 5: launch_ps<TARGET_MVNORMAL, 5>(h, P, P.consumer_blocks, live); break;
+            case 2: launch_ps<TARGET_MVNORMAL, 2>(h, P, grid, live); break;
+            case 3: launch_ps<TARGET_MVNORMAL, 3>(h, P, grid, live); break;
+            case 4: launch_ps<TARGET_MVNORMAL, 4>(h, P, grid, live); break;
+            case 5: launch_ps<TARGET_MVNORMAL, 5>(h, P, grid, live); break;
             default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
             }
         }

@@ -78,6 +78,15 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     static_assert(TL0 + 3 <= 64, "one DMA instruction per pass");
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if constexpr (!LIVE) {
+        // launches that end at the next boundary (sharded runs, deferred visibility) are short: their producer half rides
+        // in the same launch, as in the replicated consumer -- every wave of a producer workgroup is one 64-lane unit.
+        // (LIVE launches: produce_kernel beside them.)
+        if ((int64_t)blockIdx.x >= P.consumer_blocks) {
+            pc_produce<D>(P, ((int64_t)blockIdx.x - P.consumer_blocks) * PS_CHAINS + w, lane);
+            return;
+        }
+    }
     __shared__ __attribute__((aligned(16))) unsigned char raw[PS_CHAINS][PS_SLOTS][1024];
     __shared__ __attribute__((aligned(16))) double sdelta[PS_CHAINS][(PS_R + 1) * DP];       // row PS_R: negative zeros
     __shared__ __attribute__((aligned(16))) double ctab[PS_CHAINS][2][32 * CR];
