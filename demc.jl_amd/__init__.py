@@ -9,7 +9,7 @@ The directory name has a dot, so import it through the repo-root alias module::
 All computation below the generation loop runs in ``libdemcz_hip.so`` (HIP, gfx950) through the
 C ABI of ``include/demcz.h``; there is no CPU fallback.
 """
-from ._lib import DemczError, build, LIB_PATH, SYMBOLS          # noqa: F401
+from ._lib import DemczError, build, LIB_PATH, SYMBOLS, LAYOUT_SPLIT, LAYOUT_SPLIT_WAVE          # noqa: F401
 from .engine import HipEngine, selftest_draws                   # noqa: F401
 from .targets import MvNormalTarget, IsoQuadTarget, LinRegSSETarget, is_device_target   # noqa: F401
 from .sampler import (MC, DEMCopt, demcopt, demcz_sample, demcz_anneal, tempbaseline,   # noqa: F401

@@ -181,6 +181,7 @@ static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t n
 static bool pc_available(int target_kind, int d, bool full_block);
 static bool split_ml_available(int target_kind, int d, bool full_block, int64_t nobs);
 static bool ps_available(int target_kind, int d);
+static int64_t live_wg_capacity(demcz_handle* h);
 // the draw records on the device no longer match what the next launch will need (or are about to be freed): nothing of
 // the side-stream producer may still be writing them
 static void rec_invalidate(demcz_handle* h)
@@ -357,6 +358,13 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
             h->lanes = DEMCZ_LAYOUT_SPLIT;
             h->split_kind = 4;
             h->split_per_wg = PS_CHAINS;
+            // The library's own choice also asks that the consumers of a LIVE launch all fit the chip at once (one launch
+            // per K-window is where this layout loses to the replicated consumer): MI355X, d = 5: 1024 chains.
+            if (cfg->lanes_per_chain == 0 && (cfg->N + PS_CHAINS - 1) / PS_CHAINS > live_wg_capacity(h)) {
+                h->split_kind = kind;
+                h->split_per_wg = PC_CONSUMER_CHAINS;
+                h->live_wg_cap = -1;
+            }
         } else if (cfg->lanes_per_chain == DEMCZ_LAYOUT_SPLIT) {
             if (!split_ok) {
                 h->err = "demcz_create: the split layout is not built for this target / d / block structure";

@@ -342,10 +342,10 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     int64_t nb = 0;
     unsigned int cnt_total = 0, cnt_first = 0;
 #ifdef DEMCZ_STAMPS
-    unsigned long long sa[6] = {0, 0, 0, 0, 0, 0}, sa_t = __builtin_readcyclecounter(), sa_n = 0, sa_bad = 0;
-#define PS_TICK(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); sa[i] += t_ - sa_t; sa_t = t_; } while (0)
-#else
-#define PS_TICK(i) do { } while (0)
+    // diagnostic build (scripts/ps_stamps.py): shader-clock time of the launch, of the two kinds of LIVE waits, their counts.
+    // Only the waits are bracketed: a stamp drains the wave's outstanding LDS and scalar-memory operations.
+    const unsigned long long sa_start = __builtin_readcyclecounter();
+    unsigned long long sa_reread = 0, sa_ring = 0, sa_n = 0, sa_bad = 0, sa_rings = 0;
 #endif
 
     // ---- front end of a pass (raw slot `slot`): everything about it that does not depend on the chain's state --
@@ -400,6 +400,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     auto reread = [&](bool bad, int gpass) __attribute__((always_inline)) -> bool {
 #ifdef DEMCZ_STAMPS
         ++sa_bad;
+        const unsigned long long sa_t0 = __builtin_readcyclecounter();
 #endif
         const uint32_t i1 = (uint32_t)ixA, i2 = (uint32_t)(ixA >> 32);
         int spins = 0;
@@ -416,6 +417,9 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
                 bad = is_sentinel(za_f) | is_sentinel(zb_f);
             }
         }
+#ifdef DEMCZ_STAMPS
+        sa_reread += __builtin_readcyclecounter() - sa_t0;
+#endif
         wave_lds_handoff();
         write_increment();
         wave_lds_handoff();
@@ -453,11 +457,9 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         for (int j = 0; j < PS_R; ++j)
 #pragma unroll
             for (int p = 0; p < D; ++p) cand[p] = cand[p] + m[j][p];
-        PS_TICK(0);
         // the pass before's history leaves; the next pass's front end
         store_history();
         const bool bad_n = front(slot, qR(1), qR(3), g3, g5, true);
-        PS_TICK(1);
         double lpp;
         if constexpr (TARGET == TARGET_MVNORMAL) {
             double q = 0.0;
@@ -487,7 +489,6 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
 #pragma unroll
             for (int q = 0; q < CR / 2; ++q) reinterpret_cast<double2*>(tnew + lane * CR)[q] = make_double2(row[2 * q], row[2 * q + 1]);
         }
-        PS_TICK(2);
         // all accept tests at once
         unsigned long long mask, chg_a, chg_r;
         {
@@ -524,7 +525,6 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             const double lw = from_lane(lpp, win);
             lp = win ? lw : lp;
         }
-        PS_TICK(3);
         wave_lds_handoff();
         // history rows of the pass: read now, stored during the next pass
         {
@@ -543,10 +543,17 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             if constexpr (LIVE) {
                 // the slot of pub_rows this boundary uses was emptied PS_PUB boundaries ago -- almost always
                 asm volatile("" : "+v"(pub_seen));          // (not looked at before this point: the read has had the whole pass)
+#ifdef DEMCZ_STAMPS
+                const unsigned long long sa_t1 = __builtin_readcyclecounter();
+                if (pub_seen + (unsigned int)PS_PUB <= (unsigned int)nb) ++sa_rings;
+#endif
                 while (pub_seen + (unsigned int)PS_PUB <= (unsigned int)nb) {
                     __builtin_amdgcn_s_sleep(1);
                     pub_seen = __hip_atomic_load(&pub_done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
+#ifdef DEMCZ_STAMPS
+                sa_ring += __builtin_readcyclecounter() - sa_t1;
+#endif
                 if (lane < D) pub_rows[(w * PS_PUB + (int)((unsigned int)nb % PS_PUB)) * D + lane] = v;
                 asm volatile("" ::: "memory");                 // (one wave's LDS operations execute in order)
                 if (lane == 0) __hip_atomic_store(&pub_seq[w], (unsigned int)nb + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -556,7 +563,6 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             if (lane < D && P.snap) P.snap[nb * P.N * D + c + P.N * lane] = v;
             ++nb;
         }
-        PS_TICK(4);
         if constexpr (LIVE) {
             // only now -- this wave's own row is on its way -- may it wait for rows of other waves
             if (__builtin_amdgcn_ballot_w64(bad_n) != 0ull) {
@@ -572,7 +578,6 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         slot = (slot + 1 == PS_SLOTS) ? 0 : slot + 1;
         ixA = ixB;
         ixB = pf_f;
-        PS_TICK(5);
 #ifdef DEMCZ_STAMPS
         ++sa_n;
 #endif
@@ -585,11 +590,9 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     }
     wave_store_counts(P, c, cnt_total, cnt_first);
 #ifdef DEMCZ_STAMPS
-    if (P.stamps && lane == 0 && c < 65536) {      // scripts/ps_stamps.py names the six sums
+    if (P.stamps && lane == 0 && c < 65536) {
         unsigned long long* o = P.stamps + (size_t)c * 16;
-        for (int i = 0; i < 6; ++i) o[8 + i] = sa[i];
-        o[14] = sa_n;
-        o[15] = sa_bad;
+        o[8] = __builtin_readcyclecounter() - sa_start; o[9] = sa_reread; o[10] = sa_ring; o[11] = sa_bad; o[12] = sa_rings; o[14] = sa_n;
     }
 #endif
     leave();

@@ -48,6 +48,10 @@ struct DemczConfig
     stream::Ptr{Cvoid}; lanes_per_chain::Int32; reserved0::Int32
 end
 
+# lanes_per_chain beyond 0 (the library chooses) / 1 / 8 / 16: the producer-consumer split layouts (include/demcz.h)
+const LAYOUT_SPLIT = Int32(100)
+const LAYOUT_SPLIT_WAVE = Int32(164)
+
 struct DemczError <: Exception; code::Int32; msg::String; end
 lasterr(h) = unsafe_string(ccall((:demcz_last_error, libdemcz), Cstring, (Ptr{Cvoid},), h))
 chk(rc, h=C_NULL) = rc == 0 ? nothing : throw(DemczError(rc, lasterr(h)))

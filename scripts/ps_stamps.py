@@ -1,4 +1,4 @@
-"""Where a pass of the wave-per-chain consumer (demcz_kernels_ps.h) spends its time: shader-clock sums written by a
+"""What the in-launch row hand-off costs the wave-per-chain consumer (demcz_kernels_ps.h): shader-clock sums written by a
 diagnostic build (-DDEMCZ_STAMPS, build_ab/stamps.so; never the shipped library).
 usage: python scripts/ps_stamps.py [N] [K] [generations] [M0]   (run on the GPU box; M0: rows of a synthetic initial archive)"""
 import ctypes as C
@@ -41,16 +41,12 @@ rc = lib.demcz_debug_read_stamps(e._h, buf.ctypes.data_as(C.c_void_p), N)
 assert rc == 0, rc
 s = buf.astype(np.float64)
 n = s[:, 14]
-names = ["candidates: state + the node's rows (and whatever the loop's top waits for)",
-         "previous pass's history stores; front end of the next pass: slot wait, increments -> LDS, DMA, node rows <- LDS",
-         "log-density of all nodes, candidates -> LDS", "accept tests, path from the lane mask, new state from the winner's registers",
-         "history values <- LDS, boundary (append hand-off)", "LIVE re-reads, bookkeeping of the passes"]
-print(f"N={N} K={K}: last launch, {n.mean():.0f} passes per chain wave; shader-clock ticks per pass, mean / max over chains")
-tot = 0
-for i, nm in enumerate(names):
-    v = s[:, 8 + i] / n
-    tot += v.mean()
-    print(f"  {v.mean():8.0f} {v.max():8.0f}   {nm}")
-print(f"  {tot:8.0f}            per pass in all")
-print(f"  passes that had to ask again for a row: {100 * (s[:, 15] / n).mean():.2f} %")
+tot, rr, ring, nrr, nring = s[:, 8], s[:, 9], s[:, 10], s[:, 11], s[:, 12]
+print(f"N={N} K={K} M0={M0}: last launch, {n.mean():.0f} passes per chain wave; shader-clock ticks, mean / max over chain waves")
+print(f"  {tot.mean():10.0f} {tot.max():10.0f}   whole launch ({(tot / n).mean():.0f} per pass)")
+print(f"  {rr.mean():10.0f} {rr.max():10.0f}   waiting for rows other waves had not published yet "
+      f"({100 * (nrr / n).mean():.2f} % of passes, {rr.sum() / max(nrr.sum(), 1):.0f} per wait)")
+print(f"  {ring.mean():10.0f} {ring.max():10.0f}   waiting for the publisher to free a slot "
+      f"({100 * (nring / np.maximum(n / 2, 1)).mean():.2f} % of boundaries)")
+print(f"  share of the launch spent in those waits: {100 * ((rr + ring) / tot).mean():.1f} %")
 e.close()
