@@ -116,6 +116,11 @@ struct demcz_handle {
     hipEvent_t prod_done[2] = {nullptr, nullptr};   // records of buffer b are complete
     hipEvent_t prod_gate = nullptr;                 // main stream: the consumer that last read the buffer about to be refilled is done
     bool prod_pending[2] = {false, false};          // buffer b was (or is being) filled on the side stream: wait for prod_done[b]
+    // An event (not owned here) recorded on the compute stream after the most recent window launch, nullptr if there is none:
+    // whoever needs "that launch is done" on another stream -- the R-hat stream, the producer gate of the next launch --
+    // waits for it instead of putting a marker of its own into the stream.  (Every marker between two window launches is
+    // microseconds of an idle GPU: scripts/step_overhead.py.)
+    hipEvent_t after_launch_ev = nullptr;
     // accept mask by ballot: per launch and consumer wave {changed over the launch, changed in its first generation};
     // a ring of launches, newest last (demcz_get_changed_total)
     unsigned int* d_acc = nullptr;
@@ -755,8 +760,12 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
                     HIPCHK(h, hipEventCreateWithFlags(&h->prod_gate, hipEventDisableTiming));
                     for (int b = 0; b < 2; ++b) HIPCHK(h, hipEventCreateWithFlags(&h->prod_done[b], hipEventDisableTiming));
                 }
-                HIPCHK(h, hipEventRecord(h->prod_gate, h->stream));
-                HIPCHK(h, hipStreamWaitEvent(h->prod_stream, h->prod_gate, 0));
+                if (h->after_launch_ev) {
+                    HIPCHK(h, hipStreamWaitEvent(h->prod_stream, h->after_launch_ev, 0));
+                } else {
+                    HIPCHK(h, hipEventRecord(h->prod_gate, h->stream));
+                    HIPCHK(h, hipStreamWaitEvent(h->prod_stream, h->prod_gate, 0));
+                }
                 ps = h->prod_stream;
             } else if (h->prod_pending[bout]) {
                 HIPCHK(h, hipStreamWaitEvent(h->stream, h->prod_done[bout], 0));      // (never two writers of one buffer)
@@ -1422,6 +1431,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         P.live_spin_limit = h->live_spin_limit ? (int32_t)h->live_spin_limit : LIVE_SPIN_LIMIT;
         P.acc_out = h->d_acc ? h->d_acc + (size_t)h->acc_next * (size_t)h->acc_waves * 2 : nullptr;
         rc = launch_window(h, P, live);
+        h->after_launch_ev = nullptr;         // (whatever was recorded before this launch says nothing about it)
         if (rc) return rc;
         if (h->d_acc) {
             h->acc_log.push_back({g, w_end, h->acc_next});
@@ -1457,6 +1467,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     }
     if (timed) {
         HIPCHK(h, hipEventRecord(tev.b, h->stream));
+        h->after_launch_ev = tev.b;
         h->timed.emplace_back(tev.a, tev.b);
         tev.a = tev.b = nullptr;
         h->timed_launches += timed_launches;
@@ -1663,8 +1674,13 @@ static int32_t rhat_enqueue(demcz_handle* h, int64_t g_from, int64_t g_to, doubl
     if (side && !h->comm) {
         if (!h->diag_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->diag_stream, hipStreamNonBlocking));
         if (!h->diag_ev) HIPCHK(h, hipEventCreateWithFlags(&h->diag_ev, hipEventDisableTiming));
-        HIPCHK(h, hipEventRecord(h->diag_ev, h->stream));
-        HIPCHK(h, hipStreamWaitEvent(h->diag_stream, h->diag_ev, 0));
+        if (h->after_launch_ev) {
+            HIPCHK(h, hipStreamWaitEvent(h->diag_stream, h->after_launch_ev, 0));
+        } else {
+            HIPCHK(h, hipEventRecord(h->diag_ev, h->stream));
+            HIPCHK(h, hipStreamWaitEvent(h->diag_stream, h->diag_ev, 0));
+            h->after_launch_ev = h->diag_ev;
+        }
         qs = h->diag_stream;
     }
     int32_t rc = rhat_prepare(h, g_from, g_to, r, true, qs);
@@ -2346,6 +2362,7 @@ extern "C" int32_t demcz_get_kernel_time(demcz_handle* h, int64_t* launches, dou
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     double total = 0.0;
+    h->after_launch_ev = nullptr;         // (may be one of the events destroyed below)
     for (auto& pr : h->timed) {
         float ms = 0.0f;
         HIPCHK(h, hipEventElapsedTime(&ms, pr.first, pr.second));

@@ -231,20 +231,24 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     //      4k..4k+3); g0 / g3 / g5 are the first generations of entries 0, 3 and 5.
     unsigned int segq = 0u;
     int cg = 0, ctb = P.to_boundary;           // where the pass after the last one in the queue starts
+    // (opaque copies: as plain kernel arguments the compiler re-loads them from the argument segment inside the loop when
+    //  scalar registers are short, and the wait for that load is a wait for every LDS read in flight as well)
+    int ngen_s = P.ngen, K_s = P.K;
+    asm volatile("" : "+s"(ngen_s), "+s"(K_s));
     auto seg_make = [&]() __attribute__((always_inline)) -> unsigned int {
-        int n = P.ngen - cg;
+        int n = ngen_s - cg;
         n = (n < 0) ? 0 : n;
         n = (n < PS_R) ? n : PS_R;
         const int R = (ctb < n) ? ctb : n;
         const int B = (R > 0 && ctb - R == 0) ? 1 : 0;
         cg += R;
-        ctb = B ? P.K : ctb - R;
+        ctb = B ? K_s : ctb - R;
         return (unsigned int)(R | (B << 3));
     };
 #pragma unroll
     for (int k = 0; k < 6; ++k) segq |= seg_make() << (4 * k);
     auto qR = [&](int k) __attribute__((always_inline)) -> int { return (int)((segq >> (4 * k)) & 7u); };
-    auto gclamp = [&](int g) __attribute__((always_inline)) { return (g < P.ngen) ? g : P.ngen - 1; };
+    auto gclamp = [&](int g) __attribute__((always_inline)) { return (g < ngen_s) ? g : ngen_s - 1; };
     int g0 = 0, g3 = qR(0) + qR(1) + qR(2), g5 = g3 + qR(3) + qR(4);
     int npass;
     {
@@ -333,6 +337,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         const uint32_t lim_x = hR * hx_span, lim_l = hR * hl_span;      // generations beyond the pass: out of range
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hx_ptr), 0, (int)lim_x, 0x00020000);
         const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hl_ptr), 0, (int)lim_l, 0x00020000);
+        // (tried: non-temporal stores -- 217 -> 238 us per 1000-generation launch)
         __builtin_amdgcn_raw_buffer_store_b64(vv, rx, (int)hx_off, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b64(vv, rl, (int)hl_off, 0, 0);
         hx_ptr += lim_x;
