@@ -8,6 +8,7 @@
 #include "demcz_kernels_pc.h"
 #include "demcz_kernels_lr.h"
 #include "demcz_kernels_ps.h"
+#include "demcz_kernels_pw.h"
 
 #include <rccl/rccl.h>
 
@@ -352,7 +353,8 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
                           : (kind == 3) ? 64 / L : 1;
         const bool split_ok = kind != 0;
         // one wave per chain (demcz_kernels_ps.h): where the replicated consumer is built and a pass's draws fit one DMA
-        const bool ps_ok = kind == 1 && ps_available(cfg->target_kind, d);
+        const bool ps_ok = (kind == 1 || kind == 2) && h->full_block && ps_available(cfg->target_kind, d);
+        const int per_wg_default = h->split_per_wg;
         h->split_kind = 0;
         if (cfg->lanes_per_chain == DEMCZ_LAYOUT_SPLIT_WAVE || (cfg->lanes_per_chain == 0 && ps_ok && cfg->N <= PS_MAX_N && !getenv("DEMCZ_NO_PS"))) {
             // (us per K-window at d=5, one wave per chain / eight replicated lanes: see DESIGN.md, K1g)
@@ -367,7 +369,7 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
             // per K-window is where this layout loses to the replicated consumer): MI355X, d = 5: 1024 chains.
             if (cfg->lanes_per_chain == 0 && (cfg->N + PS_CHAINS - 1) / PS_CHAINS > live_wg_capacity(h)) {
                 h->split_kind = kind;
-                h->split_per_wg = PC_CONSUMER_CHAINS;
+                h->split_per_wg = per_wg_default;
                 h->live_wg_cap = -1;
             }
         } else if (cfg->lanes_per_chain == DEMCZ_LAYOUT_SPLIT) {
@@ -693,7 +695,8 @@ static bool split_ml_available(int target_kind, int d, bool full_block, int64_t 
     return target_kind == DEMCZ_TARGET_LINREG_SSE && d == 10 && lr16_dynamic_lds<10>(nobs) <= ML_MAX_DYNAMIC_LDS;
 }
 
-static bool ps_available(int target_kind, int d) { return target_kind == DEMCZ_TARGET_MVNORMAL && d >= 2 && d <= 5; }
+// one wave per chain: window_kernel_ps (d <= 5: a pass's draws are one DMA) / window_kernel_pw (C4's d = 20)
+static bool ps_available(int target_kind, int d) { return target_kind == DEMCZ_TARGET_MVNORMAL && ((d >= 2 && d <= 5) || d == 20); }
 
 static int pc_roles(int d) { return ((d == 1) ? 1 : (d + 1) / 2) + 2; }
 // doubles of draw record per (generation, chain), and producer lanes per (generation, chain)
@@ -715,6 +718,19 @@ static void launch_ps(const demcz_handle* h, const WindowParams& P, int64_t bloc
     } else {
         if (live) hipLaunchKernelGGL((window_kernel_ps<TARGET, D, true, false>), grid, wgl, 0, h->stream, P);
         else hipLaunchKernelGGL((window_kernel_ps<TARGET, D, false, false>), grid, wg, 0, h->stream, P);
+    }
+}
+
+template <int TARGET, int D>
+static void launch_pw(const demcz_handle* h, const WindowParams& P, int64_t blocks, bool live)
+{
+    const dim3 grid((unsigned)blocks), wg(64 * PS_CHAINS), wgl(64 * (PS_CHAINS + 1));
+    if (P.temperature) {
+        if (live) hipLaunchKernelGGL((window_kernel_pw<TARGET, D, true, true>), grid, wgl, 0, h->stream, P);
+        else hipLaunchKernelGGL((window_kernel_pw<TARGET, D, false, true>), grid, wg, 0, h->stream, P);
+    } else {
+        if (live) hipLaunchKernelGGL((window_kernel_pw<TARGET, D, true, false>), grid, wgl, 0, h->stream, P);
+        else hipLaunchKernelGGL((window_kernel_pw<TARGET, D, false, false>), grid, wg, 0, h->stream, P);
     }
 }
 
@@ -742,7 +758,7 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
     const int64_t blocks = P.consumer_blocks + (units + upw - 1) / upw;
     if (blocks <= 0) return DEMCZ_OK;
     if (h->split_kind == 4) {
-        if (P.ZS != ((P.d <= 2) ? 2 : (P.d <= 4) ? 4 : 8)) return fail(h, DEMCZ_ERR_STATE, "split layout: archive row stride");
+        if (P.ZS != ((P.d <= 2) ? 2 : (P.d <= 4) ? 4 : ((P.d + 7) / 8) * 8)) return fail(h, DEMCZ_ERR_STATE, "split layout: archive row stride");
         const int bin = (P.rec_in == h->d_rec[0]) ? 0 : 1, bout = (P.rec_out == h->d_rec[0]) ? 0 : 1;
         const bool one_launch = !live && P.consumer_blocks > 0;     // a short launch: producer workgroups ride in the consumer's grid
         if (units > 0 && one_launch && h->prod_pending[bout]) {
@@ -782,6 +798,7 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
             case 3: hipLaunchKernelGGL((produce_kernel<3>), pg, pw, dyn, ps, P); break;
             case 4: hipLaunchKernelGGL((produce_kernel<4>), pg, pw, dyn, ps, P); break;
             case 5: hipLaunchKernelGGL((produce_kernel<5>), pg, pw, dyn, ps, P); break;
+            case 20: hipLaunchKernelGGL((produce_kernel<20>), pg, pw, dyn, ps, P); break;
             default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
             }
             HIPCHK(h, hipGetLastError());
@@ -801,6 +818,7 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
             case 3: launch_ps<TARGET_MVNORMAL, 3>(h, P, grid, live); break;
             case 4: launch_ps<TARGET_MVNORMAL, 4>(h, P, grid, live); break;
             case 5: launch_ps<TARGET_MVNORMAL, 5>(h, P, grid, live); break;
+            case 20: launch_pw<TARGET_MVNORMAL, 20>(h, P, grid, live); break;
             default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
             }
         }
@@ -1184,6 +1202,13 @@ static int64_t live_wg_capacity(demcz_handle* h)
         case 3: per_cu = ps_live_blocks_per_cu<3>(); break;
         case 4: per_cu = ps_live_blocks_per_cu<4>(); break;
         case 5: per_cu = ps_live_blocks_per_cu<5>(); break;
+        case 20: {
+            int a = 0, b = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, 20, true, false>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) a = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, 20, true, true>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) b = 0;
+            per_cu = std::min(a, b);
+            break;
+        }
         default: per_cu = 0;
         }
     } else if (h->split_kind == 3) {

@@ -1,0 +1,566 @@
+// demcz_kernels_pw.h -- K1g': the wave-per-chain consumer (demcz_kernels_ps.h) for dimensions whose pass does not fit
+// one DMA instruction and whose node rows do not fit the registers (BASELINE C4's per-GPU shard: MvNormal d = 20).
+//
+// The same scheme: one wavefront per chain, lane n evaluates node n of the tree of accept / reject outcomes of the next
+// R <= 5 generations, every candidate formed by the additions the serial order would have made (a rejected generation
+// adds -0.0), ONE log-density evaluation for all 31 nodes, all accept tests one compare into a lane mask, the path
+// read off the mask -- bit-identical to the serial order.  What differs from the d <= 5 kernel:
+//   * a pass's draws are NDMA = ceil((10 * ceil(d/2) + 3 * (d + 2) [+ 3]) / 64) LDS-DMA instructions (d = 20: three) into
+//     a slot of NDMA KiB; the counted wait counts them;
+//   * increments and history rows take ceil(5 d / 64) and ceil(5 (d + 1) / 64) rounds of lanes;
+//   * a node's rows of increments stay in LDS and are read as they are added (100 doubles would not fit the registers);
+//     the front end of the next pass therefore only forms increments (after the adds, in program order);
+//   * W comes through scalar loads issued inside the log-density every pass (no room to keep 210 doubles), mu from an LDS copy;
+//   * the state travels through the LDS candidate table (one table; the winner's row is copied to row 0) instead of
+//     40 v_readlanes.
+// Everything else -- records, producer half, LIVE hand-off with sentinel and publisher, counted waits -- is the d <= 5
+// kernel's; see there for the reasoning.
+#pragma once
+
+#include "demcz_kernels_ps.h"
+
+#pragma clang fp contract(off)
+
+namespace demcz {
+
+template <int TARGET, int D, bool LIVE, bool TEMPER>
+__global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_kernel_pw(const WindowParams P)
+{
+    static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "split layout: MvNormal / isotropic targets");
+    static_assert(D >= 6 && D <= 24, "d <= 5: window_kernel_ps");
+    constexpr int HW = (D + 1) / 2;                        // 16-byte pieces of an archive row
+    constexpr int ZSC = ((D + 7) / 8) * 8;                 // archive row stride in doubles (demcz_create: ZS)
+    constexpr int DP = ((D + 1) / 2) * 2;                  // increments row in LDS
+    constexpr int CR = ((D + 2) / 2) * 2;                  // candidate row in LDS: D doubles, log-density, pad
+    // pieces of a pass's DMAs: [0, ROWL) archive rows (generation u, first / second row, piece j); [FL0, TL0) the D + 2
+    // record fields, three pieces = six generations each (fields 0..D-1 normals, D log u: this pass; D+1 row indices: the
+    // pass two after it); [TL0, TL0 + 3) temperatures; the rest idle
+    constexpr int ROWL = PS_R * 2 * HW;
+    constexpr int FL0 = ROWL;
+    constexpr int TL0 = FL0 + 3 * (D + 2);
+    constexpr int NDMA = (TL0 + 3 + 63) / 64;
+    constexpr int SLOTB = NDMA * 1024;
+    constexpr int NF = (PS_R * D + 63) / 64;               // rounds of lanes that form increments
+    constexpr int NH = (PS_R * (D + 1) + 63) / 64;         // rounds of lanes that store history
+    constexpr int VMW = NDMA + 4 * NH;                     // vector-memory instructions behind a slot's last DMA when it is waited for
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if constexpr (!LIVE) {
+        if ((int64_t)blockIdx.x >= P.consumer_blocks) {    // short launches: the producer half rides in the grid
+            pc_produce<D>(P, ((int64_t)blockIdx.x - P.consumer_blocks) * PS_CHAINS + w, lane);
+            return;
+        }
+    }
+    __shared__ __attribute__((aligned(16))) unsigned char raw[PS_CHAINS][PS_SLOTS][SLOTB];
+    __shared__ __attribute__((aligned(16))) double sdelta[PS_CHAINS][(PS_R + 1) * DP];       // row PS_R: negative zeros
+    __shared__ __attribute__((aligned(16))) double ctab[PS_CHAINS][32 * CR];                   // row 0: the current state
+    __shared__ __attribute__((aligned(16))) double mul[DP];          // mu, one copy per workgroup
+    __shared__ double pub_rows[LIVE ? PS_CHAINS * PS_PUB * D : 1];
+    __shared__ unsigned int pub_seq[PS_CHAINS], pub_done[PS_CHAINS], pub_exit[PS_CHAINS];
+    for (int e = threadIdx.x; e < D; e += blockDim.x) mul[e] = P.tp.mu[e];
+    if constexpr (LIVE) {
+        if (threadIdx.x < PS_CHAINS) { pub_seq[threadIdx.x] = 0u; pub_done[threadIdx.x] = 0u; pub_exit[threadIdx.x] = 0u; }
+    }
+    __syncthreads();
+    if constexpr (LIVE) {
+        if (w == PS_CHAINS) {       // the publisher (demcz_kernels_ps.h): element e = (chain wave, p), in rounds of 64
+            constexpr int NPL = (PS_CHAINS * D + 63) / 64;
+            unsigned int done[NPL], idle = 0u;
+#pragma unroll
+            for (int t = 0; t < NPL; ++t) done[t] = 0u;
+            while (true) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                bool any = false, allgone = true;
+#pragma unroll
+                for (int t = 0; t < NPL; ++t) {
+                    const int e = lane + 64 * t;
+                    const bool pl = e < PS_CHAINS * D;
+                    const int cw = pl ? e / D : 0, pp = pl ? e % D : 0;
+                    const int64_t cl = (int64_t)blockIdx.x * PS_CHAINS + cw;
+                    const unsigned int seq = __hip_atomic_load(&pub_seq[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const bool ready = pl && seq != done[t];
+                    if (ready) {
+                        const double v = pub_rows[(cw * PS_PUB + (int)(done[t] % PS_PUB)) * D + pp];
+                        if (cl < P.N && P.do_append) live_store(&P.Zw[(P.M_append + (int64_t)done[t] * P.N + cl) * P.ZS + pp], v);
+                        ++done[t];
+                    }
+                    asm volatile("" ::: "memory");
+                    if (ready && pp == 0) __hip_atomic_store(&pub_done[cw], done[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    any |= __builtin_amdgcn_ballot_w64(ready) != 0ull;
+                    const bool gone = !pl || (__hip_atomic_load(&pub_exit[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u &&
+                                              __hip_atomic_load(&pub_seq[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == done[t]);
+                    allgone &= __builtin_amdgcn_ballot_w64(!gone) == 0ull;
+                }
+                if (any) { idle = 0u; continue; }
+                if (allgone) break;
+                if ((++idle & 4095u) == 0u && __hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            return;
+        }
+    }
+    auto leave = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (LIVE) {
+            if (lane == 0) __hip_atomic_store(&pub_exit[w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    const int64_t c = (int64_t)blockIdx.x * PS_CHAINS + w;
+    if (c >= P.N) {
+        wave_store_counts(P, c, 0u, 0u);
+        leave();
+        return;
+    }
+    if constexpr (LIVE) {
+        if (__hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { leave(); return; }
+    }
+    __builtin_amdgcn_s_setprio(3);
+    unsigned char* const raw_w = &raw[w][0][0];
+    double* const sd_w = &sdelta[w][0];
+    double* const ct_w = &ctab[w][0];
+    const unsigned raw_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)raw_w);
+
+    // ---- what this lane is, in each of its parts (demcz_kernels_ps.h) --------------------------------------------
+    const int nn = (lane >= 1 && lane < 32) ? lane : 1;
+    const int lev = 32 - __builtin_clz((unsigned)nn);
+    const double* mrow[PS_R];
+#pragma unroll
+    for (int j = 1; j <= PS_R; ++j) {
+        const bool take = lane != 0 && ((j == lev) || (j < lev && ((nn >> (lev - 1 - j)) & 1)));
+        mrow[j - 1] = sd_w + (take ? j - 1 : PS_R) * DP;
+    }
+    int anc = nn;
+    while (anc > 1 && (anc & 1) == 0) anc >>= 1;
+    anc = (anc == 1) ? 0 : (anc >> 1);
+    const int anc4 = anc * 4;
+    unsigned int need1 = 0u, need0 = 0u;
+#pragma unroll
+    for (int t = 1; t < PS_R; ++t) {
+        if (t < lev) {
+            const unsigned int a = (unsigned int)nn >> (lev - t);
+            if ((nn >> (lev - 1 - t)) & 1) need1 |= 1u << a; else need0 |= 1u << a;
+        }
+    }
+    const bool nodel = lane >= 1 && lane < 32;
+    const int lgo = (FL0 + 3 * D) * 16 + (lev - 1) * 8;
+    [[maybe_unused]] const int tko = TL0 * 16 + (lev - 1) * 8;
+    const int ixo = (FL0 + 3 * (D + 1)) * 16;
+    // increments: element e = lane + 64 t = (generation u, parameter p)
+    bool fl[NF];
+    int fu[NF], fp[NF], zao[NF], zbo[NF], zto[NF];
+    double eps_p[NF];
+#pragma unroll
+    for (int t = 0; t < NF; ++t) {
+        const int e = lane + 64 * t;
+        fl[t] = e < PS_R * D;
+        fu[t] = fl[t] ? e / D : 0;
+        fp[t] = fl[t] ? e % D : 0;
+        zao[t] = ((fu[t] * 2) * HW) * 16 + fp[t] * 8;
+        zbo[t] = ((fu[t] * 2 + 1) * HW) * 16 + fp[t] * 8;
+        zto[t] = (FL0 + 3 * fp[t]) * 16 + fu[t] * 8;
+        eps_p[t] = P.eps[fp[t]];
+    }
+    const double scale = P.gamma / sqrt((double)(2 * D));
+    // DMA sources: piece q = lane + 64 k
+    bool rowl[NDMA], ixl[NDMA];
+    int ru[NDMA], rwhich[NDMA];
+    const unsigned char* sbase[NDMA];
+#pragma unroll
+    for (int k = 0; k < NDMA; ++k) {
+        const int q = lane + 64 * k;
+        rowl[k] = q < ROWL;
+        ru[k] = rowl[k] ? q / (2 * HW) : 0;
+        rwhich[k] = rowl[k] ? (q / HW) % 2 : 0;
+        const int rj = rowl[k] ? q % HW : 0;
+        const bool fieldl = q >= FL0 && q < TL0;
+        const int ff = fieldl ? (q - FL0) / 3 : 0, fj = fieldl ? (q - FL0) % 3 : 0;
+        ixl[k] = fieldl && ff == D + 1;
+        const bool templ = TEMPER && q >= TL0 && q < TL0 + 3;
+        if (rowl[k]) sbase[k] = reinterpret_cast<const unsigned char*>(P.Z) + rj * 16;
+        else if (fieldl) sbase[k] = reinterpret_cast<const unsigned char*>(P.rec_in + ((int64_t)ff * P.N + c) * P.rec_stride) + fj * 16;
+        else if (templ) sbase[k] = reinterpret_cast<const unsigned char*>(P.temperature) + (q - TL0) * 16;
+        else sbase[k] = reinterpret_cast<const unsigned char*>(P.rec_in);
+    }
+    // history: element e = lane + 64 t = (generation j of the pass, p; p == D: log_obj)
+    bool hl[NH];
+    int hp[NH];
+    unsigned int hmask[NH];
+    uint32_t hx_off[NH], hl_off[NH];
+    const bool hist = P.chain != nullptr;
+#pragma unroll
+    for (int t = 0; t < NH; ++t) {
+        const int e = lane + 64 * t;
+        hl[t] = e < PS_R * (D + 1);
+        const int hj = hl[t] ? e / (D + 1) : 0;
+        hp[t] = hl[t] ? e % (D + 1) : 0;
+        hmask[t] = (hj + 1 >= 5) ? 0xffffffffu : ((1u << (1u << (hj + 1))) - 1u);
+        hx_off[t] = (hl[t] && hp[t] < D) ? (uint32_t)((((int64_t)hj * D + hp[t]) * P.N + c) * 8) : 0x7fffff00u;
+        hl_off[t] = (hl[t] && hp[t] == D) ? (uint32_t)(((int64_t)hj * P.N + c) * 8) : 0x7fffff00u;
+    }
+
+    // ---- passes of the launch: the nibble queue of demcz_kernels_ps.h
+    unsigned int segq = 0u;
+    int cg = 0, ctb = P.to_boundary;
+    int ngen_s = P.ngen, K_s = P.K;
+    asm volatile("" : "+s"(ngen_s), "+s"(K_s));
+    auto seg_make = [&]() __attribute__((always_inline)) -> unsigned int {
+        int n = ngen_s - cg;
+        n = (n < 0) ? 0 : n;
+        n = (n < PS_R) ? n : PS_R;
+        const int R = (ctb < n) ? ctb : n;
+        const int B = (R > 0 && ctb - R == 0) ? 1 : 0;
+        cg += R;
+        ctb = B ? K_s : ctb - R;
+        return (unsigned int)(R | (B << 3));
+    };
+#pragma unroll
+    for (int k = 0; k < 6; ++k) segq |= seg_make() << (4 * k);
+    auto qR = [&](int k) __attribute__((always_inline)) -> int { return (int)((segq >> (4 * k)) & 7u); };
+    auto gclamp = [&](int g) __attribute__((always_inline)) { return (g < ngen_s) ? g : ngen_s - 1; };
+    int g0 = 0, g3 = qR(0) + qR(1) + qR(2), g5 = g3 + qR(3) + qR(4);
+    int npass;
+    {
+        const int n1 = (P.to_boundary < P.ngen) ? P.to_boundary : P.ngen, rest = P.ngen - n1;
+        npass = (n1 + PS_R - 1) / PS_R + (rest / P.K) * ((P.K + PS_R - 1) / PS_R) + (rest % P.K + PS_R - 1) / PS_R;
+    }
+
+    // state of the chain: row 0 of the table (a pass starts by reading it; only its log-density is also kept in a register)
+    double lp = P.lpcur[c];
+    {
+        constexpr int NA = (D + 63) / 64;
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            const int p = lane + 64 * t;
+            if (p < D) ct_w[p] = P.Xcur[c + P.N * p];
+        }
+        if (lane == 0) ct_w[D] = lp;
+    }
+    if (lane < DP) sd_w[PS_R * DP + lane] = -0.0;
+
+    const double* rec_ix = P.rec_in + ((int64_t)(D + 1) * P.N + c) * P.rec_stride;
+    const int gq1 = qR(0), gq2 = gq1 + qR(1), gq4 = g3 + qR(3);
+    [[maybe_unused]] uint64_t ixA[NF], ixB[NF];
+#pragma unroll
+    for (int t = 0; t < NF; ++t) {
+        ixA[t] = (uint64_t)__double_as_longlong(rec_ix[gclamp(fu[t])]);
+        ixB[t] = (uint64_t)__double_as_longlong(rec_ix[gclamp(gq1 + fu[t])]);
+    }
+    // the DMAs of a pass (length Rk, first generation gk; gix: first generation of the pass two after it) into a slot;
+    // pack[k]: the row indices the row lanes of DMA k use
+    auto issue = [&](int Rk, int gk, int gix, int slot, const uint64_t (&pack)[NDMA]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) {
+            uint32_t idx = rwhich[k] ? (uint32_t)(pack[k] >> 32) : (uint32_t)pack[k];
+            idx = (ru[k] < Rk) ? idx : 0u;
+            const uint32_t gsel = (uint32_t)(ixl[k] ? gclamp(gix) : gclamp(gk));
+            const uint64_t dyn = rowl[k] ? (uint64_t)idx * (uint64_t)(ZSC * 8) : (uint64_t)(gsel << 3);
+            ps_dma16(sbase[k] + dyn, raw_lds + (unsigned)(slot * SLOTB + k * 1024));
+        }
+    };
+    {
+        uint64_t p0[NDMA], p1[NDMA];
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) {
+            p0[k] = (uint64_t)__double_as_longlong(rec_ix[gclamp(ru[k])]);
+            p1[k] = (uint64_t)__double_as_longlong(rec_ix[gclamp(gq1 + ru[k])]);
+        }
+        // everything loaded so far is in registers, and known to be, before the first DMA (demcz_kernels_ps.h)
+        asm volatile("" :: "v"(lp));
+#pragma unroll
+        for (int t = 0; t < NF; ++t) asm volatile("" :: "v"(eps_p[t]), "v"(ixA[t]), "v"(ixB[t]));
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) asm volatile("" :: "v"(p0[k]), "v"(p1[k]));
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        issue(qR(0), 0, gq2, 0, p0);
+        issue(qR(1), gq1, g3, 1, p1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    // history: descriptors moved on every pass; the rows of a pass leave one pass later
+    const unsigned char* hx_ptr = reinterpret_cast<const unsigned char*>(hist ? P.chain + (int64_t)P.N * D * P.slot_first : P.Z);
+    const unsigned char* hl_ptr = reinterpret_cast<const unsigned char*>(hist ? P.logobj + (int64_t)P.N * P.slot_first : P.Z);
+    const uint32_t hx_span = hist ? (uint32_t)((int64_t)D * P.N * 8) : 0u, hl_span = hist ? (uint32_t)(P.N * 8) : 0u;
+    double hv[NH];
+#pragma unroll
+    for (int t = 0; t < NH; ++t) hv[t] = 0.0;
+    uint32_t hR = 0;
+    auto store_history = [&]() __attribute__((always_inline)) {
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const uint32_t lim_x = hR * hx_span, lim_l = hR * hl_span;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hx_ptr), 0, (int)lim_x, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hl_ptr), 0, (int)lim_l, 0x00020000);
+#pragma unroll
+        for (int t = 0; t < NH; ++t) {
+            const unsigned long long vb = (unsigned long long)__double_as_longlong(hv[t]);
+            const u32x2 vv = {(unsigned int)vb, (unsigned int)(vb >> 32)};
+            __builtin_amdgcn_raw_buffer_store_b64(vv, rx, (int)hx_off[t], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(vv, rl, (int)hl_off[t], 0, 0);
+        }
+        hx_ptr += lim_x;
+        hl_ptr += lim_l;
+    };
+
+    int64_t nb = 0;
+    unsigned int cnt_total = 0, cnt_first = 0;
+
+    // ---- front end of a pass: increments into LDS, the DMAs of the pass two after it; its log u / temperature
+    double logu = 0.0;
+    [[maybe_unused]] double temp = 1.0;
+    // (what a form lane read stays in LDS -- the slot is not refilled before the pass after next -- and is read again by
+    //  whoever needs it later: the LIVE re-reads, the row indices kept for them; registers are short at this d)
+    auto write_increment = [&](const double (&za_f)[NF], const double (&zb_f)[NF], const double (&zt_f)[NF]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < NF; ++t) {
+            const double diff = za_f[t] - zb_f[t];
+            const double t1 = scale * diff;
+            const double t2 = eps_p[t] * zt_f[t];
+            if (fl[t]) sd_w[fu[t] * DP + fp[t]] = t1 + t2;
+        }
+    };
+    auto front = [&](int slot, int Rn, int R2, int g2, int gix, bool counted) __attribute__((always_inline)) -> bool {
+        const unsigned char* rw = raw_w + slot * SLOTB;
+        if (counted) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VMW) : "memory");
+        uint64_t pr[NDMA];
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) pr[k] = *reinterpret_cast<const uint64_t*>(rw + ixo + ru[k] * 8);
+        bool bad = false;
+        double za_f[NF], zb_f[NF], zt_f[NF];
+#pragma unroll
+        for (int t = 0; t < NF; ++t) {
+            za_f[t] = *reinterpret_cast<const double*>(rw + zao[t]);
+            zb_f[t] = *reinterpret_cast<const double*>(rw + zbo[t]);
+            zt_f[t] = *reinterpret_cast<const double*>(rw + zto[t]);
+            if constexpr (LIVE) bad |= fl[t] && fu[t] < Rn && (is_sentinel(za_f[t]) | is_sentinel(zb_f[t]));
+        }
+        logu = *reinterpret_cast<const double*>(rw + lgo);
+        if constexpr (TEMPER) temp = *reinterpret_cast<const double*>(rw + tko);
+        write_increment(za_f, zb_f, zt_f);
+        const int s2 = (slot + 2 >= PS_SLOTS) ? slot + 2 - PS_SLOTS : slot + 2;
+        issue(R2, g2, gix, s2, pr);
+        return bad;
+    };
+    auto reread = [&](int slot, int Rn, int gpass) __attribute__((always_inline)) -> bool {
+        const unsigned char* rw = raw_w + slot * SLOTB;
+        double za_f[NF], zb_f[NF], zt_f[NF];
+#pragma unroll
+        for (int t = 0; t < NF; ++t) {
+            za_f[t] = *reinterpret_cast<const double*>(rw + zao[t]);
+            zb_f[t] = *reinterpret_cast<const double*>(rw + zbo[t]);
+            zt_f[t] = *reinterpret_cast<const double*>(rw + zto[t]);
+        }
+        int spins = 0;
+        while (true) {
+            bool bad = false;
+#pragma unroll
+            for (int t = 0; t < NF; ++t) bad |= fl[t] && fu[t] < Rn && (is_sentinel(za_f[t]) | is_sentinel(zb_f[t]));
+            if (__builtin_amdgcn_ballot_w64(bad) == 0ull) break;       // wave-uniform
+            if (spins > 0) {
+                unsigned row = 0;
+#pragma unroll
+                for (int t = 0; t < NF; ++t) {
+                    if (is_sentinel(za_f[t])) row = (uint32_t)ixA[t];
+                    if (is_sentinel(zb_f[t])) row = (uint32_t)(ixA[t] >> 32);
+                }
+                if (live_poll_abandon(P, spins, bad, row, gpass)) return true;
+                __builtin_amdgcn_s_sleep(1);
+            } else {
+                spins = 1;
+            }
+#pragma unroll
+            for (int t = 0; t < NF; ++t) {
+                if (fl[t] && fu[t] < Rn) {
+                    if (is_sentinel(za_f[t])) za_f[t] = live_load(&P.Z[(int64_t)(uint32_t)ixA[t] * ZSC + fp[t]]);
+                    if (is_sentinel(zb_f[t])) zb_f[t] = live_load(&P.Z[(int64_t)(uint32_t)(ixA[t] >> 32) * ZSC + fp[t]]);
+                }
+            }
+        }
+        wave_lds_handoff();
+        write_increment(za_f, zb_f, zt_f);
+        wave_lds_handoff();
+        return false;
+    };
+
+    {
+        const bool bad0 = front(0, qR(0), qR(2), gq2, gq4, false);
+        if constexpr (LIVE) {
+            if (__builtin_amdgcn_ballot_w64(bad0) != 0ull) {
+                if (reread(0, qR(0), 0)) { leave(); return; }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NF; ++t) { ixA[t] = ixB[t]; ixB[t] = *reinterpret_cast<const uint64_t*>(raw_w + ixo + fu[t] * 8); }
+    }
+    int slot = 1;
+    for (int ip = 0; ip < npass; ++ip) {
+        const int R = qR(0);
+        [[maybe_unused]] unsigned int pub_seen = 0u;
+        if constexpr (LIVE) {
+            if (segq & 8u) pub_seen = __hip_atomic_load(&pub_done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        const double logu_c = logu;
+        [[maybe_unused]] const double temp_c = temp;
+        wave_lds_handoff();
+        // every node's candidate: state + its rows, in order, straight from LDS
+        double cand[D];
+#pragma unroll
+        for (int q = 0; q < CR / 2; ++q) {
+            const double2 t = reinterpret_cast<const double2*>(ct_w)[q];      // (wave-uniform address)
+            if (2 * q < D) cand[2 * q] = t.x;
+            if (2 * q == D) lp = t.x;
+            if (2 * q + 1 < D) cand[2 * q + 1] = t.y;
+            if (2 * q + 1 == D) lp = t.y;
+        }
+#pragma unroll
+        for (int j = 0; j < PS_R; ++j) {
+#pragma unroll
+            for (int q = 0; q < DP / 2; ++q) {
+                const double2 t = reinterpret_cast<const double2*>(mrow[j])[q];
+                cand[2 * q] = cand[2 * q] + t.x;
+                if (2 * q + 1 < D) cand[2 * q + 1] = cand[2 * q + 1] + t.y;
+            }
+            // (one generation's row at a time, its adds done before the next row is asked for: left alone the compiler
+            //  fetches all five rows first -- 200 registers, spilled -- and adds after the front end)
+#pragma unroll
+            for (int p = 0; p < D; ++p) asm volatile("" : "+v"(cand[p]));
+        }
+        wave_lds_handoff();      // (the front end below rewrites the increments)
+        store_history();
+        const bool bad_n = front(slot, qR(1), qR(3), g3, g5, true);
+        // the candidates go to rows 1..31 of the table (row 0 keeps the state the pass started from); the log-density follows
+        if (nodel) {
+#pragma unroll
+            for (int q = 0; q < D / 2; ++q) reinterpret_cast<double2*>(ct_w + lane * CR)[q] = make_double2(cand[2 * q], cand[2 * q + 1]);
+            if constexpr (D & 1) ct_w[lane * CR + D - 1] = cand[D - 1];
+        }
+        // The log-density: target_logp's operation sequence; mu from the workgroup's LDS copy
+        double lpp;
+        {
+            double (&rr)[D] = cand;           // (the candidate itself is in the table by now)
+#pragma unroll
+            for (int q = 0; q < DP / 2; ++q) {
+                const double2 t = reinterpret_cast<const double2*>(mul)[q];
+                rr[2 * q] = cand[2 * q] - t.x;
+                if (2 * q + 1 < D) rr[2 * q + 1] = cand[2 * q + 1] - t.y;
+            }
+            // W through SCALAR loads issued here, every pass: the address is an opaque integer turned into a constant-address-
+            // space pointer (as a loop invariant the compiler would hold all D (D + 1) / 2 entries in registers; through an
+            // opaque generic pointer it fetches them with per-lane flat loads).  A pass waits ~27 scalar-cache round trips
+            // for them.  Measured alternatives at C4's shard, us per K-window: these scalar loads 7.25; W spread over the
+            // lanes' registers and read with v_readlane (420 extra vector instructions) 7.7; an LDS copy read with
+            // wave-uniform addresses 11.9 (the CU's four chain waves run into the LDS bandwidth); the 16-lane kernel 10.2.
+            typedef const __attribute__((address_space(4))) double* cptr;
+            uint64_t wa = (uint64_t)(uintptr_t)P.tp.Wp;
+            asm volatile("" : "+s"(wa));
+            const cptr Wc = (cptr)wa;
+            auto wentry = [&](int e) __attribute__((always_inline)) { return Wc[e]; };
+            double q = 0.0;
+            if constexpr (TARGET == TARGET_MVNORMAL) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double acc = wentry((i * (i + 1)) / 2) * rr[0];
+#pragma unroll
+                    for (int j = 1; j <= i; ++j) acc = fma(wentry((i * (i + 1)) / 2 + j), rr[j], acc);
+                    q = (i == 0) ? acc * acc : fma(acc, acc, q);
+                }
+                lpp = fma(-0.5, q, P.tp.c0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < D; ++i) q = (i == 0) ? rr[i] * rr[i] : fma(rr[i], rr[i], q);
+                lpp = -q;
+            }
+        }
+        if (nodel) ct_w[lane * CR + D] = lpp;
+        unsigned long long mask, chg_a, chg_r;
+        {
+            const unsigned long long lb = (unsigned long long)__double_as_longlong((lane == 0) ? lp : lpp);
+            const unsigned int blo = (unsigned int)__builtin_amdgcn_ds_bpermute(anc4, (int)(unsigned int)lb);
+            const unsigned int bhi = (unsigned int)__builtin_amdgcn_ds_bpermute(anc4, (int)(unsigned int)(lb >> 32));
+            const double lpb = __longlong_as_double((long long)(((unsigned long long)bhi << 32) | blo));
+            const double d0 = lpp - lpb;
+            double dlt = d0;
+            if constexpr (TEMPER) dlt = dlt / temp_c;
+            mask = __builtin_amdgcn_ballot_w64(logu_c < dlt);
+            chg_a = __builtin_amdgcn_fcmp(d0, 0.0, 14 /* UNE */);
+            chg_r = __builtin_amdgcn_fcmp(lpb - lpb, 0.0, 14);
+        }
+        const unsigned int m32 = (unsigned int)mask;
+        const bool onp = nodel && lev <= R && (m32 & need1) == need1 && (m32 & need0) == 0u;
+        const unsigned int path = (unsigned int)__builtin_amdgcn_ballot_w64(onp);
+        const unsigned int accp = path & m32;
+        const unsigned int win = accp ? 31u - (unsigned int)__builtin_clz(accp) : 0u;
+        {
+            const unsigned int chm = (accp & (unsigned int)chg_a) | (path & ~m32 & (unsigned int)chg_r);
+            cnt_total += (unsigned int)__builtin_popcount(chm);
+            if (g0 == 0) cnt_first = (chm >> 1) & 1u;
+        }
+        wave_lds_handoff();
+        // history rows of the pass (read now, stored during the next pass), then the winner's row becomes row 0
+#pragma unroll
+        for (int t = 0; t < NH; ++t) {
+            const unsigned int wa = accp & hmask[t];
+            const unsigned int wj = wa ? 31u - (unsigned int)__builtin_clz(wa) : 0u;
+            hv[t] = ct_w[wj * CR + hp[t]];
+        }
+        hR = (uint32_t)R;
+        wave_lds_handoff();
+        if (win != 0u) {            // wave-uniform
+            if (lane < CR / 2) reinterpret_cast<double2*>(ct_w)[lane] = reinterpret_cast<const double2*>(ct_w + win * CR)[lane];
+        }
+        wave_lds_handoff();
+        // a generation divisible by K ended the pass: runchain!'s append, demcz.jl:88-91
+        if (segq & 8u) {
+            constexpr int NA = (D + 63) / 64;
+#pragma unroll
+            for (int t = 0; t < NA; ++t) {
+                const int p = lane + 64 * t;
+                const double v = ct_w[(p < D) ? p : 0];
+                if constexpr (LIVE) {
+                    if (t == 0) {
+                        asm volatile("" : "+v"(pub_seen));
+                        while (pub_seen + (unsigned int)PS_PUB <= (unsigned int)nb) {
+                            __builtin_amdgcn_s_sleep(1);
+                            pub_seen = __hip_atomic_load(&pub_done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                    if (p < D) pub_rows[(w * PS_PUB + (int)((unsigned int)nb % PS_PUB)) * D + p] = v;
+                } else {
+                    if (p < D && P.do_append) P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p] = v;
+                }
+                if (p < D && P.snap) P.snap[nb * P.N * D + c + P.N * p] = v;
+            }
+            if constexpr (LIVE) {
+                asm volatile("" ::: "memory");
+                if (lane == 0) __hip_atomic_store(&pub_seq[w], (unsigned int)nb + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            ++nb;
+        }
+        if constexpr (LIVE) {
+            if (__builtin_amdgcn_ballot_w64(bad_n) != 0ull) {
+                if (reread(slot, qR(1), g0 + R)) { leave(); return; }
+            }
+        }
+        wave_lds_handoff();
+        g0 += R;
+        g3 += qR(3);
+        g5 += qR(5);
+        segq = (segq >> 4) | (seg_make() << 20);
+#pragma unroll
+        for (int t = 0; t < NF; ++t) { ixA[t] = ixB[t]; ixB[t] = *reinterpret_cast<const uint64_t*>(raw_w + slot * SLOTB + ixo + fu[t] * 8); }
+        slot = (slot + 1 == PS_SLOTS) ? 0 : slot + 1;
+    }
+    store_history();
+    {
+        constexpr int NA = (D + 63) / 64;
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            const int p = lane + 64 * t;
+            const double v = ct_w[(p < D) ? p : 0];
+            if (p < D) P.Xcur[c + P.N * p] = v;
+        }
+        if (lane == 0) P.lpcur[c] = ct_w[D];           // (row 0, not the register: that one is the last pass's starting value)
+    }
+    wave_store_counts(P, c, cnt_total, cnt_first);
+    leave();
+}
+
+}  // namespace demcz

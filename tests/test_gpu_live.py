@@ -22,12 +22,13 @@ def _engine(demc, w, N, d, K, G, seed, lanes=0):
     return e
 
 
-@pytest.mark.parametrize("layout", [SPLIT, SPLIT_WAVE])
+@pytest.mark.parametrize("layout,d", [(SPLIT, 5), (SPLIT_WAVE, 5), (SPLIT, 20), (SPLIT_WAVE, 20)])
 @pytest.mark.parametrize("K", [1, 3])
-def test_forced_handoff_timeout_is_redone_bit_exact(demc, oracle, K, layout):
+def test_forced_handoff_timeout_is_redone_bit_exact(demc, oracle, K, layout, d):
     """demcz_run + a synchronising call: poll limit 1 makes a wave give up at its first wait (K = 1: every
-    generation draws from rows appended one generation earlier, so there are waits at once)."""
-    N, d, G, seed = 512, 5, 120, 41
+    generation draws from rows appended one generation earlier, so there are waits at once).  Every LIVE consumer:
+    eight replicated lanes / one wave per chain at d = 5, sixteen cooperating lanes / one wave per chain at d = 20."""
+    N, G, seed = 512, 120, 41
     w = demc.workloads.mvnormal_problem(d, N)
     e = _engine(demc, w, N, d, K, G, seed, layout)
     assert e.info()["lanes_per_chain"] == layout
@@ -146,7 +147,8 @@ def test_sharded_scatter_kernels_for_R_ranks(demc, R, cnt, batched):
 
 @pytest.mark.parametrize("kind,d,N,blocks,lanes", [
     ("mvn", 5, 100, None, 0), ("mvn", 5, 100, None, SPLIT), ("mvn", 3, 37, None, SPLIT_WAVE), ("mvn-T", 5, 100, None, SPLIT_WAVE),
-    ("mvn-T", 4, 50, None, SPLIT), ("mvn", 5, 100, None, 8), ("mvn", 5, 100, None, 1), ("mvn", 20, 40, None, 0), ("mvn", 20, 40, None, 16),
+    ("mvn-T", 4, 50, None, SPLIT), ("mvn-T", 20, 40, None, SPLIT_WAVE), ("mvn-T", 20, 40, None, SPLIT), ("mvn", 20, 40, None, SPLIT),
+    ("mvn", 5, 100, None, 8), ("mvn", 5, 100, None, 1), ("mvn", 20, 40, None, 0), ("mvn", 20, 40, None, 16),
     ("mvn", 6, 50, [[0], [1, 2], [5, 3, 4]], 0), ("mvn", 6, 50, [[0], [1, 2], [5, 3, 4]], 8), ("mvn", 6, 50, [[0], [1, 2], [5, 3, 4]], 1),
     ("mvn", 7, 30, None, 1), ("linreg", 10, 70, None, 0), ("linreg", 10, 70, None, 16), ("iso", 10, 33, None, 0)])
 def test_ballot_accept_counts_equal_history_counts(demc, oracle, kind, d, N, blocks, lanes):
