@@ -66,14 +66,16 @@ def test_lag_on_gpu_equals_oracle_schedule(E, lanes):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("d", [5, 20])
 @pytest.mark.parametrize("E", [1, 2, 3])
-def test_lag_rccl_side_stream_single_rank(E):
+def test_lag_rccl_side_stream_single_rank(E, d):
     """demcz_comm_init(nranks=1) + lag: snapshots -> batched ncclAllGather on the side stream ->
-    append_batch_kernel -> event wait before the rows become visible; split calls included."""
-    N, d, G, K = 128, 5, 97, 10
+    append_batch_kernel -> event wait before the rows become visible; split calls included.  (d = 5 and d = 20: the
+    boundary snapshots of both wave-per-chain consumers.)"""
+    N, G, K = 128, 97, 10
     w = demc.workloads.mvnormal_problem(d, N)
     M0 = w["Zinit"].shape[0]
-    ref, Zref = run(OracleEngine, HOST1, E, G=G, N=N, seed=3)
+    ref, Zref = run(OracleEngine, HOST1, E, G=G, N=N, d=d, seed=3)
     e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * 10, Gcap=G, blockindex=[range(d)], eps_scale=w["eps_scale"], seed=3, target=w["target"])
     e.comm_init(e.comm_unique_id(), 1, 0)
     e.set_append_lag(E)
