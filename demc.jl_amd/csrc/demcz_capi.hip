@@ -499,6 +499,7 @@ static int32_t ensure_scratch(demcz_handle* h, int64_t n)
     if (n <= h->scratch_cap) return DEMCZ_OK;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->diag_stream) HIPCHK(h, hipStreamSynchronize(h->diag_stream));      // a check may still be reading the old buffer
+    if (h->prod_stream) HIPCHK(h, hipStreamSynchronize(h->prod_stream));      // (the checks of a wave-per-chain handle run there)
     if (h->d_scratch) HIPCHK(h, hipFree(h->d_scratch));
     h->d_scratch = nullptr; h->scratch_cap = 0;
     HIPCHK(h, hipMalloc((void**)&h->d_scratch, (size_t)n * sizeof(double)));
@@ -1124,6 +1125,7 @@ static int32_t live_rollback(demcz_handle* h, std::vector<demcz_handle::RunCall>
     const int d = h->cfg.d;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->diag_stream) HIPCHK(h, hipStreamSynchronize(h->diag_stream));
+    if (h->prod_stream) HIPCHK(h, hipStreamSynchronize(h->prod_stream));
     HIPCHK(h, hipMemcpyAsync(h->dX, h->d_safe_X, (size_t)N * d * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->dlp, h->d_safe_lp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     if (h->M_app > h->safe_M_app) {
@@ -1696,7 +1698,21 @@ static int32_t rhat_enqueue(demcz_handle* h, int64_t g_from, int64_t g_to, doubl
 {
     RhatPlan r;
     hipStream_t qs = h->stream;
-    if (side && !h->comm) {
+    // Monitoring checks run beside the next slab.  Where the handle already has a side stream -- the producer stream of the
+    // wave-per-chain layout -- they go there, behind the producer kernel: a third active queue cost 10-15 us per
+    // 1000-generation slab (the consumer of the next slab started that much later; scripts/step_overhead.py).
+    static const bool own_env = getenv("DEMCZ_RHAT_OWN_STREAM") != nullptr;
+    if (side && !h->comm && !own_env && h->prod_stream) {
+        if (!h->diag_ev) HIPCHK(h, hipEventCreateWithFlags(&h->diag_ev, hipEventDisableTiming));
+        if (h->after_launch_ev) {
+            HIPCHK(h, hipStreamWaitEvent(h->prod_stream, h->after_launch_ev, 0));
+        } else {
+            HIPCHK(h, hipEventRecord(h->diag_ev, h->stream));
+            HIPCHK(h, hipStreamWaitEvent(h->prod_stream, h->diag_ev, 0));
+            h->after_launch_ev = h->diag_ev;
+        }
+        qs = h->prod_stream;
+    } else if (side && !h->comm) {
         if (!h->diag_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->diag_stream, hipStreamNonBlocking));
         if (!h->diag_ev) HIPCHK(h, hipEventCreateWithFlags(&h->diag_ev, hipEventDisableTiming));
         if (h->after_launch_ev) {
@@ -2294,6 +2310,7 @@ static int32_t run_checked_body(demcz_handle* h, int64_t g_from, int64_t g_to, d
     }
     if (rc == DEMCZ_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: synchronise failed");
     if (rc == DEMCZ_OK && h->diag_stream && hipStreamSynchronize(h->diag_stream) != hipSuccess) rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: synchronise failed");
+    if (rc == DEMCZ_OK && h->prod_stream && hipStreamSynchronize(h->prod_stream) != hipSuccess) rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: synchronise failed");
     if (rc == DEMCZ_OK) {
         for (int32_t i = 0; i < checks; ++i)
             if (rhat_max && i < n_max) rhat_max[i] = max_of(pinned + (size_t)i * d);
