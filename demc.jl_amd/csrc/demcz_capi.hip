@@ -1513,6 +1513,7 @@ extern "C" int32_t demcz_synchronize(demcz_handle* h)
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    if (h->prod_stream) HIPCHK(h, hipStreamSynchronize(h->prod_stream));      // (the next launch's draws, monitoring checks)
     return live_verify(h);
 }
 
