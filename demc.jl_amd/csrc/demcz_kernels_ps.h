@@ -22,6 +22,12 @@
 // (lanes with nothing to store point out of range): the count of vector-memory operations between a DMA and its
 // wait is the same on every path.
 //
+// The loop is a software pipeline over passes: the state-independent front end of pass r+1 (slot wait, increments into
+// LDS, the DMA of pass r+3, each node's rows back into registers) sits inside pass r between the candidate adds and the
+// log-density; the new state is read straight out of the winning lane's registers (v_readlane; lane 0 shadows the
+// starting state); the pass's history values are read from the LDS candidate table at its end and stored during the
+// next pass.  Measured steps and what was tried and dropped: DESIGN.md section 4, K1g.
+//
 // LIVE launches (demcz_kernels_rec.h): as in the replicated consumer the first read of a row takes the cached path,
 // a sentinel is asked for again with sc1 loads, and appended rows go through LDS to a publisher wave (one per
 // workgroup of PS_CHAINS chain waves).
@@ -37,7 +43,8 @@ constexpr int PS_CHAINS = 4;     // chain waves per workgroup
 constexpr int PS_R = 5;          // generations per pass = depth of the tree of outcomes (2^5 - 1 = 31 nodes)
 constexpr int PS_PUB = 4;        // boundaries' rows a chain wave may have waiting for the publisher
 constexpr int PS_SLOTS = 3;      // ring of raw slots: the pass being worked on + two in flight
-constexpr int PS_MAX_N = 2048;   // beyond ~2 waves per SIMD the replicated consumer (8 chains per wave) is the faster one
+constexpr int PS_MAX_N = 2048;   // beyond ~2 waves per SIMD the replicated consumer (8 chains per wave) is the faster one; the library's
+                                 // own choice also asks that a LIVE launch of this layout fits the chip (demcz_create): 1024 on MI355X
 
 // one 16-byte piece per lane from a per-lane address into LDS at (wave-uniform) lds_dst + 16 * lane
 __device__ __forceinline__ void ps_dma16(const void* gsrc, unsigned lds_dst)
