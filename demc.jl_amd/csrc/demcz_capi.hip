@@ -480,6 +480,10 @@ extern "C" int32_t demcz_destroy(demcz_handle* h)
     if (!h) return DEMCZ_OK;
     (void)hipSetDevice(h->cfg.device_id);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    // (side streams: a producer kernel for a launch that never came, monitoring checks, a batched exchange)
+    if (h->prod_stream) (void)hipStreamSynchronize(h->prod_stream);
+    if (h->diag_stream) (void)hipStreamSynchronize(h->diag_stream);
+    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
     live_release(h);
     free_all(h);
     delete h;
