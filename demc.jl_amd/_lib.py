@@ -20,7 +20,7 @@ LIB_PATH = Path(os.environ["DEMCZ_LIB"]) if os.environ.get("DEMCZ_LIB") else PKG
 ABI_VERSION = 1
 # demcz_config.lanes_per_chain beyond 0 / 1 / 8 / 16 (include/demcz.h)
 LAYOUT_SPLIT = 100          # producer / consumer split, eight replicated (d <= 10) or sixteen cooperating lanes per chain
-LAYOUT_SPLIT_WAVE = 164     # the split with one wavefront per chain, five generations per pass (MvNormal, 2 <= d <= 5)
+LAYOUT_SPLIT_WAVE = 164     # the split with one wavefront per chain, five generations per pass (MvNormal, d = 2..5, 8, 10, 20)
 
 TARGET_MVNORMAL, TARGET_ISO_QUAD, TARGET_LINREG_SSE, TARGET_HOST_CALLBACK = 0, 1, 2, 3
 OK, ERR_INVALID_ARGUMENT, ERR_HIP, ERR_CAPACITY, ERR_STATE, ERR_NO_DEVICE = range(6)

@@ -701,7 +701,7 @@ static bool split_ml_available(int target_kind, int d, bool full_block, int64_t 
 }
 
 // one wave per chain: window_kernel_ps (d <= 5: a pass's draws are one DMA) / window_kernel_pw (C4's d = 20)
-static bool ps_available(int target_kind, int d) { return target_kind == DEMCZ_TARGET_MVNORMAL && ((d >= 2 && d <= 5) || d == 20); }
+static bool ps_available(int target_kind, int d) { return target_kind == DEMCZ_TARGET_MVNORMAL && ((d >= 2 && d <= 5) || d == 8 || d == 10 || d == 20); }
 
 static int pc_roles(int d) { return ((d == 1) ? 1 : (d + 1) / 2) + 2; }
 // doubles of draw record per (generation, chain), and producer lanes per (generation, chain)
@@ -803,6 +803,8 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
             case 3: hipLaunchKernelGGL((produce_kernel<3>), pg, pw, dyn, ps, P); break;
             case 4: hipLaunchKernelGGL((produce_kernel<4>), pg, pw, dyn, ps, P); break;
             case 5: hipLaunchKernelGGL((produce_kernel<5>), pg, pw, dyn, ps, P); break;
+            case 8: hipLaunchKernelGGL((produce_kernel<8>), pg, pw, dyn, ps, P); break;
+            case 10: hipLaunchKernelGGL((produce_kernel<10>), pg, pw, dyn, ps, P); break;
             case 20: hipLaunchKernelGGL((produce_kernel<20>), pg, pw, dyn, ps, P); break;
             default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
             }
@@ -823,6 +825,8 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
             case 3: launch_ps<TARGET_MVNORMAL, 3>(h, P, grid, live); break;
             case 4: launch_ps<TARGET_MVNORMAL, 4>(h, P, grid, live); break;
             case 5: launch_ps<TARGET_MVNORMAL, 5>(h, P, grid, live); break;
+            case 8: launch_pw<TARGET_MVNORMAL, 8>(h, P, grid, live); break;
+            case 10: launch_pw<TARGET_MVNORMAL, 10>(h, P, grid, live); break;
             case 20: launch_pw<TARGET_MVNORMAL, 20>(h, P, grid, live); break;
             default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
             }
@@ -1198,6 +1202,15 @@ static int ps_live_blocks_per_cu()
     return std::min(a, b);
 }
 
+template <int D>
+static int pw_live_blocks_per_cu()
+{
+    int a = 0, b = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, D, true, false>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) a = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, D, true, true>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) b = 0;
+    return std::min(a, b);
+}
+
 static int64_t live_wg_capacity(demcz_handle* h)
 {
     if (h->live_wg_cap >= 0) return h->live_wg_cap;
@@ -1208,13 +1221,9 @@ static int64_t live_wg_capacity(demcz_handle* h)
         case 3: per_cu = ps_live_blocks_per_cu<3>(); break;
         case 4: per_cu = ps_live_blocks_per_cu<4>(); break;
         case 5: per_cu = ps_live_blocks_per_cu<5>(); break;
-        case 20: {
-            int a = 0, b = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, 20, true, false>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) a = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, 20, true, true>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) b = 0;
-            per_cu = std::min(a, b);
-            break;
-        }
+        case 8: per_cu = pw_live_blocks_per_cu<8>(); break;
+        case 10: per_cu = pw_live_blocks_per_cu<10>(); break;
+        case 20: per_cu = pw_live_blocks_per_cu<20>(); break;
         default: per_cu = 0;
         }
     } else if (h->split_kind == 3) {

@@ -90,7 +90,7 @@ typedef struct demcz_config {
                                      lanes run the chains, and on one GPU a launch runs through many
                                      K boundaries (small N); DEMCZ_LAYOUT_SPLIT_WAVE = the same with
                                      one wavefront per chain that resolves five generations per pass
-                                     (smallest N; MvNormal, 2 <= d <= 5).  Results are bit-identical. */
+                                     (smallest N; MvNormal, d = 2..5, 8, 10, 20).  Results are bit-identical. */
     int32_t reserved0;
 } demcz_config;
 

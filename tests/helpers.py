@@ -25,5 +25,5 @@ SPLIT, SPLIT_WAVE = 100, 164       # DEMCZ_LAYOUT_SPLIT, DEMCZ_LAYOUT_SPLIT_WAVE
 
 def auto_split_layout(d, N):
     """What lanes_per_chain = 0 selects where a split layout is built (MvNormal, full block): one wave per chain for the
-    smallest populations of 2 <= d <= 5 (as many chains as a LIVE launch of it holds: 1024 on MI355X), the replicated / cooperating consumers otherwise."""
-    return SPLIT_WAVE if ((2 <= d <= 5 or d == 20) and N <= 1024) else SPLIT
+    smallest populations of d in 2..5, 8, 10, 20 (as many chains as a LIVE launch of it holds: 1024 on MI355X), the replicated / cooperating consumers otherwise."""
+    return SPLIT_WAVE if ((2 <= d <= 5 or d in (8, 10, 20)) and N <= 1024) else SPLIT

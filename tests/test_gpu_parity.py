@@ -33,7 +33,7 @@ def test_mvnormal_full_block_bit_exact(demc, oracle, N, d, G, lanes):
         if d == 7:
             pytest.skip("no multi-lane build for d=7")
         lanes = 16 if d == 20 else 8
-    if (lanes == SPLIT and d == 7) or (lanes == SPLIT_WAVE and not (2 <= d <= 5 or d == 20)):
+    if (lanes == SPLIT and d == 7) or (lanes == SPLIT_WAVE and not (2 <= d <= 5 or d in (8, 10, 20))):
         pytest.skip("split layout not built for this d")
     w = demc.workloads.mvnormal_problem(d, N)
     seed = 99 + N
