@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("d,N,K,tempered,lag", [(5, 1024, 10, False, 0), (5, 1000, 7, True, 0), (2, 513, 3, True, 0), (20, 1024, 10, False, 0),
-                                                (20, 600, 7, True, 0), (5, 1024, 10, False, 3), (20, 1024, 10, False, 2)])
+                                                (20, 600, 7, True, 0), (5, 1024, 10, False, 3), (20, 1024, 10, False, 2), (8, 1024, 10, False, 0),
+                                                (10, 700, 7, True, 0), (10, 1024, 10, False, 2)])
 def test_wave_per_chain_equals_one_lane_kernel_over_many_passes(demc, d, N, K, tempered, lag):
     G = 1500
     w = demc.workloads.mvnormal_problem(d, N)
