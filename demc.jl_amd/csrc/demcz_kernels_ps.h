@@ -42,7 +42,11 @@ namespace demcz {
 constexpr int PS_CHAINS = 4;     // chain waves per workgroup
 constexpr int PS_R = 5;          // generations per pass = depth of the tree of outcomes (2^5 - 1 = 31 nodes)
 constexpr int PS_PUB = 4;        // boundaries' rows a chain wave may have waiting for the publisher
-constexpr int PS_SLOTS = 3;      // ring of raw slots: the pass being worked on + two in flight
+#ifndef PS_AHEAD_N
+#define PS_AHEAD_N 2
+#endif
+constexpr int PS_AHEAD = PS_AHEAD_N;        // a pass's DMA is issued this many passes before its slot is consumed
+constexpr int PS_SLOTS = PS_AHEAD + 1;      // ring of raw slots: the one being consumed + those in flight
 constexpr int PS_MAX_N = 2048;   // beyond ~2 waves per SIMD the replicated consumer (8 chains per wave) is the faster one; the library's
                                  // own choice also asks that a LIVE launch of this layout fits the chip (demcz_create): 1024 on MI355X
 
@@ -252,11 +256,14 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         ctb = B ? K_s : ctb - R;
         return (unsigned int)(R | (B << 3));
     };
+    constexpr int QN = 2 + 2 * PS_AHEAD;           // entries 0 .. 1 + 2 PS_AHEAD
+    static_assert(QN <= 8, "the queue is one 32-bit word");
 #pragma unroll
-    for (int k = 0; k < 6; ++k) segq |= seg_make() << (4 * k);
+    for (int k = 0; k < QN; ++k) segq |= seg_make() << (4 * k);
     auto qR = [&](int k) __attribute__((always_inline)) -> int { return (int)((segq >> (4 * k)) & 7u); };
     auto gclamp = [&](int g) __attribute__((always_inline)) { return (g < ngen_s) ? g : ngen_s - 1; };
-    int g0 = 0, g3 = qR(0) + qR(1) + qR(2), g5 = g3 + qR(3) + qR(4);
+    auto gsum = [&](int k) __attribute__((always_inline)) { int g = 0; for (int i = 0; i < k; ++i) g += qR(i); return g; };   // first generation of entry k
+    int g0 = 0, g3 = gsum(1 + PS_AHEAD), g5 = gsum(1 + 2 * PS_AHEAD);       // (named for PS_AHEAD = 2: entries 3 and 5)
     int npass;
     {
         const int n1 = (P.to_boundary < P.ngen) ? P.to_boundary : P.ngen, rest = P.ngen - n1;
@@ -279,9 +286,11 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
 
     // row indices: of this pass and the next (form lanes keep theirs for the LIVE re-reads), by ordinary loads once
     const double* rec_ix = P.rec_in + ((int64_t)(D + 1) * P.N + c) * P.rec_stride;
-    const int gq1 = qR(0), gq2 = gq1 + qR(1), gq4 = g3 + qR(3);           // first generations of entries 1, 2, 4
-    [[maybe_unused]] uint64_t ixA = (uint64_t)__double_as_longlong(rec_ix[gclamp(fu)]);
-    [[maybe_unused]] uint64_t ixB = (uint64_t)__double_as_longlong(rec_ix[gclamp(gq1 + fu)]);
+    // (form lanes keep the row indices of the passes in flight for the LIVE re-reads: ixq[0] = those of the pass whose
+    //  slot is consumed next)
+    [[maybe_unused]] uint64_t ixq[PS_AHEAD];
+#pragma unroll
+    for (int k = 0; k < PS_AHEAD; ++k) ixq[k] = (uint64_t)__double_as_longlong(rec_ix[gclamp(gsum(k) + fu)]);
     // The DMA of a pass (length Rk, first generation gk) into a slot; `pack`: the row indices its row lanes use; gix: the
     // first generation of the pass two after it, whose row indices come with it.
     auto issue = [&](int Rk, int gk, int gix, int slot, uint64_t pack) __attribute__((always_inline)) {
@@ -292,8 +301,9 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         ps_dma16(sbase + dyn, raw_lds + (unsigned)slot * 1024u);
     };
     {
-        const uint64_t p0 = (uint64_t)__double_as_longlong(rec_ix[gclamp(ru)]);
-        const uint64_t p1 = (uint64_t)__double_as_longlong(rec_ix[gclamp(gq1 + ru)]);
+        uint64_t pp[PS_AHEAD];
+#pragma unroll
+        for (int k = 0; k < PS_AHEAD; ++k) pp[k] = (uint64_t)__double_as_longlong(rec_ix[gclamp(gsum(k) + ru)]);
         // Everything loaded so far is in registers, and the compiler knows it (each value is an operand of an empty
         // statement), before the first DMA: a wait of the compiler's own for one of these, placed inside the loop,
         // would wait for the DMAs in flight as well -- every pass.  (The W entries stay in vector registers: as scalars
@@ -305,10 +315,12 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             for (int i = 0; i < D * (D + 1) / 2; ++i) asm volatile("" : "+v"(Wc[i]));
         }
         asm volatile("" : "+v"(c0v));
-        asm volatile("" :: "v"(lp), "v"(eps_p), "v"(ixA), "v"(ixB), "v"(p0), "v"(p1));
+        asm volatile("" :: "v"(lp), "v"(eps_p));
+#pragma unroll
+        for (int k = 0; k < PS_AHEAD; ++k) asm volatile("" :: "v"(ixq[k]), "v"(pp[k]));
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        issue(qR(0), 0, gq2, 0, p0);
-        issue(qR(1), gq1, g3, 1, p1);
+#pragma unroll
+        for (int k = 0; k < PS_AHEAD; ++k) issue(qR(k), gsum(k), gsum(k + PS_AHEAD), k, pp[k]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     auto uniform = [&](double v) __attribute__((always_inline)) {          // a wave-uniform double as a scalar value
@@ -390,7 +402,8 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         const unsigned char* rw = raw_w + slot * 1024;
         // behind this slot's DMA in program order: the DMA of the pass after it and two passes' history stores (two
         // instructions each) -- it has landed when at most those five are outstanding
-        if (counted) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        // (PS_AHEAD - 1 whole passes -- two history stores and a DMA each -- and this pass's two stores are behind it)
+        if (counted) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * PS_AHEAD - 1) : "memory");
         za_f = *reinterpret_cast<const double*>(rw + zao);
         zb_f = *reinterpret_cast<const double*>(rw + zbo);
         zt_f = *reinterpret_cast<const double*>(rw + zto);
@@ -401,7 +414,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         bool bad = false;
         if constexpr (LIVE) bad = fl && fu < Rn && (is_sentinel(za_f) | is_sentinel(zb_f));
         write_increment();
-        const int s2 = (slot + 2 >= PS_SLOTS) ? slot + 2 - PS_SLOTS : slot + 2;
+        const int s2 = (slot + PS_AHEAD >= PS_SLOTS) ? slot + PS_AHEAD - PS_SLOTS : slot + PS_AHEAD;
         issue(R2, g2, gix, s2, pr);
         wave_lds_handoff();
         load_rows();
@@ -414,7 +427,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         ++sa_bad;
         const unsigned long long sa_t0 = __builtin_readcyclecounter();
 #endif
-        const uint32_t i1 = (uint32_t)ixA, i2 = (uint32_t)(ixA >> 32);
+        const uint32_t i1 = (uint32_t)ixq[0], i2 = (uint32_t)(ixq[0] >> 32);
         int spins = 0;
         while (__builtin_amdgcn_ballot_w64(bad) != 0ull) {       // wave-uniform
             if (spins > 0) {
@@ -442,14 +455,15 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     {
         // the first pass's front end, on its own; at the start of a launch every row it may draw is published
         // (slot 0; the DMA it issues is the third pass's)
-        const bool bad0 = front(0, qR(0), qR(2), gq2, gq4, false);
+        const bool bad0 = front(0, qR(0), qR(PS_AHEAD), gsum(PS_AHEAD), gsum(2 * PS_AHEAD), false);
         if constexpr (LIVE) {
             if (__builtin_amdgcn_ballot_w64(bad0) != 0ull) {
                 if (reread(bad0, 0)) { leave(); return; }
             }
         }
-        ixA = ixB;
-        ixB = pf_f;
+#pragma unroll
+        for (int k = 0; k + 1 < PS_AHEAD; ++k) ixq[k] = ixq[k + 1];
+        ixq[PS_AHEAD - 1] = pf_f;
     }
     int slot = 1;                     // the raw slot the next front end consumes
     for (int ip = 0; ip < npass; ++ip) {
@@ -471,7 +485,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             for (int p = 0; p < D; ++p) cand[p] = cand[p] + m[j][p];
         // the pass before's history leaves; the next pass's front end
         store_history();
-        const bool bad_n = front(slot, qR(1), qR(3), g3, g5, true);
+        const bool bad_n = front(slot, qR(1), qR(1 + PS_AHEAD), g3, g5, true);
         double lpp;
         if constexpr (TARGET == TARGET_MVNORMAL) {
             double q = 0.0;
@@ -584,12 +598,13 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         wave_lds_handoff();      // sdelta and the other candidate table are rewritten by the next pass
         // the queue moves on
         g0 += R;
-        g3 += qR(3);
-        g5 += qR(5);
-        segq = (segq >> 4) | (seg_make() << 20);
+        g3 += qR(1 + PS_AHEAD);
+        g5 += qR(1 + 2 * PS_AHEAD);
+        segq = (segq >> 4) | (seg_make() << (4 * (QN - 1)));
         slot = (slot + 1 == PS_SLOTS) ? 0 : slot + 1;
-        ixA = ixB;
-        ixB = pf_f;
+#pragma unroll
+        for (int k = 0; k + 1 < PS_AHEAD; ++k) ixq[k] = ixq[k + 1];
+        ixq[PS_AHEAD - 1] = pf_f;
 #ifdef DEMCZ_STAMPS
         ++sa_n;
 #endif
