@@ -356,8 +356,9 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         const bool ps_ok = (kind == 1 || kind == 2) && h->full_block && ps_available(cfg->target_kind, d);
         const int per_wg_default = h->split_per_wg;
         h->split_kind = 0;
-        if (cfg->lanes_per_chain == DEMCZ_LAYOUT_SPLIT_WAVE || (cfg->lanes_per_chain == 0 && ps_ok && cfg->N <= PS_MAX_N && !getenv("DEMCZ_NO_PS"))) {
-            // (us per K-window at d=5, one wave per chain / eight replicated lanes: see DESIGN.md, K1g)
+        if (cfg->lanes_per_chain == DEMCZ_LAYOUT_SPLIT_WAVE || (cfg->lanes_per_chain == 0 && ps_ok && cfg->N <= PS_MAX_N && cfg->K >= 2 && !getenv("DEMCZ_NO_PS"))) {
+            // (us per K-window at d=5, one wave per chain / eight replicated lanes: see DESIGN.md, K1g; K = 1 leaves a
+            //  pass one generation: 1.05 against 0.99 us per generation, scripts/k_small.py)
             if (!ps_ok) {
                 h->err = "demcz_create: the wave-per-chain split layout is not built for this target / d / block structure";
                 return bail(DEMCZ_ERR_INVALID_ARGUMENT);
