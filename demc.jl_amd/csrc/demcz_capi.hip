@@ -97,7 +97,8 @@ struct demcz_handle {
 #endif
     int64_t rec_cap = 0;              // generations each buffer holds
     int rec_cur = 0;
-    mutable bool lds_raised = false;  // hipFuncAttributeMaxDynamicSharedMemorySize raised on this handle's device (the attribute is per device)
+    bool lr_spec = false;             // split_kind 2, regression target: window_kernel_lr8s (eight chains per workgroup, two generations per pass)
+    mutable bool lds_raised = false, lds_raised_spec = false;  // hipFuncAttributeMaxDynamicSharedMemorySize raised on this handle's device (the attribute is per device)
     bool no_live = false;             // a LIVE hand-off failed on this handle: one launch per K-window from then on
     bool live_claimed = false;        // this handle holds its device's LIVE slot (one handle per device at a time)
     unsigned int live_spin_limit = 0; // polls before a LIVE wait gives up (0: the default, demcz_kernels_rec.h)
@@ -397,6 +398,16 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         } else if (cfg->lanes_per_chain == 0 && L > 1 && cfg->N * L <= 262144) {
             h->lanes = L;       // up to ~4 waves per SIMD; measured crossover with one lane per chain at d=5:
         }                       // N=32768 29.9 vs 35.4 us per window, N=65536 53.8 vs 45.8
+    }
+    if (h->lanes == DEMCZ_LAYOUT_SPLIT && h->split_kind == 2 && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE && !getenv("DEMCZ_NO_LR_SPEC")) {
+        // Eight chains per workgroup, two generations per log-density pass, where that still is at most one workgroup per CU
+        // (C5: 2048 chains = 256 workgroups; sixteen chains per workgroup leave half the chip idle there).
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device_id) != hipSuccess) cus = 0;
+        if ((cfg->N + LR8_CHAINS - 1) / LR8_CHAINS <= (int64_t)cus && lr8s_dynamic_lds<10>(cfg->nobs) <= ML_MAX_DYNAMIC_LDS) {
+            h->lr_spec = true;
+            h->split_per_wg = LR8_CHAINS;
+        }
     }
     // no pointer of the caller's survives create
     h->cfg.block_offsets = nullptr; h->cfg.block_indices = nullptr; h->cfg.eps_scale = nullptr;
@@ -855,7 +866,16 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_lr16<10, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
             h->lds_raised = true;
         }
-        if (live) hipLaunchKernelGGL((window_kernel_lr16<10, true, true>), grid, wg, dyn, h->stream, P);
+        if (h->lr_spec) {
+            const size_t dyn = lr8s_dynamic_lds<10>(P.tp.nobs);
+            if (!h->lds_raised_spec) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_lr8s<10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_lr8s<10, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
+                h->lds_raised_spec = true;
+            }
+            if (live) hipLaunchKernelGGL((window_kernel_lr8s<10, true>), grid, wg, dyn, h->stream, P);
+            else hipLaunchKernelGGL((window_kernel_lr8s<10, false>), grid, wg, dyn, h->stream, P);
+        } else if (live) hipLaunchKernelGGL((window_kernel_lr16<10, true, true>), grid, wg, dyn, h->stream, P);
         else hipLaunchKernelGGL((window_kernel_lr16<10, true, false>), grid, wg, dyn, h->stream, P);
     } else if (h->split_kind == 2) {
         const dim3 grid((unsigned)blocks), wg(64);
@@ -1236,6 +1256,14 @@ static int64_t live_wg_capacity(demcz_handle* h)
         case 20: f = reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 20, 16, true, true>); break;
         }
         if (!f || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 64, 0) != hipSuccess) per_cu = 0;
+    } else if (h->split_kind == 2 && h->lr_spec) {
+        // Every consumer workgroup takes a CU's LDS for itself (the design matrix): the launch's 256 workgroups are resident
+        // together iff every CU is there for them, and a CU's other tenants (producer workgroups of the same grid come behind
+        // the consumers and need the same LDS; the R-hat kernels need none) cannot take it from them.  No halving here.
+        const size_t dyn = lr8s_dynamic_lds<10>(h->cfg.nobs);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_lr8s<10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&window_kernel_lr8s<10, true>), 64 * LR16_WAVES, dyn) != hipSuccess) per_cu = 0;
+        per_cu *= 2;        // (undoes the halving below)
     } else if (h->split_kind == 2 && h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE) {
         const size_t dyn = lr16_dynamic_lds<10>(h->cfg.nobs);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_lr16<10, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);

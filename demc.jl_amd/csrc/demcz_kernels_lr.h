@@ -41,6 +41,7 @@ __host__ __device__ constexpr size_t lr16_dynamic_lds(int64_t nobs)
 }
 
 typedef double lr_d4 __attribute__((ext_vector_type(4)));
+typedef double lr_d2 __attribute__((ext_vector_type(2)));
 
 // Workgroup barrier for data that travels through LDS only: wait for this wave's LDS operations, then s_barrier.
 // (__syncthreads() also waits for every outstanding GLOBAL access of the wave -- here that is the next generation's
@@ -388,6 +389,453 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr16(const Wind
         unsigned long long* o = P.stamps + ((size_t)blockIdx.x * LR16_WAVES + w) * 16;
         for (int i = 0; i < 6; ++i) o[8 + i] = sa[i];
         o[14] = (unsigned long long)P.ngen;
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// K1b-s: the same instruction fed with EIGHT chains and two generations.  At C5's N = 2048 the kernel above is 128
+// workgroups on 256 CUs, and a workgroup's log-density pass takes the same time whatever its 16 columns hold.  Here a
+// workgroup runs eight chains; column jc holds chain jc's proposal of its next generation g, column jc + 8 its proposal of
+// generation g + 1 AS IF GENERATION g WERE REJECTED (x unchanged: the proposal is x + delta(g+1), and delta does not depend
+// on the state).  One pass gives both log-densities.  If g is rejected -- most are: the acceptance ratio the reference's
+// annealer steers for is 0.1 .. 0.5 (demcz_anneal.jl:48-57) and with a fixed gamma it is a few per cent -- generation g + 1
+// is resolved by the same pass and the chain advances by two; if g is accepted the second column is discarded and the chain
+// advances by one.  Every generation is still evaluated exactly as the spec says (same operands, same order): results are
+// bit-identical to every other layout.  Chains of a workgroup run at their own pace; each lane carries its chain's
+// generation counter.  A second column never crosses a K boundary (a chain must publish its row before it may wait for
+// rows of the same boundary, as in demcz_kernels_ps.h).
+//
+// Draws and archive rows.  A lane wants entries k = q, 4 + q, 8 + q of a generation's normals and of both archive rows: read
+// from memory like that (window_kernel_lr16) a load instruction is 64 separate requests and costs ~120 cycles to issue, and
+// two generations ahead for a chain that may move by one or two makes 25 of them a step.  Instead every WAVE keeps, in LDS of
+// its own, a ring of four generations per chain -- record (D normals, log u, row indices) and both archive rows, 16 pieces of
+// 16 bytes -- and refills the entries of generations g + 2, g + 3 at every step with four coalesced 16-byte loads per lane
+// (asked for at the step's top, written to the ring at its end), the row indices of g + 4, g + 5 alongside.  Nothing is
+// shared between waves, so no barrier is added; the lanes read what they need with LDS reads.
+// Split form only (the draws come from records), four waves per workgroup split by residue as above.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int LR8_CHAINS = 8;
+constexpr int LR8_RING = 4;                                 // generations per chain in a wave's ring
+constexpr int LR8_CH_DOUBLES = LR8_RING * 32 + 4;           // (+ 4: the chains' entries fall into different banks)
+constexpr int LR8_IXRING = 8;
+
+// the value of the lane eight places on in the same row of sixteen (row_ror:8)
+__device__ __forceinline__ double dpp_ror8(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(uint64_t)b, 0x128, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)((uint64_t)b >> 32), 0x128, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo));
+}
+
+template <int D>
+__host__ __device__ constexpr size_t lr8s_dynamic_lds(int64_t nobs)
+{
+    return lr16_dynamic_lds<D>(nobs) + (size_t)LR16_WAVES * ((size_t)LR8_CHAINS * LR8_CH_DOUBLES * 8 + (size_t)LR8_CHAINS * LR8_IXRING * 8 + LR8_CHAINS * 4);
+}
+
+template <int D, bool LIVE>
+__global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr8s(const WindowParams P)
+{
+    constexpr int NMF = (D + 3) / 4;
+    constexpr int F = D + 2;
+    static_assert(F % 2 == 0 && F / 2 + 2 * (D / 2) == 16, "a generation's record and two rows are sixteen 16-byte pieces");
+    if ((int64_t)blockIdx.x >= P.consumer_blocks) {
+        pc_produce<D>(P, ((int64_t)blockIdx.x - P.consumer_blocks) * LR16_WAVES + (int64_t)(threadIdx.x >> 6), (int)(threadIdx.x & 63));
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char lr_dyn_lds[];
+    const int64_t nobs = P.tp.nobs;
+    const int ngrp = (int)((nobs + 63) / 64);
+    double* A_l = reinterpret_cast<double*>(lr_dyn_lds);
+    double* y_l = A_l + (size_t)ngrp * LR16_WAVES * NMF * 64;
+    double* part_l = y_l + (size_t)ngrp * LR16_WAVES * 16;
+    unsigned int* flag_l = reinterpret_cast<unsigned int*>(part_l + 2 * LR16_CHAINS * 18);
+    // (where the fused form keeps its draws) what each wave saw missing, two steps' worth: [step & 1][wave][generation g / g + 1]
+    [[maybe_unused]] unsigned long long* miss_l = reinterpret_cast<unsigned long long*>(flag_l + 4);
+    static_assert(LR16_CHAINS * ((D + 1) / 2 + 2) * 16 >= 2 * LR16_WAVES * 2 * 8, "the draws' LDS holds the waves' masks");
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, l = tid & 63, q = l >> 4, j = l & 15, jc = j & 7;
+    // this wave's ring, row-index ring and generation table
+    double* ring_w = reinterpret_cast<double*>(lr_dyn_lds + lr16_dynamic_lds<D>(nobs)) + (size_t)w * (LR8_CHAINS * LR8_CH_DOUBLES + LR8_CHAINS * LR8_IXRING);
+    double* ixr_w = ring_w + LR8_CHAINS * LR8_CH_DOUBLES;
+    int* gen_w = reinterpret_cast<int*>(reinterpret_cast<double*>(lr_dyn_lds + lr16_dynamic_lds<D>(nobs)) + (size_t)LR16_WAVES * (LR8_CHAINS * LR8_CH_DOUBLES + LR8_CHAINS * LR8_IXRING)) + w * LR8_CHAINS;
+    for (int i = tid; i < ngrp * LR16_WAVES * NMF * 64; i += 64 * LR16_WAVES) {      // (the layouts of window_kernel_lr16)
+        const int ll = i & 63;
+        int rest = i >> 6;
+        const int m = rest % NMF;
+        rest /= NMF;
+        const int ww = rest & 3, T = rest >> 2;
+        const int row = ll & 15, kk = ll >> 4;
+        const int64_t o = 16 * (int64_t)(4 * T + (row >> 2)) + 4 * ww + (row & 3);
+        const int col = 4 * m + kk;
+        A_l[i] = (o < nobs && col < D) ? P.tp.design[o * D + col] : 0.0;
+    }
+    for (int i = tid; i < ngrp * LR16_WAVES * 16; i += 64 * LR16_WAVES) {
+        const int reg = i & 3, qq = (i >> 2) & 3, ww = (i >> 4) & 3, T = i >> 6;
+        const int64_t o = 16 * (int64_t)(4 * T + reg) + 4 * ww + qq;
+        y_l[i] = (o < nobs) ? P.tp.yobs[o] : 0.0;
+    }
+    if (tid == 0) {
+        flag_l[0] = 0u;
+        flag_l[1] = 0u;
+        if constexpr (LIVE) flag_l[0] = __hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (l < LR8_CHAINS) gen_w[l] = 0;
+    __syncthreads();
+    if (flag_l[0] != 0u) return;
+
+    const bool sp = j >= 8;                                // this lane's column: the proposal of generation g (false) / g + 1 (true)
+    const int64_t c_raw = (int64_t)blockIdx.x * LR8_CHAINS + jc;
+    const bool active = c_raw < P.N;
+    const int64_t c = active ? c_raw : P.N - 1;
+
+    double x[NMF], epsv[NMF];
+    bool own[NMF];
+    int kq[NMF];
+#pragma unroll
+    for (int m = 0; m < NMF; ++m) {
+        const int k = 4 * m + q;
+        own[m] = k < D;
+        kq[m] = own[m] ? k : 0;
+        x[m] = own[m] ? P.Xcur[c + P.N * k] : 0.0;
+        epsv[m] = P.eps[kq[m]];
+    }
+    double lp = P.lpcur[c];
+    const double scale = (D == 1) ? P.gamma : P.gamma / sqrt((double)(2 * D));
+    const int last = P.ngen - 1;
+    const int64_t rq_gen = (int64_t)P.N * F;
+
+    // ---- the wave's loader: piece pc of generation (chain ch's next) + off + go, for 4 x 64 = 8 chains x 2 generations x 16 pieces.
+    // A piece's address is base + n * stride with n the generation (record pieces) or the archive row (row pieces): one
+    // 32 x 32 -> 64-bit multiply-add per piece.  (N <= 2048 here -- one workgroup per CU at most -- so N F 8 < 2^32.)
+    int ld_ch[4], ld_go[4], ld_at[4];
+    bool ld_rec[4], ld_hi[4];
+    uint64_t ld_base[4];
+    uint32_t ld_stride[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pp = i * 64 + l, pc = pp & 15;
+        ld_ch[i] = pp >> 5; ld_go[i] = (pp >> 4) & 1;
+        const int64_t cr = (int64_t)blockIdx.x * LR8_CHAINS + ld_ch[i];
+        const int64_t cc = cr < P.N ? cr : P.N - 1;
+        ld_rec[i] = pc < F / 2;
+        ld_hi[i] = pc >= F / 2 + D / 2;
+        ld_at[i] = ld_ch[i] * LR8_CH_DOUBLES + pc * 2;
+        ld_base[i] = ld_rec[i] ? (uint64_t)(P.rec_in + cc * F + pc * 2) : (uint64_t)(P.Z + (pc - F / 2 - (ld_hi[i] ? D / 2 : 0)) * 2);
+        ld_stride[i] = ld_rec[i] ? (uint32_t)(P.N * F * 8) : (uint32_t)(P.ZS * 8);
+    }
+    lr_d2 dat[4];
+    int dat_at[4];                                         // where in the ring the piece goes (doubles)
+    auto stage_ask = [&](int off) {
+        int gl[4];
+        double ixv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gl[i] = gen_w[ld_ch[i]] + off + ld_go[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ixv[i] = ixr_w[ld_ch[i] * LR8_IXRING + (gl[i] & (LR8_IXRING - 1))];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint64_t ii = (uint64_t)__double_as_longlong(ixv[i]);
+            const uint32_t row = ld_hi[i] ? (uint32_t)(ii >> 32) : (uint32_t)ii;
+            const uint32_t gc = (uint32_t)(gl[i] < last ? gl[i] : last);      // (past the launch's end: a harmless repeat of its last generation)
+            const uint32_t n = ld_rec[i] ? gc : row;
+            dat_at[i] = ld_at[i] + (gl[i] & (LR8_RING - 1)) * 32;
+            dat[i] = *reinterpret_cast<const lr_d2*>(ld_base[i] + (uint64_t)n * ld_stride[i]);
+        }
+    };
+    auto stage_put = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<lr_d2*>(ring_w + dat_at[i]) = dat[i];
+    };
+    // packed row indices: lane (chain l >> 3, e = l & 7) of the first fill takes generation e; a step's lanes l < 16 take
+    // generations (chain's next) + 4 + (l & 1) of chain l >> 1
+    {
+        const int ch = l >> 3, e = l & 7;
+        const int64_t cr = (int64_t)blockIdx.x * LR8_CHAINS + ch;
+        const int64_t cc = cr < P.N ? cr : P.N - 1;
+        ixr_w[ch * LR8_IXRING + e] = P.rec_in[rq_gen * (e < last ? e : last) + cc * F + (D + 1)];
+    }
+    stage_ask(0);
+    stage_put();
+    const int ix_ch = (l >> 1) & 7, ix_e = l & 1;
+    const int64_t ix_c = [&] { const int64_t cr = (int64_t)blockIdx.x * LR8_CHAINS + ix_ch; return cr < P.N ? cr : P.N - 1; }();
+
+    int gen = 0;                         // this chain's next generation (of the launch, 0-based)
+    int to_b = P.to_boundary;            // countdown to the chain's next K boundary
+    int64_t nb = 0;                      // boundaries it has passed inside this launch
+    unsigned int cnt_total = 0, cnt_first = 0;
+    const unsigned long long speak64 = __builtin_amdgcn_ballot_w64(q == 0 && (w == LR16_WAVES - 1) && active);
+    // the history rows of the step before (written a step later, behind the loads: see window_kernel_lr16)
+    double x_mid[NMF], lp_mid = lp;
+    int h_gen = 0, h_adv = 0;
+#pragma unroll
+    for (int m = 0; m < NMF; ++m) x_mid[m] = x[m];
+    // column jc writes the first of a step's generations, column jc + 8 the second; wave m parameter group m, the last wave log_obj
+    // (one 32 x 32 -> 64-bit multiply-add per address: N D 8 < 2^32 with N <= 2048)
+    const bool h_lane = P.chain && active && (w == LR16_WAVES - 1 ? q == 0 : 4 * w + q < D);
+    const uint64_t h_base = (w == LR16_WAVES - 1) ? (uint64_t)(P.logobj + c) : (uint64_t)(P.chain + c + P.N * (4 * w + q));
+    const uint32_t h_stride = (uint32_t)((w == LR16_WAVES - 1 ? P.N : P.N * D) * 8);
+    auto write_hist = [&]() {
+        const bool mine = h_lane && (sp ? h_adv == 2 : h_adv >= 1);
+        const uint32_t slot = (uint32_t)(P.slot_first + h_gen + (sp ? 1 : 0));
+        const bool midrow = !sp && h_adv == 2;            // the first of two generations: the state the rejected one left
+        double v = midrow ? lp_mid : lp;                                                   // demcz.jl:85
+#pragma unroll
+        for (int m = 0; m < NMF; ++m) v = (w == m) ? (midrow ? x_mid[m] : x[m]) : v;       // demcz.jl:84
+        if (mine) *reinterpret_cast<double*>(h_base + (uint64_t)slot * h_stride) = v;
+    };
+    const bool z_lane = active && !sp && w < NMF && 4 * w + q < D;
+    const uint64_t z_base = (uint64_t)(P.Zw + (P.M_append + c) * P.ZS + (4 * w + q));
+    const uint32_t z_stride = (uint32_t)(P.N * P.ZS * 8);
+    constexpr int PROW = 18;
+    int step = 0;
+    [[maybe_unused]] int spins = 0;
+#ifdef DEMCZ_STAMPS
+    unsigned long long sa[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sa_t = __builtin_readcyclecounter();
+#endif
+    while (__builtin_amdgcn_ballot_w64(gen <= last) != 0ull) {       // (the four waves hold the same state: the same decision)
+        LR_TICK(5);
+        bool a_ok = gen <= last;
+        bool b_ok = a_ok && gen < last && to_b != 1;                  // the second generation: inside the launch, not behind a boundary
+        // ---- this lane's column's generation (g, or g + 1) of its chain, from the wave's ring
+        const int gmine = gen + (sp ? 1 : 0);
+        double* rp = ring_w + jc * LR8_CH_DOUBLES + (gmine & (LR8_RING - 1)) * 32;
+        double za[NMF], zb[NMF], zt[NMF];
+#pragma unroll
+        for (int m = 0; m < NMF; ++m) {
+            zt[m] = rp[kq[m]];
+            za[m] = rp[F + kq[m]];
+            zb[m] = rp[F + D + kq[m]];
+        }
+        const double logu = rp[D], ixm = rp[D + 1];
+        const double tmine = P.temperature ? P.temperature[gmine < last ? gmine : last] : 1.0;
+        // LIVE: rows appended since the gather was issued read as the sentinel until they are published.  They are asked for
+        // again (sc1) and the answer is looked at in the NEXT step: a chain with a missing row sits this step out (if only its
+        // second generation's is missing, that one is not attempted) while the workgroup's other chains go on -- chains of one
+        // workgroup may be boundaries apart, so the workgroup must never stand still for one of them.  The four waves read the
+        // archive each at its own moment: what they saw meets in LDS at the step's barrier, so that they decide alike.
+        [[maybe_unused]] unsigned long long seen0 = 0ull, seen1 = 0ull;
+        [[maybe_unused]] bool smine = false;
+        if constexpr (LIVE) {
+            bool b = false;
+#pragma unroll
+            for (int m = 0; m < NMF; ++m) b |= is_sentinel(za[m]) | is_sentinel(zb[m]);
+            smine = (sp ? b_ok : a_ok) && b;
+            seen0 = __builtin_amdgcn_ballot_w64(smine && !sp);
+            seen1 = __builtin_amdgcn_ballot_w64(smine && sp);
+        }
+        LR_TICK(4);
+        // the proposal (update_demcz_chain_block, demcz.jl:180-188) of this lane's column -- both columns' from the SAME x -- is its B operand
+        double xp[NMF], bop[NMF];
+#pragma unroll
+        for (int m = 0; m < NMF; ++m) {
+            const double diff = za[m] - zb[m];
+            const double t1 = scale * diff;
+            const double t2 = epsv[m] * zt[m];
+            const double delta = t1 + t2;
+            xp[m] = x[m] + delta;
+            bop[m] = own[m] ? xp[m] : 0.0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        LR_TICK(6);
+        if constexpr (LIVE) {
+            if ((seen0 | seen1) != 0ull) {      // (behind the proposal: nothing of this step waits for the answer; it goes to the ring)
+                if (smine) {
+                    const uint64_t ii = (uint64_t)__double_as_longlong(ixm);
+                    const int64_t ra = (int64_t)(uint32_t)ii, rb = (int64_t)(uint32_t)(ii >> 32);
+#pragma unroll
+                    for (int m = 0; m < NMF; ++m) {
+                        if (is_sentinel(za[m])) za[m] = live_load(&P.Z[ra * P.ZS + kq[m]]);
+                        if (is_sentinel(zb[m])) zb[m] = live_load(&P.Z[rb * P.ZS + kq[m]]);
+                    }
+                }
+            }
+        }
+        LR_TICK(7);
+        // ---- ask for generations g + 2, g + 3 and the row indices of g + 4, g + 5 (the same memory operations on every trip)
+        stage_ask(2);
+        const int ix_g = gen_w[ix_ch] + 4 + ix_e;
+        double ix_new = 0.0;
+        if (l < 2 * LR8_CHAINS) ix_new = P.rec_in[rq_gen * (ix_g < last ? ix_g : last) + ix_c * F + (D + 1)];
+        __builtin_amdgcn_sched_barrier(0);
+        LR_TICK(8);
+        if (step > 0) write_hist();
+        __builtin_amdgcn_sched_barrier(0);
+        LR_TICK(0);
+        double sacc = 0.0;
+        {
+            constexpr int TF = 4;
+            const double* Aw = A_l + (size_t)w * NMF * 64 + l;
+            const double* yw = y_l + (size_t)(w * 4 + q) * 4;
+            auto finish = [&](const lr_d4& a, int T) {
+                const double2 y01 = reinterpret_cast<const double2*>(yw + (size_t)T * 64)[0];
+                const double2 y23 = reinterpret_cast<const double2*>(yw + (size_t)T * 64)[1];
+                double e;
+                e = y01.x - a[0]; sacc = fma(e, e, sacc);
+                e = y01.y - a[1]; sacc = fma(e, e, sacc);
+                e = y23.x - a[2]; sacc = fma(e, e, sacc);
+                e = y23.y - a[3]; sacc = fma(e, e, sacc);
+            };
+            int T = 0;
+            for (; T + TF <= ngrp; T += TF) {
+                lr_d4 a[TF];
+#pragma unroll
+                for (int i = 0; i < TF; ++i) a[i] = lr_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int m = 0; m < NMF; ++m)
+#pragma unroll
+                    for (int i = 0; i < TF; ++i)
+                        a[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aw[((size_t)(T + i) * LR16_WAVES * NMF + m) * 64], bop[m], a[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TF; ++i) finish(a[i], T + i);
+            }
+            for (; T < ngrp; ++T) {
+                lr_d4 a = lr_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int m = 0; m < NMF; ++m)
+                    a = __builtin_amdgcn_mfma_f64_16x16x4f64(Aw[((size_t)T * LR16_WAVES * NMF + m) * 64], bop[m], a, 0, 0, 0);
+                finish(a, T);
+            }
+        }
+        double* part = part_l + (size_t)(step & 1) * LR16_CHAINS * PROW;
+        part[j * PROW + 4 * w + q] = sacc;
+        LR_TICK(1);
+        if constexpr (LIVE) {
+            if (l == 0) {
+                miss_l[((step & 1) * LR16_WAVES + w) * 2] = seen0;
+                miss_l[((step & 1) * LR16_WAVES + w) * 2 + 1] = seen1;
+            }
+            // (a launch another workgroup has given up is left too; looked at now and then, by one lane for all)
+            if (tid == 0 && (step & 255) == 255 && __hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) flag_l[1] = 1u;
+        }
+        wg_barrier_lds();
+        LR_TICK(2);
+        if constexpr (LIVE) {
+            if (flag_l[1] != 0u) return;                       // workgroup-uniform
+            unsigned long long m0 = 0ull, m1 = 0ull;
+#pragma unroll
+            for (int ww = 0; ww < LR16_WAVES; ++ww) {
+                m0 |= miss_l[((step & 1) * LR16_WAVES + ww) * 2];
+                m1 |= miss_l[((step & 1) * LR16_WAVES + ww) * 2 + 1];
+            }
+            const unsigned long long mine = 0x0101010101010101ull << jc;        // every lane of this chain, in any wave
+            const bool miss0 = (m0 & mine) != 0ull, miss1 = (m1 & mine) != 0ull;
+            // a chain that has waited live_spin_limit steps in a row gives the launch up (demcz_kernels_rec.h; the host then
+            // redoes it one K-window at a time)
+            spins = miss0 ? spins + 1 : 0;
+            const bool timeout = miss0 && spins >= P.live_spin_limit;
+            if (__builtin_amdgcn_ballot_w64(timeout) != 0ull) {                  // the same in all four waves
+                if (timeout && atomicCAS(P.live_err, 0u, 1u) == 0u) {
+                    P.live_err[1] = (unsigned)gen; P.live_err[2] = (unsigned)(uint32_t)(uint64_t)__double_as_longlong(ixm); P.live_err[3] = blockIdx.x;
+                }
+                return;
+            }
+            a_ok = a_ok && !miss0;
+            b_ok = b_ok && !miss0 && !miss1;
+        }
+        // this column's partials, combined by the spec's tree, and its test (demcz.jl:197-203 / demcz_anneal.jl:172-178) against
+        // the chain's CURRENT log_obj: right for generation g, and for g + 1 if g is rejected
+        double lpm;
+        {
+            double pt[16];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const double2 tt = reinterpret_cast<const double2*>(part + j * PROW)[i];
+                pt[2 * i] = tt.x;
+                pt[2 * i + 1] = tt.y;
+            }
+#pragma unroll
+            for (int h = 8; h >= 1; h >>= 1) {
+#pragma unroll
+                for (int i = 0; i < h; ++i) pt[i] = pt[i] + pt[i + h];
+            }
+            lpm = -0.5 * pt[0];
+        }
+        LR_TICK(9);
+        double dl = lpm - lp;
+        if (P.temperature) dl = dl / tmine;
+        const unsigned long long pass = __builtin_amdgcn_ballot_w64(logu < dl);
+        // the other column of the chain is eight lanes away, in the same row of sixteen
+        const double lpo = dpp_ror8(lpm);
+        double xo[NMF];
+#pragma unroll
+        for (int m = 0; m < NMF; ++m) xo[m] = dpp_ror8(xp[m]);
+        const double lpa = sp ? lpo : lpm, lpb = sp ? lpm : lpo;
+        const bool acca = a_ok && ((pass >> (l & ~8)) & 1ull) != 0ull;
+        const bool two = b_ok && !acca;                      // generation g was rejected: g + 1 started from the same state
+        const bool accb = two && ((pass >> (l | 8)) & 1ull) != 0ull;
+        const int adv = a_ok ? (two ? 2 : 1) : 0;
+        const double lp_a = acca ? lpa : lp;                // log_obj after generation g
+        const double lp_new = accb ? lpb : lp_a;            // ... after the step
+        {
+            // acceptance counts by ballot: column jc speaks for generation g, column jc + 8 for g + 1
+            const double df = sp ? (lp_new - lp_a) : (lp_a - lp);
+            const bool counted = sp ? two : a_ok;
+            const unsigned long long chg = __builtin_amdgcn_fcmp(df, 0.0, 14 /* UNE */) & speak64 & __builtin_amdgcn_ballot_w64(counted);
+            cnt_total += (unsigned int)__builtin_popcountll(chg);
+            cnt_first += (unsigned int)__builtin_popcountll(chg & __builtin_amdgcn_ballot_w64(!sp && gen == 0));
+        }
+        h_gen = gen;
+        h_adv = adv;
+        lp_mid = lp;
+#pragma unroll
+        for (int m = 0; m < NMF; ++m) {
+            x_mid[m] = x[m];
+            const double xa = sp ? xo[m] : xp[m], xb = sp ? xp[m] : xo[m];
+            x[m] = acca ? xa : (accb ? xb : x[m]);
+        }
+        lp = lp_new;
+        LR_TICK(10);
+        // ---- what was asked for at the top goes to the ring (the generation table still says where), then the table moves
+        stage_put();
+        if (l < 2 * LR8_CHAINS) ixr_w[ix_ch * LR8_IXRING + (ix_g & (LR8_IXRING - 1))] = ix_new;
+        if constexpr (LIVE) {
+            if ((seen0 | seen1) != 0ull) {
+#pragma unroll
+                for (int m = 0; m < NMF; ++m) {
+                    if (smine) { rp[F + kq[m]] = za[m]; rp[F + D + kq[m]] = zb[m]; }
+                }
+            }
+        }
+        gen += adv;
+        to_b -= adv;
+        if (q == 0 && !sp) gen_w[jc] = gen;
+        LR_TICK(11);
+        if (to_b == 0 && adv != 0) {        // the step ended on a generation divisible by K: runchain!'s append, demcz.jl:88-91
+            to_b = P.K;
+            if (z_lane) {                   // wave m: parameter group m of column jc's lanes
+                double v = 0.0;
+#pragma unroll
+                for (int m = 0; m < NMF; ++m) v = (w == m) ? x[m] : v;
+                if (P.do_append) {
+                    double* dst = reinterpret_cast<double*>(z_base + (uint64_t)(uint32_t)nb * z_stride);
+                    if constexpr (LIVE) live_store(dst, v);
+                    else *dst = v;
+                }
+                if (P.snap) P.snap[nb * P.N * D + c + P.N * (4 * w + q)] = v;
+            }
+            ++nb;
+        }
+        ++step;
+        LR_TICK(3);
+    }
+    write_hist();
+    const bool writer = (w == 0) && active && !sp;
+#pragma unroll
+    for (int m = 0; m < NMF; ++m)
+        if (own[m] && writer) P.Xcur[c + P.N * (4 * m + q)] = x[m];
+    if (q == 0 && writer) P.lpcur[c] = lp;
+    static_assert(NMF < LR16_WAVES, "parameter groups and log_obj each have a wave to write them");
+    wave_store_counts(P, (int64_t)blockIdx.x * LR16_WAVES + w, cnt_total, cnt_first);
+#ifdef DEMCZ_STAMPS
+    if (P.stamps && (tid & 63) == 0 && blockIdx.x < 16384u) {      // as window_kernel_lr16, per STEP; [15]: steps
+        unsigned long long* o = P.stamps + ((size_t)blockIdx.x * LR16_WAVES + w) * 16;
+        for (int i = 0; i < 6; ++i) o[8 + i] = sa[i];
+        for (int i = 0; i < 6; ++i) o[i] = sa[6 + i];
+        o[14] = (unsigned long long)P.ngen;
+        o[15] = (unsigned long long)step;
     }
 #endif
 }
