@@ -137,6 +137,48 @@ def cpu_baseline(w, N, d, K, seed, budget_updates):
     return out
 
 
+# Window-kernel time of one batch of the deferred schedule at 1024 chains, d = 5, K = 10 (one launch per batch of E
+# boundaries), measured on one MI355X with `bench.py --append-lag E`: 23.4 us at E = 10, 47.1 at 25, 87.5 at 50
+#  -- what a batch's all-gather has to hide behind.
+def deferred_batch_us(E, n_loc):
+    return (7.5 + 1.6 * E) * (n_loc / 1024.0)
+
+
+def tune_append_lag(dist, torch, n_loc, d, K, every, device):
+    """Sharded runs: boundaries per all-gather (demcz_set_append_lag).  A batch's rows travel while the next batch computes;
+    if the all-gather takes longer than that the run is bound by the links' latency, not by the kernels.  The latency of an
+    8-rank all-gather of a few hundred KB is the node's, not ours to assume: time it here, once, for each batch size that
+    divides a slab, and take the smallest one whose all-gather (with a quarter to spare) fits behind its batch's compute.
+    Every rank sees the same (max-reduced) timings, so every rank takes the same schedule.  Returns (E, [(E, us), ...])."""
+    world = dist.get_world_size()
+    cands = [c for c in (10, 20, 25, 50) if (every // K) % c == 0] or [10]
+    rows = []
+    for E in cands:
+        n = E * n_loc * d
+        src = torch.zeros(n, dtype=torch.float64, device=device)
+        dst = torch.empty(n * world, dtype=torch.float64, device=device)
+        for _ in range(3):
+            dist.all_gather_into_tensor(dst, src)
+        if device != "cpu":
+            torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            dist.all_gather_into_tensor(dst, src)
+        if device != "cpu":
+            torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rows.append((E, float(t.item()) * 1e6))
+    chosen = cands[-1]
+    for E, us in rows:
+        if us * 1.25 < deferred_batch_us(E, n_loc):
+            chosen = E
+            break
+    return chosen, rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,10 +226,20 @@ def main():
         from demc_jl_amd.dist import torch_sharding
         sharding = torch_sharding(mode="rccl")
 
-    # sharded default: 10 boundaries per all-gather -- a batch (100 generations, ~35 us of compute) then outlasts a
-    # latency-bound 8-rank all-gather, which 3 boundaries (~12 us) would not
-    lag = args.append_lag if args.append_lag >= 0 else (0 if world == 1 else 10)
+    # sharded default: boundaries per all-gather chosen by tune_append_lag (10 if the probe fails): a batch's compute
+    # (23.5 us per 100 generations) has to outlast a latency-bound all-gather over the node's links
     d, K, n_loc = args.dim, 10, args.chains_per_gpu
+    lag_probe = None
+    if args.append_lag >= 0:
+        lag = args.append_lag
+    elif world == 1:
+        lag = 0
+    else:
+        lag = 10
+        try:      # (a failed probe leaves the documented default; a probe cannot change results, only the schedule that is reported)
+            lag, lag_probe = tune_append_lag(dist, torch, n_loc, d, K, args.slab_generations, "cpu" if args.dry_run else "cuda")
+        except Exception as e:
+            lag_probe = f"failed: {e}"
     N = n_loc * world
     every = args.slab_generations
     S = args.steps
@@ -201,7 +253,7 @@ def main():
         plan = {"world": world, "rank": rank, "local_rank": local_rank, "chains_total": N, "chains_per_gpu": n_loc,
                 "chain_id0": rank * n_loc, "append_lag": lag, "generations": G, "warmup_slabs": W, "timed_slabs": S,
                 "Mcap": int(w["Zinit"].shape[0] + -(-N * G // K)), "X_shard_shape": list(X[rank * n_loc:(rank + 1) * n_loc].shape),
-                "mode": sharding.mode if sharding else "single GPU"}
+                "mode": sharding.mode if sharding else "single GPU", "append_lag_probe_us": lag_probe}
         if sharding is not None:
             uid = bytes(range(128)) if rank == 0 else None         # stands in for demcz_comm_unique_id's ncclUniqueId
             got = sharding.broadcast_bytes(uid)
@@ -291,7 +343,8 @@ def main():
                                    f"gamma=2.38, eps=1e-5; step = one autostop slab = {every} generations with full "
                                    f"history + Z append every K + the slab's split-Rhat check (demcz.jl:30-55)",
                        "chains_total": N, "dim": d, "K": K, "generations_per_step": every, "generations_timed": gens,
-                       "lanes_per_chain": lanes, "append_lag": lag, "live_launches": live_on, "live_redos": live_redos,
+                       "lanes_per_chain": lanes, "append_lag": lag, "append_lag_probe_us": lag_probe,
+                       "live_launches": live_on, "live_redos": live_redos,
                        "parallelism": f"chains sharded x{world}, Z replicated" if world > 1 else "single GPU"},
             "gens_to_rhat_1p05": gens_to_rhat, "rhat_trace": rhat_trace[-12:], "accept_ratio_mean": acc,
             "value_window_kernels_only": N * gens / (ev_ms / 1e3) if ev_ms > 0 else None,
