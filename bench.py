@@ -147,11 +147,13 @@ def deferred_batch_us(E, n_loc):
 def tune_append_lag(dist, torch, n_loc, d, K, every, device):
     """Sharded runs: boundaries per all-gather (demcz_set_append_lag).  A batch's rows travel while the next batch computes;
     if the all-gather takes longer than that the run is bound by the links' latency, not by the kernels.  The latency of an
-    8-rank all-gather of a few hundred KB is the node's, not ours to assume: time it here, once, for each batch size that
-    divides a slab, and take the smallest one whose all-gather (with a quarter to spare) fits behind its batch's compute.
+    8-rank all-gather of a few hundred KB is the node's, not ours to assume: time it here, once, for the batch sizes offered
+    (they divide a slab), and take the smallest one whose all-gather (with a quarter to spare) fits behind its batch's compute.
     Every rank sees the same (max-reduced) timings, so every rank takes the same schedule.  Returns (E, [(E, us), ...])."""
     world = dist.get_world_size()
-    cands = [c for c in (10, 20, 25, 50) if (every // K) % c == 0] or [10]
+    # (E = 10 is not offered: the exchange's fixed cost per batch on the compute stream -- two cross-stream waits, the snapshot --
+    #  is ~14 us even at nranks = 1, scripts/rccl_single_rank_lag.py: 60 % of a 10-boundary batch, 30 % of a 25-boundary one)
+    cands = [c for c in (25, 50) if (every // K) % c == 0] or [10]
     rows = []
     for E in cands:
         n = E * n_loc * d
@@ -226,7 +228,7 @@ def main():
         from demc_jl_amd.dist import torch_sharding
         sharding = torch_sharding(mode="rccl")
 
-    # sharded default: boundaries per all-gather chosen by tune_append_lag (10 if the probe fails): a batch's compute
+    # sharded default: boundaries per all-gather chosen by tune_append_lag (25 if the probe fails): a batch's compute
     # (23.5 us per 100 generations) has to outlast a latency-bound all-gather over the node's links
     d, K, n_loc = args.dim, 10, args.chains_per_gpu
     lag_probe = None
@@ -235,7 +237,7 @@ def main():
     elif world == 1:
         lag = 0
     else:
-        lag = 10
+        lag = 25 if (args.slab_generations // K) % 25 == 0 else 10
         try:      # (a failed probe leaves the documented default; a probe cannot change results, only the schedule that is reported)
             lag, lag_probe = tune_append_lag(dist, torch, n_loc, d, K, args.slab_generations, "cpu" if args.dry_run else "cuda")
         except Exception as e:

@@ -104,8 +104,8 @@ def test_bench_multi_gpu_launch_path_dry_run():
     for rk, p in enumerate(out["ranks"]):
         assert (p["world"], p["rank"], p["chains_total"], p["chains_per_gpu"], p["chain_id0"]) == (2, rk, 2048, 1024, rk * 1024)
         # boundaries per all-gather: probed (every rank takes the same one), from the batch sizes that divide a slab
-        assert p["append_lag"] in (10, 20, 25, 50) and p["append_lag"] == out["ranks"][0]["append_lag"]
-        assert [e for e, _ in p["append_lag_probe_us"]] == [10, 20, 25, 50] and all(us > 0 for _, us in p["append_lag_probe_us"])
+        assert p["append_lag"] in (25, 50) and p["append_lag"] == out["ranks"][0]["append_lag"]
+        assert [e for e, _ in p["append_lag_probe_us"]] == [25, 50] and all(us > 0 for _, us in p["append_lag_probe_us"])
         assert p["mode"] == "rccl" and p["unique_id_ok"] and p["all_gather_ranks"] == [0.0, 1.0]
         assert p["warmup_slabs"] == 1 and p["timed_slabs"] == 3 and p["generations"] == 4000      # one untimed slab always runs
         assert p["X_shard_shape"] == [1024, 5] and p["Mcap"] == 2048 + 2048 * 400
