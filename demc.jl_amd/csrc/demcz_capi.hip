@@ -140,7 +140,7 @@ struct demcz_handle {
     // draw from, M_app the rows written or reserved; equal when lag == 0
     int lag = 0;
     int64_t M_app = 0;
-    struct PendingRows { int64_t visible_from; int64_t M_after; hipEvent_t ev; };
+    struct PendingRows { int64_t visible_from; int64_t M_after; hipEvent_t ev; int64_t xseq = 0; };   // xseq: the exchange that carries the rows (0: none yet)
     std::deque<PendingRows> pending;
     int64_t batch_J = -1;              // boundary index that closes the batch the last pending entry belongs to
     // sharded + lag: snapshots of a batch travel together on a side stream
@@ -148,6 +148,9 @@ struct demcz_handle {
     double* d_send[2] = {nullptr, nullptr};
     double* d_recv[2] = {nullptr, nullptr};
     hipEvent_t buf_done[2] = {nullptr, nullptr};
+    // exchanges are numbered; the compute stream already waits for exchange number `xseq_waited` and everything before it
+    // (admit_pending), so a send buffer last read by one of those needs no wait of its own
+    int64_t xseq = 0, xseq_waited = 0, buf_xseq[2] = {0, 0};
     int batch_buf = 0, batch_cnt = 0;
     int64_t batch_base = 0;
 };
@@ -1096,6 +1099,8 @@ static int32_t exchange_batch(demcz_handle* h)
     HIPCHK(h, hipEventCreateWithFlags(&done, hipEventDisableTiming));
     HIPCHK(h, hipEventRecord(done, h->comm_stream));
     h->pending.back().ev = done;                       // the entry that covers this batch
+    h->pending.back().xseq = ++h->xseq;
+    h->buf_xseq[buf] = h->xseq;
     HIPCHK(h, hipEventRecord(h->buf_done[buf], h->comm_stream));
     h->batch_cnt = 0;
     h->batch_buf ^= 1;
@@ -1111,6 +1116,7 @@ static int32_t admit_pending(demcz_handle* h, int64_t g)
         if (pe.ev) {
             HIPCHK(h, hipStreamWaitEvent(h->stream, pe.ev, 0));
             HIPCHK(h, hipEventDestroy(pe.ev));
+            h->xseq_waited = std::max(h->xseq_waited, pe.xseq);      // (the side stream runs its exchanges in order)
         }
         h->M = pe.M_after;
         h->pending.pop_front();
@@ -1471,7 +1477,8 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         if (nbound > 0 && sharded && E > 0) {
             if (h->batch_cnt == 0) {
                 // the buffer was last read by the exchange two batches ago
-                HIPCHK(h, hipStreamWaitEvent(h->stream, h->buf_done[h->batch_buf], 0));
+                // (every wait is a barrier packet between two window kernels: not asked for twice)
+                if (h->buf_xseq[h->batch_buf] > h->xseq_waited) HIPCHK(h, hipStreamWaitEvent(h->stream, h->buf_done[h->batch_buf], 0));
                 h->batch_base = h->M_app;
             }
             P.snap = h->d_send[h->batch_buf] + (size_t)h->batch_cnt * h->cfg.N * h->cfg.d;
