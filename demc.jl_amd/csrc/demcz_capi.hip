@@ -777,8 +777,11 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
     const int upw = lr_split ? LR16_WAVES : (h->split_kind == 4) ? PS_CHAINS + (live ? 1 : 0) : (h->split_kind == 1 && live) ? PC8_LIVE_WAVES : 1;
     const int64_t blocks = P.consumer_blocks + (units + upw - 1) / upw;
     if (blocks <= 0) return DEMCZ_OK;
-    if (h->split_kind == 4) {
-        if (P.ZS != ((P.d <= 2) ? 2 : (P.d <= 4) ? 4 : ((P.d + 7) / 8) * 8)) return fail(h, DEMCZ_ERR_STATE, "split layout: archive row stride");
+    if (h->split_kind == 4 || h->lr_spec) {
+        // consumers whose LIVE launches have the producer half as a kernel of its own beside them: one wave per chain (ps / pw),
+        // and the regression target's eight-chains-per-workgroup kernel (its workgroups take a CU's LDS each: producer
+        // workgroups of the same grid could only follow them)
+        if (h->split_kind == 4 && P.ZS != ((P.d <= 2) ? 2 : (P.d <= 4) ? 4 : ((P.d + 7) / 8) * 8)) return fail(h, DEMCZ_ERR_STATE, "split layout: archive row stride");
         const int bin = (P.rec_in == h->d_rec[0]) ? 0 : 1, bout = (P.rec_out == h->d_rec[0]) ? 0 : 1;
         const bool one_launch = !live && P.consumer_blocks > 0;     // a short launch: producer workgroups ride in the consumer's grid
         if (units > 0 && one_launch && h->prod_pending[bout]) {
@@ -812,7 +815,8 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
             // never touch: more of them only take issue slots from the chain waves (measured); alone they
             // take the whole chip.
             static const size_t throttle_env = getenv("DEMCZ_PRODUCE_LDS") ? (size_t)atol(getenv("DEMCZ_PRODUCE_LDS")) : PRODUCE_THROTTLE_LDS;
-            const size_t dyn = (ps != h->stream) ? throttle_env : 0;
+            // (regression target: what a consumer workgroup leaves of its CU's LDS holds ONE 8 KB producer workgroup)
+            const size_t dyn = (ps != h->stream) ? (h->lr_spec ? (size_t)8192 : throttle_env) : 0;
             switch (P.d) {
             case 2: hipLaunchKernelGGL((produce_kernel<2>), pg, pw, dyn, ps, P); break;
             case 3: hipLaunchKernelGGL((produce_kernel<3>), pg, pw, dyn, ps, P); break;
@@ -834,7 +838,19 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
                 HIPCHK(h, hipStreamWaitEvent(h->stream, h->prod_done[bin], 0));
                 h->prod_pending[bin] = false;
             }
+            static_assert(PS_CHAINS == LR16_WAVES, "producer units per workgroup of a one-launch grid");
             const int64_t grid = P.consumer_blocks + (one_launch ? (units + PS_CHAINS - 1) / PS_CHAINS : 0);
+            if (h->lr_spec) {
+                const size_t dynl = lr8s_dynamic_lds<10>(P.tp.nobs);
+                if (!h->lds_raised_spec) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_lr8s<10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_lr8s<10, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
+                    h->lds_raised_spec = true;
+                }
+                const dim3 g((unsigned)grid), wgl(64 * LR16_WAVES);
+                if (live) hipLaunchKernelGGL((window_kernel_lr8s<10, true>), g, wgl, dynl, h->stream, P);
+                else hipLaunchKernelGGL((window_kernel_lr8s<10, false>), g, wgl, dynl, h->stream, P);
+            } else
             switch (P.d) {
             case 2: launch_ps<TARGET_MVNORMAL, 2>(h, P, grid, live); break;
             case 3: launch_ps<TARGET_MVNORMAL, 3>(h, P, grid, live); break;
@@ -869,16 +885,7 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_lr16<10, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
             h->lds_raised = true;
         }
-        if (h->lr_spec) {
-            const size_t dyn = lr8s_dynamic_lds<10>(P.tp.nobs);
-            if (!h->lds_raised_spec) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_lr8s<10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_lr8s<10, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
-                h->lds_raised_spec = true;
-            }
-            if (live) hipLaunchKernelGGL((window_kernel_lr8s<10, true>), grid, wg, dyn, h->stream, P);
-            else hipLaunchKernelGGL((window_kernel_lr8s<10, false>), grid, wg, dyn, h->stream, P);
-        } else if (live) hipLaunchKernelGGL((window_kernel_lr16<10, true, true>), grid, wg, dyn, h->stream, P);
+        if (live) hipLaunchKernelGGL((window_kernel_lr16<10, true, true>), grid, wg, dyn, h->stream, P);
         else hipLaunchKernelGGL((window_kernel_lr16<10, true, false>), grid, wg, dyn, h->stream, P);
     } else if (h->split_kind == 2) {
         const dim3 grid((unsigned)blocks), wg(64);

@@ -1,5 +1,5 @@
 """C5 (regression target, d = 10, nobs = 1000, N = 2048, annealed): window-kernel time per launch, launches, LIVE state.
-usage: python scripts/c5_steps.py [gens] [gamma]   (gamma: default the workload's 2.38 -> ~1 % acceptance; ~0.5 gives the 0.2-0.4 the annealer's adaptation steers for)   (DEMCZ_NO_LR_SPEC=1: sixteen chains per workgroup, one generation per pass)"""
+usage: python scripts/c5_steps.py [gens] [gamma]   (gamma: default the workload's 2.0 -> ~1 % acceptance; ~0.5 gives the 0.2-0.4 the annealer's adaptation steers for)   (DEMCZ_NO_LR_SPEC=1: sixteen chains per workgroup, one generation per pass)"""
 import sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
