@@ -1,5 +1,5 @@
 """Where a block-step of the block-update split kernel (window_kernel_mlb, C3) goes: shader-clock sums per wave from a
--DDEMCZ_STAMPS build.  usage: python scripts/mlb_stamps.py [N]"""
+-DDEMCZ_STAMPS build.  usage: python scripts/mlb_stamps.py [N] [gens]   (DEMCZ_NO_LIVE=1: one launch per K-window, no in-launch hand-off)"""
 import ctypes as C, os, subprocess, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -14,7 +14,8 @@ import numpy as np
 import demc_jl_amd as demc
 from demc_jl_amd import _lib
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-d, G = 20, 102
+d = 20
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 102
 w = demc.workloads.mvnormal_problem(d, N)
 blocks = [range(0, 5), range(5, 10), range(10, 15), range(15, 20)]
 M0 = w["Zinit"].shape[0]
@@ -30,7 +31,7 @@ s = buf.astype(np.float64)
 ns = s[:, 14]
 names = ["wait for the step's rows, sentinel poll, increments", "next block-step's draws: entry -> LDS -> rows asked for", "dependent part: r -> W r -> q -> accept",
          "history row, append", "-", "between steps"]
-print(f"N={N}: last launch {int(ns[0])} block-steps per wave; ticks per block-step, mean over waves / max")
+print(f"N={N} gens={G} archive {e.M} rows: last launch {int(ns[0])} block-steps per wave; ticks per block-step, mean over waves / max")
 for i in (0, 1, 2, 3, 5):
     v = s[:, 8 + i] / ns
     print(f"  {v.mean():8.0f} {v.max():8.0f}   {names[i]}")
