@@ -354,7 +354,7 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         h->split_lanes = (kind == 2) ? 16 : (kind == 3) ? L : 0;
         // chains per consumer workgroup
         h->split_per_wg = (kind == 1) ? PC_CONSUMER_CHAINS : (kind == 2) ? ((cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? LR16_CHAINS : 4)
-                          : (kind == 3) ? 64 / L : 1;
+                          : (kind == 3) ? MLB_REC_WAVES * (64 / L) : 1;
         const bool split_ok = kind != 0;
         // one wave per chain (demcz_kernels_ps.h): where the replicated consumer is built and a pass's draws fit one DMA
         const bool ps_ok = (kind == 1 || kind == 2) && h->full_block && ps_available(cfg->target_kind, d);
@@ -468,7 +468,7 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         int64_t waves;
         if (h->lanes == DEMCZ_LAYOUT_SPLIT) {
             const int64_t wgs = (N + h->split_per_wg - 1) / h->split_per_wg;
-            waves = wgs * ((h->split_kind == 2 && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? LR16_WAVES : (h->split_kind == 4) ? PS_CHAINS : 1);
+            waves = wgs * ((h->split_kind == 2 && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? LR16_WAVES : (h->split_kind == 4) ? PS_CHAINS : (h->split_kind == 3) ? MLB_REC_WAVES : 1);
         } else if (h->lanes > 1) {
             const int per_wave = 64 / h->lanes;
             const bool lr = h->full_block && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE;
@@ -774,7 +774,7 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
     const bool lr_split = h->split_kind == 2 && h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE;
     const int64_t units = nbc * rec_roles(h) * P.next_ngen;               // 64-lane producer units
     // producer units per workgroup = waves per workgroup of the instantiation that is launched
-    const int upw = lr_split ? LR16_WAVES : (h->split_kind == 4) ? PS_CHAINS + (live ? 1 : 0) : (h->split_kind == 1 && live) ? PC8_LIVE_WAVES : 1;
+    const int upw = lr_split ? LR16_WAVES : (h->split_kind == 4) ? PS_CHAINS + (live ? 1 : 0) : (h->split_kind == 3) ? MLB_REC_WAVES : (h->split_kind == 1 && live) ? PC8_LIVE_WAVES : 1;
     const int64_t blocks = P.consumer_blocks + (units + upw - 1) / upw;
     if (blocks <= 0) return DEMCZ_OK;
     if (h->split_kind == 4 || h->lr_spec) {
@@ -863,7 +863,7 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
             }
         }
     } else if (h->split_kind == 3) {
-        const dim3 grid((unsigned)blocks), wg(64);
+        const dim3 grid((unsigned)blocks), wg(64 * MLB_REC_WAVES);
 #define DEMCZ_LAUNCH_MLB_REC(DD, LL)                                                                                         \
         do {                                                                                                                 \
             if (live) hipLaunchKernelGGL((window_kernel_mlb<TARGET_MVNORMAL, DD, LL, true, true>), grid, wg, 0, h->stream, P);   \
@@ -1268,7 +1268,7 @@ static int64_t live_wg_capacity(demcz_handle* h)
         case 10: f = reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 10, 8, true, true>); break;
         case 20: f = reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 20, 16, true, true>); break;
         }
-        if (!f || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 64, 0) != hipSuccess) per_cu = 0;
+        if (!f || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 64 * MLB_REC_WAVES, 0) != hipSuccess) per_cu = 0;
     } else if (h->split_kind == 2 && h->lr_spec) {
         // Every consumer workgroup takes a CU's LDS for itself (the design matrix): the launch's 256 workgroups are resident
         // together iff every CU is there for them, and a CU's other tenants (producer workgroups of the same grid come behind

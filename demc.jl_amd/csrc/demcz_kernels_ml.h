@@ -313,31 +313,39 @@ constexpr int MLB_MAX_BLOCKS = 64;
 
 // REC / LIVE: the split form (demcz_kernels_rec.h, pcb_produce) -- a block-step's draws are read from the
 // records (entries two block-steps ahead, archive rows one ahead) instead of made here.
+// The split form runs FOUR waves to a workgroup -- nothing is shared but the block tables: a workgroup's waves are placed one per
+// SIMD, whereas one-wave workgroups now and then land two to a SIMD (22-30 of C3's 1024 ran a quarter slower than the rest, and
+// in a LIVE launch everybody who draws one of their rows falls back to their pace: scripts/mlb_stamps.py).
+constexpr int MLB_REC_WAVES = 4;
+
 template <int TARGET, int D, int L, bool REC = false, bool LIVE = false>
-__global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
+__global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_mlb(const WindowParams P)
 {
+    constexpr int WPW = REC ? MLB_REC_WAVES : 1;
+    const int wv = (int)(threadIdx.x >> 6);
+    const int64_t vb = (int64_t)blockIdx.x * WPW + wv;          // this wave's index among the consumer waves
     static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "block layout: MvNormal / isotropic targets");
     static_assert(!LIVE || REC, "LIVE launches are a property of the split form");
     if constexpr (REC) {
         if ((int64_t)blockIdx.x >= P.consumer_blocks) {
-            pcb_produce(P, (int64_t)blockIdx.x - P.consumer_blocks);
+            pcb_produce(P, ((int64_t)blockIdx.x - P.consumer_blocks) * WPW + wv);
             return;
         }
     }
     constexpr int G = 64 / L;
     constexpr int NP = (D + L - 1) / L;
     constexpr int DP = ((D + 1) / 2) * 2;
-    __shared__ double2 rec[G * L];
-    __shared__ __attribute__((aligned(16))) double rvec[G * DP];
-    __shared__ __attribute__((aligned(16))) double yvec[G * DP];
+    __shared__ double2 rec[WPW * G * L];
+    __shared__ __attribute__((aligned(16))) double rvec[WPW * G * DP];
+    __shared__ __attribute__((aligned(16))) double yvec[WPW * G * DP];
     __shared__ int slot_l[MLB_MAX_BLOCKS * D];             // position of parameter p in block ib, or -1
     __shared__ int blen_l[MLB_MAX_BLOCKS], boff_l[MLB_MAX_BLOCKS];
     __shared__ double bscale_l[MLB_MAX_BLOCKS];
 
-    const int lane = threadIdx.x;
+    const int lane = (int)(threadIdx.x & 63);
     const int NB = P.Nblocks;
-    for (int i = lane; i < NB * D; i += 64) slot_l[i] = P.slot_of[i];
-    if (lane == 0) {
+    for (int i = (int)threadIdx.x; i < NB * D; i += 64 * WPW) slot_l[i] = P.slot_of[i];
+    if (threadIdx.x == 0) {
         int off = 0;
         for (int ib = 0; ib < NB; ++ib) {
             const int b = P.block_offsets[ib + 1] - P.block_offsets[ib];
@@ -348,10 +356,10 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
             off += 1 + (nn + 1) / 2 + 1;
         }
     }
-    __syncthreads();                                       // one wave per workgroup: table hand-off only
+    __syncthreads();                                       // table hand-off only; the waves share nothing else
 
-    const int r = lane % L, gq = lane / L;
-    const int64_t c = (int64_t)blockIdx.x * G + gq;
+    const int r = lane % L, gq = wv * G + lane / L;        // gq: the chain's slot in the workgroup's LDS arrays
+    const int64_t c = vb * G + lane / L;
     if (c >= P.N) return;
     const uint64_t chain = (uint64_t)(P.chain_id0 + c);
 
@@ -467,7 +475,7 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
     unsigned int cnt_total = 0, cnt_first = 0;             // accept mask by ballot (WindowParams::acc_out)
     const unsigned long long speak64 = __builtin_amdgcn_ballot_w64(r == 0);
 #ifdef DEMCZ_STAMPS
-    unsigned long long sb[6] = {0, 0, 0, 0, 0, 0}, sb_t = __builtin_readcyclecounter();
+    unsigned long long sb[6] = {0, 0, 0, 0, 0, 0}, sb_t = __builtin_readcyclecounter(), sb_waits = 0;
 #define MLB_TICK(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); sb[i] += t_ - sb_t; sb_t = t_; } while (0)
 #else
 #define MLB_TICK(i) do { } while (0)
@@ -484,6 +492,10 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
 #pragma unroll
                 for (int k = 0; k < NP; ++k) bad |= is_sentinel(za[k]) | is_sentinel(zb[k]);
                 int spins = 0;
+                MLB_TICK(4);
+#ifdef DEMCZ_STAMPS
+                if (__builtin_amdgcn_ballot_w64(bad) != 0ull) ++sb_waits;
+#endif
                 while (__builtin_amdgcn_ballot_w64(bad) != 0ull) {       // wave-uniform
                     if (live_poll_abandon(P, spins, bad, (unsigned)(is_sentinel(za[0]) ? row1_c : row2_c), gi)) return;
                     __builtin_amdgcn_s_sleep(1);
@@ -603,12 +615,13 @@ __global__ void __launch_bounds__(64) window_kernel_mlb(const WindowParams P)
         if (p < D) P.Xcur[c + P.N * p] = x[k];
     }
     if (r == 0) P.lpcur[c] = lp;
-    wave_store_counts(P, blockIdx.x, cnt_total, cnt_first);
+    wave_store_counts(P, vb, cnt_total, cnt_first);
 #ifdef DEMCZ_STAMPS
-    if (P.stamps && threadIdx.x == 0 && blockIdx.x < 65536u) {     // [wait+poll+increments, next draws, dependent part, history, -, between]
-        unsigned long long* o = P.stamps + (size_t)blockIdx.x * 16;
+    if (P.stamps && lane == 0 && vb < 65536) {     // [wait+poll+increments, next draws, dependent part, history, -, between]
+        unsigned long long* o = P.stamps + (size_t)vb * 16;
         for (int i = 0; i < 6; ++i) o[8 + i] = sb[i];
         o[14] = (unsigned long long)P.ngen * (unsigned long long)NB;
+        o[15] = sb_waits;
     }
 #endif
 }

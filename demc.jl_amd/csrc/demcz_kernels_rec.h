@@ -91,7 +91,7 @@ __device__ __forceinline__ void pcb_produce(const WindowParams& P, int64_t pb)
 {
     const int64_t nbc = (P.N + 63) / 64;
     const int64_t plane = pb / nbc;                        // wave-uniform
-    const int64_t c = (pb % nbc) * 64 + threadIdx.x;
+    const int64_t c = (pb % nbc) * 64 + (threadIdx.x & 63);
     const int s = (int)(plane % P.S), gi = (int)(plane / P.S);
     if (gi >= P.next_ngen || c >= P.N) return;
     const int role = P.slot_role[s];

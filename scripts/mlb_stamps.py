@@ -29,11 +29,23 @@ lib.demcz_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 assert lib.demcz_debug_read_stamps(e._h, buf.ctypes.data_as(C.c_void_p), nw) == 0
 s = buf.astype(np.float64)
 ns = s[:, 14]
-names = ["wait for the step's rows, sentinel poll, increments", "next block-step's draws: entry -> LDS -> rows asked for", "dependent part: r -> W r -> q -> accept",
-         "history row, append", "-", "between steps"]
+names = ["waiting for rows not yet published (sentinel poll), increments", "next block-step's draws: entry -> LDS -> rows asked for", "dependent part: r -> W r -> q -> accept",
+         "history row, append", "the step's rows and record arrive (asked for a block-step ago)", "between steps"]
 print(f"N={N} gens={G} archive {e.M} rows: last launch {int(ns[0])} block-steps per wave; ticks per block-step, mean over waves / max")
-for i in (0, 1, 2, 3, 5):
+for i in (4, 0, 1, 2, 3, 5):
     v = s[:, 8 + i] / ns
     print(f"  {v.mean():8.0f} {v.max():8.0f}   {names[i]}")
 print(f"  {(s[:, 8:14].sum(axis=1) / ns).mean():8.0f} ticks per block-step in all")
+wt = s[:, 15]
+if wt.sum() > 0:
+    print(f"  block-steps in which a wave found a row missing: {100 * wt.sum() / ns.sum():.1f} %, {s[:, 8].sum() / wt.sum():.0f} ticks per such step (mean); per wave min / max share {100 * (wt / ns).min():.1f} / {100 * (wt / ns).max():.1f} %")
 e.close()
+# per-wave speed without the waits: is somebody slower than the rest all the time?
+work = (s[:, 8:14].sum(axis=1) - s[:, 8]) / ns
+order = np.argsort(work)
+print(f"  ticks per block-step without the waits, per wave: min {work.min():.0f}  5 % {np.percentile(work, 5):.0f}  median {np.median(work):.0f}  95 % {np.percentile(work, 95):.0f}  max {work.max():.0f}")
+print("  slowest waves (workgroup index: ticks):", ", ".join(f"{int(i)}: {work[i]:.0f}" for i in order[-8:]))
+print("  by workgroup index mod 8 (XCD), mean:", " ".join(f"{work[k::8].mean():.0f}" for k in range(8)))
+print("  waits per wave by workgroup index mod 8, mean ticks per step:", " ".join(f"{(s[k::8, 8] / ns[k::8]).mean():.0f}" for k in range(8)))
+print("  by workgroup index, buckets of 64, mean:", " ".join(f"{work[k:k + 64].mean():.0f}" for k in range(0, len(work), 64)))
+print("  workgroups slower than 1.1 x median:", int((work > 1.1 * np.median(work)).sum()), "of", len(work), "; indices", np.nonzero(work > 1.1 * np.median(work))[0][:40].tolist())
