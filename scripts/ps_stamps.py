@@ -50,3 +50,10 @@ print(f"  {ring.mean():10.0f} {ring.max():10.0f}   waiting for the publisher to 
       f"({100 * (nring / np.maximum(n / 2, 1)).mean():.2f} % of boundaries)")
 print(f"  share of the launch spent in those waits: {100 * ((rr + ring) / tot).mean():.1f} %")
 e.close()
+# who waits least is who sets the pace: by position in the workgroup (one of the four chain waves shares its SIMD with the
+# publisher wave) and the spread over all chain waves
+wt = rr / n
+print("  waiting per pass by chain wave of the workgroup (0..3), mean ticks:", " ".join(f"{wt[k::4].mean():.0f}" for k in range(4)))
+print(f"  waiting per pass over all chain waves: min {wt.min():.0f}  5 % {np.percentile(wt, 5):.0f}  median {np.median(wt):.0f}  95 % {np.percentile(wt, 95):.0f}  max {wt.max():.0f}")
+lo = np.argsort(wt)[:12]
+print("  the chain waves that wait least (index: ticks per pass):", ", ".join(f"{int(i)}: {wt[i]:.0f}" for i in lo))
