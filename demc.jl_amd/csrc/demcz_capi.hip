@@ -353,7 +353,7 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
                          : (!h->full_block && cfg->target_kind == DEMCZ_TARGET_MVNORMAL && L > 1) ? 3 : 0;
         h->split_lanes = (kind == 2) ? 16 : (kind == 3) ? L : 0;
         // chains per consumer workgroup
-        h->split_per_wg = (kind == 1) ? PC_CONSUMER_CHAINS : (kind == 2) ? ((cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? LR16_CHAINS : 4)
+        h->split_per_wg = (kind == 1) ? PC_CONSUMER_CHAINS : (kind == 2) ? ((cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? LR16_CHAINS : 4 * ML_WAVES)
                           : (kind == 3) ? MLB_REC_WAVES * (64 / L) : 1;
         const bool split_ok = kind != 0;
         // one wave per chain (demcz_kernels_ps.h): where the replicated consumer is built and a pass's draws fit one DMA
@@ -468,7 +468,7 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         int64_t waves;
         if (h->lanes == DEMCZ_LAYOUT_SPLIT) {
             const int64_t wgs = (N + h->split_per_wg - 1) / h->split_per_wg;
-            waves = wgs * ((h->split_kind == 2 && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? LR16_WAVES : (h->split_kind == 4) ? PS_CHAINS : (h->split_kind == 3) ? MLB_REC_WAVES : 1);
+            waves = wgs * ((h->split_kind == 2 && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? LR16_WAVES : (h->split_kind == 4) ? PS_CHAINS : (h->split_kind == 3) ? MLB_REC_WAVES : (h->split_kind == 2) ? ML_WAVES : 1);
         } else if (h->lanes > 1) {
             const int per_wave = 64 / h->lanes;
             const bool lr = h->full_block && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE;
@@ -669,7 +669,7 @@ template <int TARGET, int D, int L>
 static void launch_window_ml(const demcz_handle* h, const WindowParams& P)
 {
     constexpr int NG = 64 / L;      // chains per workgroup (one wave)
-    hipLaunchKernelGGL((window_kernel_ml<TARGET, D, L>), dim3((unsigned)((P.N + NG - 1) / NG)), dim3(64), 0, h->stream, P);
+    hipLaunchKernelGGL((window_kernel_ml<TARGET, D, L>), dim3((unsigned)((P.N + NG * ML_WAVES - 1) / (NG * ML_WAVES))), dim3(64 * ML_WAVES), 0, h->stream, P);
 }
 
 // which multi-lane layout is compiled for (target, d, full single block): 0 = none
@@ -774,7 +774,7 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
     const bool lr_split = h->split_kind == 2 && h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE;
     const int64_t units = nbc * rec_roles(h) * P.next_ngen;               // 64-lane producer units
     // producer units per workgroup = waves per workgroup of the instantiation that is launched
-    const int upw = lr_split ? LR16_WAVES : (h->split_kind == 4) ? PS_CHAINS + (live ? 1 : 0) : (h->split_kind == 3) ? MLB_REC_WAVES : (h->split_kind == 1 && live) ? PC8_LIVE_WAVES : 1;
+    const int upw = lr_split ? LR16_WAVES : (h->split_kind == 4) ? PS_CHAINS + (live ? 1 : 0) : (h->split_kind == 3) ? MLB_REC_WAVES : (h->split_kind == 2) ? ML_WAVES : (h->split_kind == 1 && live) ? PC8_LIVE_WAVES : 1;
     const int64_t blocks = P.consumer_blocks + (units + upw - 1) / upw;
     if (blocks <= 0) return DEMCZ_OK;
     if (h->split_kind == 4 || h->lr_spec) {
@@ -888,7 +888,7 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
         if (live) hipLaunchKernelGGL((window_kernel_lr16<10, true, true>), grid, wg, dyn, h->stream, P);
         else hipLaunchKernelGGL((window_kernel_lr16<10, true, false>), grid, wg, dyn, h->stream, P);
     } else if (h->split_kind == 2) {
-        const dim3 grid((unsigned)blocks), wg(64);
+        const dim3 grid((unsigned)blocks), wg(64 * ML_WAVES);
         if (live) hipLaunchKernelGGL((window_kernel_ml<TARGET_MVNORMAL, 20, 16, true, true>), grid, wg, 0, h->stream, P);
         else hipLaunchKernelGGL((window_kernel_ml<TARGET_MVNORMAL, 20, 16, true, false>), grid, wg, 0, h->stream, P);
     } else if (h->cfg.target_kind == DEMCZ_TARGET_MVNORMAL) {
@@ -1282,7 +1282,7 @@ static int64_t live_wg_capacity(demcz_handle* h)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_lr16<10, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&window_kernel_lr16<10, true, true>), 64 * LR16_WAVES, dyn) != hipSuccess) per_cu = 0;
     } else if (h->split_kind == 2) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&window_kernel_ml<TARGET_MVNORMAL, 20, 16, true, true>), 64, 0) != hipSuccess) per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&window_kernel_ml<TARGET_MVNORMAL, 20, 16, true, true>), 64 * ML_WAVES, 0) != hipSuccess) per_cu = 0;
     } else if (h->cfg.target_kind == DEMCZ_TARGET_ISO_QUAD) {
         per_cu = pc_live_blocks_per_cu<TARGET_ISO_QUAD, 10>();
     } else {

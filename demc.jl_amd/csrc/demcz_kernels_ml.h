@@ -33,14 +33,24 @@ namespace demcz {
 // drawing: what is left per generation is the state-dependent part.  LIVE: the launch runs through K
 // boundaries and takes appended rows from other waves through the archive itself (sentinel + sc1).
 // Used where the eight-replicated-lanes consumer does not fit (d = 20: 210 whitening coefficients).
+// waves per workgroup of window_kernel_ml: the waves share nothing; a workgroup's waves are placed one per SIMD, one-wave
+// workgroups now and then two to a SIMD (demcz_kernels_ml.h, MLB_REC_WAVES)
+#ifndef DEMCZ_ML_WAVES
+#define DEMCZ_ML_WAVES 4      // (1: 2.68 x 10^9 updates/s at C4's whole population on one GPU, 4: 2.91 x 10^9; scripts/ab_cfg.sh)
+#endif
+constexpr int ML_WAVES = DEMCZ_ML_WAVES;
+
 template <int TARGET, int D, int L, bool REC = false, bool LIVE = false>
-__global__ void __launch_bounds__(64) window_kernel_ml(const WindowParams P)
+__global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowParams P)
 {
+    constexpr int WPW = ML_WAVES;
+    const int wv = (int)(threadIdx.x >> 6);
+    const int64_t vb = (int64_t)blockIdx.x * WPW + wv;          // this wave's index among the chain waves
     static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "lane-cooperative layout: MvNormal / isotropic targets");
     static_assert(!LIVE || REC, "LIVE launches are a property of the split form");
     if constexpr (REC) {
         if ((int64_t)blockIdx.x >= P.consumer_blocks) {
-            pc_produce<D>(P, (int64_t)blockIdx.x - P.consumer_blocks);
+            pc_produce<D>(P, ((int64_t)blockIdx.x - P.consumer_blocks) * WPW + wv, (int)(threadIdx.x & 63));
             return;
         }
     }
@@ -53,14 +63,14 @@ __global__ void __launch_bounds__(64) window_kernel_ml(const WindowParams P)
     constexpr int DP = ((D + 1) / 2) * 2;                  // staging row, 16-byte multiple
     constexpr int YP = DP;                                 // second staging row: y components
 
-    __shared__ double2 rec[NG * S];
-    __shared__ __attribute__((aligned(16))) double rvec[NG * DP];
-    __shared__ __attribute__((aligned(16))) double yvec[NG * YP];
+    __shared__ double2 rec[WPW * NG * S];
+    __shared__ __attribute__((aligned(16))) double rvec[WPW * NG * DP];
+    __shared__ __attribute__((aligned(16))) double yvec[WPW * NG * YP];
 
     const int lane = threadIdx.x & 63;
     const int r = lane % L;
-    const int gq = lane / L;
-    const int64_t c = (int64_t)blockIdx.x * NG + gq;
+    const int gq = wv * NG + lane / L;                     // the chain's slot in the workgroup's LDS arrays
+    const int64_t c = vb * NG + lane / L;
     if (c >= P.N) return;
     constexpr bool active = true;
     const uint64_t chain = (uint64_t)(P.chain_id0 + c);
@@ -298,7 +308,7 @@ __global__ void __launch_bounds__(64) window_kernel_ml(const WindowParams P)
         if (p < D && active) P.Xcur[c + P.N * p] = x[k];
     }
     if (r == 0 && active) P.lpcur[c] = lp;
-    wave_store_counts(P, blockIdx.x, cnt_total, cnt_first);
+    wave_store_counts(P, vb, cnt_total, cnt_first);
 }
 
 // ------------------------------------------------------------------------------------------------
