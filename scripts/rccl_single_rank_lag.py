@@ -1,7 +1,7 @@
 """The sharded data path on ONE GPU (demcz_comm_init with nranks = 1): what a batch of the deferred schedule costs end to end --
 window launch, snapshot, ncclAllGather on the side stream's communicator, scatter kernel, the events between them -- against
 the same schedule without a communicator.  Wall time per generation for E = 10, 25, 50 boundaries per batch.
-usage: python scripts/rccl_single_rank_lag.py [gens]"""
+usage: python scripts/rccl_single_rank_lag.py [gens] [d]     (d = 20: C4's per-GPU shard)"""
 import sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -10,7 +10,8 @@ import numpy as np
 import demc_jl_amd as demc
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-N, d, K = 1024, 5, 10
+N, K = 1024, 10
+d = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 w = demc.workloads.mvnormal_problem(d, N)
 M0 = w["Zinit"].shape[0]
 for comm in (False, True):
