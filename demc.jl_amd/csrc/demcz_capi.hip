@@ -97,6 +97,7 @@ struct demcz_handle {
 #endif
     int64_t rec_cap = 0;              // generations each buffer holds
     int rec_cur = 0;
+    int wpw = 1;                      // waves per consumer workgroup of the lane-cooperative kernels (window_kernel_ml / _mlb): 1 or 4, by population
     bool lr_spec = false;             // split_kind 2, regression target: window_kernel_lr8s (eight chains per workgroup, two generations per pass)
     mutable bool lds_raised = false, lds_raised_spec = false;  // hipFuncAttributeMaxDynamicSharedMemorySize raised on this handle's device (the attribute is per device)
     bool no_live = false;             // a LIVE hand-off failed on this handle: one launch per K-window from then on
@@ -352,9 +353,16 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
                          : split_ml_available(cfg->target_kind, d, h->full_block, cfg->nobs) ? 2
                          : (!h->full_block && cfg->target_kind == DEMCZ_TARGET_MVNORMAL && L > 1) ? 3 : 0;
         h->split_lanes = (kind == 2) ? 16 : (kind == 3) ? L : 0;
+        {   // four-wave workgroups once there is a chain wave for every SIMD (see demcz_kernels_ml.h, ML_WAVES)
+            int cus = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device_id) != hipSuccess) cus = 0;
+            const int lanes_pc = (kind == 2) ? 16 : (L > 1 ? L : 64);
+            const int64_t chain_waves = (cfg->N * lanes_pc + 63) / 64;
+            h->wpw = (cus > 0 && chain_waves >= 4ll * cus) ? ML_WAVES : 1;
+        }
         // chains per consumer workgroup
-        h->split_per_wg = (kind == 1) ? PC_CONSUMER_CHAINS : (kind == 2) ? ((cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? LR16_CHAINS : 4 * ML_WAVES)
-                          : (kind == 3) ? MLB_REC_WAVES * (64 / L) : 1;
+        h->split_per_wg = (kind == 1) ? PC_CONSUMER_CHAINS : (kind == 2) ? ((cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? LR16_CHAINS : 4 * h->wpw)
+                          : (kind == 3) ? h->wpw * (64 / L) : 1;
         const bool split_ok = kind != 0;
         // one wave per chain (demcz_kernels_ps.h): where the replicated consumer is built and a pass's draws fit one DMA
         const bool ps_ok = (kind == 1 || kind == 2) && h->full_block && ps_available(cfg->target_kind, d);
@@ -468,7 +476,7 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         int64_t waves;
         if (h->lanes == DEMCZ_LAYOUT_SPLIT) {
             const int64_t wgs = (N + h->split_per_wg - 1) / h->split_per_wg;
-            waves = wgs * ((h->split_kind == 2 && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? LR16_WAVES : (h->split_kind == 4) ? PS_CHAINS : (h->split_kind == 3) ? MLB_REC_WAVES : (h->split_kind == 2) ? ML_WAVES : 1);
+            waves = wgs * ((h->split_kind == 2 && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? LR16_WAVES : (h->split_kind == 4) ? PS_CHAINS : (h->split_kind == 3 || h->split_kind == 2) ? h->wpw : 1);
         } else if (h->lanes > 1) {
             const int per_wave = 64 / h->lanes;
             const bool lr = h->full_block && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE;
@@ -669,7 +677,8 @@ template <int TARGET, int D, int L>
 static void launch_window_ml(const demcz_handle* h, const WindowParams& P)
 {
     constexpr int NG = 64 / L;      // chains per workgroup (one wave)
-    hipLaunchKernelGGL((window_kernel_ml<TARGET, D, L>), dim3((unsigned)((P.N + NG * ML_WAVES - 1) / (NG * ML_WAVES))), dim3(64 * ML_WAVES), 0, h->stream, P);
+    const int wpw = h->wpw;
+    hipLaunchKernelGGL((window_kernel_ml<TARGET, D, L>), dim3((unsigned)((P.N + NG * wpw - 1) / (NG * wpw))), dim3(64 * wpw), 0, h->stream, P);
 }
 
 // which multi-lane layout is compiled for (target, d, full single block): 0 = none
@@ -774,7 +783,7 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
     const bool lr_split = h->split_kind == 2 && h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE;
     const int64_t units = nbc * rec_roles(h) * P.next_ngen;               // 64-lane producer units
     // producer units per workgroup = waves per workgroup of the instantiation that is launched
-    const int upw = lr_split ? LR16_WAVES : (h->split_kind == 4) ? PS_CHAINS + (live ? 1 : 0) : (h->split_kind == 3) ? MLB_REC_WAVES : (h->split_kind == 2) ? ML_WAVES : (h->split_kind == 1 && live) ? PC8_LIVE_WAVES : 1;
+    const int upw = lr_split ? LR16_WAVES : (h->split_kind == 4) ? PS_CHAINS + (live ? 1 : 0) : (h->split_kind == 3 || h->split_kind == 2) ? h->wpw : (h->split_kind == 1 && live) ? PC8_LIVE_WAVES : 1;
     const int64_t blocks = P.consumer_blocks + (units + upw - 1) / upw;
     if (blocks <= 0) return DEMCZ_OK;
     if (h->split_kind == 4 || h->lr_spec) {
@@ -863,7 +872,7 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
             }
         }
     } else if (h->split_kind == 3) {
-        const dim3 grid((unsigned)blocks), wg(64 * MLB_REC_WAVES);
+        const dim3 grid((unsigned)blocks), wg(64 * h->wpw);
 #define DEMCZ_LAUNCH_MLB_REC(DD, LL)                                                                                         \
         do {                                                                                                                 \
             if (live) hipLaunchKernelGGL((window_kernel_mlb<TARGET_MVNORMAL, DD, LL, true, true>), grid, wg, 0, h->stream, P);   \
@@ -888,7 +897,7 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
         if (live) hipLaunchKernelGGL((window_kernel_lr16<10, true, true>), grid, wg, dyn, h->stream, P);
         else hipLaunchKernelGGL((window_kernel_lr16<10, true, false>), grid, wg, dyn, h->stream, P);
     } else if (h->split_kind == 2) {
-        const dim3 grid((unsigned)blocks), wg(64 * ML_WAVES);
+        const dim3 grid((unsigned)blocks), wg(64 * h->wpw);
         if (live) hipLaunchKernelGGL((window_kernel_ml<TARGET_MVNORMAL, 20, 16, true, true>), grid, wg, 0, h->stream, P);
         else hipLaunchKernelGGL((window_kernel_ml<TARGET_MVNORMAL, 20, 16, true, false>), grid, wg, 0, h->stream, P);
     } else if (h->cfg.target_kind == DEMCZ_TARGET_MVNORMAL) {
@@ -1268,7 +1277,7 @@ static int64_t live_wg_capacity(demcz_handle* h)
         case 10: f = reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 10, 8, true, true>); break;
         case 20: f = reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 20, 16, true, true>); break;
         }
-        if (!f || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 64 * MLB_REC_WAVES, 0) != hipSuccess) per_cu = 0;
+        if (!f || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 64 * h->wpw, 0) != hipSuccess) per_cu = 0;
     } else if (h->split_kind == 2 && h->lr_spec) {
         // Every consumer workgroup takes a CU's LDS for itself (the design matrix): the launch's 256 workgroups are resident
         // together iff every CU is there for them, and a CU's other tenants (producer workgroups of the same grid come behind
@@ -1282,7 +1291,7 @@ static int64_t live_wg_capacity(demcz_handle* h)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_kernel_lr16<10, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_MAX_DYNAMIC_LDS);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&window_kernel_lr16<10, true, true>), 64 * LR16_WAVES, dyn) != hipSuccess) per_cu = 0;
     } else if (h->split_kind == 2) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&window_kernel_ml<TARGET_MVNORMAL, 20, 16, true, true>), 64 * ML_WAVES, 0) != hipSuccess) per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&window_kernel_ml<TARGET_MVNORMAL, 20, 16, true, true>), 64 * h->wpw, 0) != hipSuccess) per_cu = 0;
     } else if (h->cfg.target_kind == DEMCZ_TARGET_ISO_QUAD) {
         per_cu = pc_live_blocks_per_cu<TARGET_ISO_QUAD, 10>();
     } else {

@@ -34,7 +34,9 @@ namespace demcz {
 // boundaries and takes appended rows from other waves through the archive itself (sentinel + sc1).
 // Used where the eight-replicated-lanes consumer does not fit (d = 20: 210 whitening coefficients).
 // waves per workgroup of window_kernel_ml: the waves share nothing; a workgroup's waves are placed one per SIMD, one-wave
-// workgroups now and then two to a SIMD (demcz_kernels_ml.h, MLB_REC_WAVES)
+// workgroups now and then two to a SIMD (demcz_kernels_ml.h, MLB_REC_WAVES).  The host launches ML_WAVES-wave workgroups
+// where the chain waves are at least one per SIMD of the chip, one-wave workgroups below that (they spread over more CUs:
+// d = 20 split form, N = 2048 / 4096: 1.66 / 2.33 x 10^9 updates/s with one wave, 1.58 / 2.62 with four).
 #ifndef DEMCZ_ML_WAVES
 #define DEMCZ_ML_WAVES 4      // (1: 2.68 x 10^9 updates/s at C4's whole population on one GPU, 4: 2.91 x 10^9; scripts/ab_cfg.sh)
 #endif
@@ -43,14 +45,15 @@ constexpr int ML_WAVES = DEMCZ_ML_WAVES;
 template <int TARGET, int D, int L, bool REC = false, bool LIVE = false>
 __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowParams P)
 {
-    constexpr int WPW = ML_WAVES;
+    constexpr int WPW = ML_WAVES;                               // at most; the launch says how many (blockDim.x / 64: 1 or ML_WAVES)
+    const int wpw = (int)(blockDim.x >> 6);
     const int wv = (int)(threadIdx.x >> 6);
-    const int64_t vb = (int64_t)blockIdx.x * WPW + wv;          // this wave's index among the chain waves
+    const int64_t vb = (int64_t)blockIdx.x * wpw + wv;          // this wave's index among the chain waves
     static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "lane-cooperative layout: MvNormal / isotropic targets");
     static_assert(!LIVE || REC, "LIVE launches are a property of the split form");
     if constexpr (REC) {
         if ((int64_t)blockIdx.x >= P.consumer_blocks) {
-            pc_produce<D>(P, ((int64_t)blockIdx.x - P.consumer_blocks) * WPW + wv, (int)(threadIdx.x & 63));
+            pc_produce<D>(P, ((int64_t)blockIdx.x - P.consumer_blocks) * wpw + wv, (int)(threadIdx.x & 63));
             return;
         }
     }
@@ -331,14 +334,15 @@ constexpr int MLB_REC_WAVES = 4;
 template <int TARGET, int D, int L, bool REC = false, bool LIVE = false>
 __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_mlb(const WindowParams P)
 {
-    constexpr int WPW = REC ? MLB_REC_WAVES : 1;
+    constexpr int WPW = REC ? MLB_REC_WAVES : 1;                // at most; the launch says how many (blockDim.x / 64: 1 or MLB_REC_WAVES)
+    const int wpw = (int)(blockDim.x >> 6);
     const int wv = (int)(threadIdx.x >> 6);
-    const int64_t vb = (int64_t)blockIdx.x * WPW + wv;          // this wave's index among the consumer waves
+    const int64_t vb = (int64_t)blockIdx.x * wpw + wv;          // this wave's index among the consumer waves
     static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "block layout: MvNormal / isotropic targets");
     static_assert(!LIVE || REC, "LIVE launches are a property of the split form");
     if constexpr (REC) {
         if ((int64_t)blockIdx.x >= P.consumer_blocks) {
-            pcb_produce(P, ((int64_t)blockIdx.x - P.consumer_blocks) * WPW + wv);
+            pcb_produce(P, ((int64_t)blockIdx.x - P.consumer_blocks) * wpw + wv);
             return;
         }
     }
@@ -354,7 +358,7 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
 
     const int lane = (int)(threadIdx.x & 63);
     const int NB = P.Nblocks;
-    for (int i = (int)threadIdx.x; i < NB * D; i += 64 * WPW) slot_l[i] = P.slot_of[i];
+    for (int i = (int)threadIdx.x; i < NB * D; i += (int)blockDim.x) slot_l[i] = P.slot_of[i];
     if (threadIdx.x == 0) {
         int off = 0;
         for (int ib = 0; ib < NB; ++ib) {
