@@ -24,9 +24,11 @@ for comm in (False, True):
         e.run(1, G, w["gamma"]); e.synchronize()
         e.set_kernel_timing(True)
         t0 = time.perf_counter()
-        e.run(G + 1, 2 * G, w["gamma"]); e.synchronize()
+        e.run(G + 1, 2 * G, w["gamma"])
+        t_enq = time.perf_counter() - t0        # the call returns when everything is enqueued
+        e.synchronize()
         dt = time.perf_counter() - t0
         n, ms = e.get_kernel_time()
-        print(f"{'RCCL nranks=1' if comm else 'no communicator'}  E={E:2d}: {dt / (G / (K * E)) * 1e6:7.1f} us wall per batch, window kernels {ms * 1e3 / max(n, 1):6.1f} us per launch "
+        print(f"{'RCCL nranks=1' if comm else 'no communicator'}  E={E:2d}: {dt / (G / (K * E)) * 1e6:7.1f} us wall per batch ({t_enq / (G / (K * E)) * 1e6:5.1f} us of host time to enqueue it), window kernels {ms * 1e3 / max(n, 1):6.1f} us per launch "
               f"({n} launches) -> {N * G / dt:.3e} updates/s", flush=True)
         e.close()
