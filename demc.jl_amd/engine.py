@@ -172,8 +172,19 @@ class HipEngine:
         self._chk(self._L.demcz_synchronize(self._h))
 
     # -- results ------------------------------------------------------------------------------
-    def get_history(self, g_from, g_to, chain=True, log_obj=True):
+    def get_history(self, g_from, g_to, chain=True, log_obj=True, out=None):
+        """`out`: (chain, log_obj) column-major arrays of at least g_to - g_from + 1 generations to fill instead of new ones
+        (their pages already touched: the download then runs at the link's rate, not at the page faults'); the views of
+        the generations asked for are returned."""
         G = g_to - g_from + 1
+        if out is not None and chain and log_obj:
+            ch_full, lo_full = out
+            ok = (ch_full.flags.f_contiguous and lo_full.flags.f_contiguous and ch_full.shape[:2] == (self.N, self.d)
+                  and lo_full.shape[0] == self.N and ch_full.shape[2] >= G and lo_full.shape[1] >= G
+                  and ch_full.dtype == np.float64 and lo_full.dtype == np.float64)
+            if ok:
+                self._chk(self._L.demcz_get_history(self._h, int(g_from), int(g_to), _lib.ptr(ch_full), _lib.ptr(lo_full)))
+                return ch_full[:, :, :G], lo_full[:, :G]
         ch = np.empty((self.N, self.d, G), order="F") if chain else None
         lo = np.empty((self.N, G), order="F") if log_obj else None
         self._chk(self._L.demcz_get_history(self._h, int(g_from), int(g_to), _lib.ptr(ch), _lib.ptr(lo)))
