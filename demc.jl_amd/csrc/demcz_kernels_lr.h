@@ -394,7 +394,8 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr16(const Wind
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// K1b-3 (third form of the regression kernel): the same instruction fed with EIGHT chains and two generations.  At C5's N = 2048 the kernel above is 128
+// K1b-3 (the regression kernel's third form): the same instruction fed with EIGHT chains and two
+// generations.  At C5's N = 2048 the kernel above is 128
 // workgroups on 256 CUs, and a workgroup's log-density pass takes the same time whatever its 16 columns hold.  Here a
 // workgroup runs eight chains; column jc holds chain jc's proposal of its next generation g, column jc + 8 its proposal of
 // generation g + 1 AS IF GENERATION g WERE REJECTED (x unchanged: the proposal is x + delta(g+1), and delta does not depend
