@@ -97,6 +97,7 @@ struct demcz_handle {
 #endif
     int64_t rec_cap = 0;              // generations each buffer holds
     int rec_cur = 0;
+    bool host_paced = false;          // inside demcz_run_checked (a blocking call): see launch_window_pc
     int wpw = 1;                      // waves per consumer workgroup of the lane-cooperative kernels (window_kernel_ml / _mlb): 1 or 4, by population
     bool lr_spec = false;             // split_kind 2, regression target: window_kernel_lr8s (eight chains per workgroup, two generations per pass)
     mutable bool lds_raised = false, lds_raised_spec = false;  // hipFuncAttributeMaxDynamicSharedMemorySize raised on this handle's device (the attribute is per device)
@@ -844,7 +845,12 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
         }
         if (P.consumer_blocks > 0) {
             if (h->prod_pending[bin]) {            // this launch's records were made on the side stream
-                HIPCHK(h, hipStreamWaitEvent(h->stream, h->prod_done[bin], 0));
+                // A blocking caller (demcz_run_checked) waits for them HERE, on the host: the producer finishes half a launch
+                // before the consumer that is running does, so the host is still ahead of the GPU -- and the window launch goes
+                // into the queue with nothing in front of it.  A wait enqueued while its event is still pending is a barrier
+                // packet between two window kernels (~ 10 us of an idle queue per 1000-generation step, scripts/probes/fixed_cost.py).
+                if (h->host_paced) HIPCHK(h, hipEventSynchronize(h->prod_done[bin]));
+                else HIPCHK(h, hipStreamWaitEvent(h->stream, h->prod_done[bin], 0));
                 h->prod_pending[bin] = false;
             }
             static_assert(PS_CHAINS == LR16_WAVES, "producer units per workgroup of a one-launch grid");
@@ -2397,7 +2403,9 @@ extern "C" int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_
     // everything before this call is verified first, so that a failed LIVE hand-off inside it rolls back to HERE
     int32_t rc = live_verify(h);
     if (rc) return rc;
+    h->host_paced = (getenv("DEMCZ_NO_HOST_PACING") == nullptr);
     rc = run_checked_body(h, g_from, g_to, gamma, temperature, every, threshold, g_stop, n_checks, rhat_max, n_max, rhat_last);
+    h->host_paced = false;
     if (h->live_log.empty()) return rc;
     // the statistics and the stop decision above may rest on a slab whose row hand-off failed: look, and if so
     // undo the whole call and make it again with one launch per K-window (the handle stays in that mode)
