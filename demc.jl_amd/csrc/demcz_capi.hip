@@ -1136,7 +1136,10 @@ static int32_t admit_pending(demcz_handle* h, int64_t g)
     while (!h->pending.empty() && h->pending.front().visible_from <= g) {
         auto pe = h->pending.front();
         if (pe.ev) {
-            HIPCHK(h, hipStreamWaitEvent(h->stream, pe.ev, 0));
+            // (a blocking caller waits on the host: see launch_window_pc -- the exchange of a batch has the whole next batch to
+            //  finish, and the batch after that is only enqueued now)
+            if (h->host_paced) HIPCHK(h, hipEventSynchronize(pe.ev));
+            else HIPCHK(h, hipStreamWaitEvent(h->stream, pe.ev, 0));
             HIPCHK(h, hipEventDestroy(pe.ev));
             h->xseq_waited = std::max(h->xseq_waited, pe.xseq);      // (the side stream runs its exchanges in order)
         }
