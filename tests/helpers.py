@@ -3,8 +3,9 @@ import numpy as np
 
 
 def oracle_sample(O, target, Z0, N, K, G, blocks, eps, gamma, seed, temperature=None, schedule=0, init="last_rows",
-                  X0=None, lp0=None, rng_offset=0):
-    """Oracle twin of demcz_sample's generation loop.  Returns dict(chain, log_obj, X, logp, Z, M, changed)."""
+                  X0=None, lp0=None, rng_offset=0, threads=0):
+    """Oracle twin of demcz_sample's generation loop.  Returns dict(chain, log_obj, X, logp, Z, M, changed).
+    threads > 0: the oracle's OpenMP loop over chains (synchronous schedule; the same bits as one thread)."""
     M0, d = Z0.shape
     Mcap = M0 + -(-N * G // K)
     prob = O.Problem(N, d, K, Mcap, eps, seed, blocks=blocks, target=target.spec())
@@ -16,7 +17,7 @@ def oracle_sample(O, target, Z0, N, K, G, blocks, eps, gamma, seed, temperature=
     Z = np.zeros((Mcap, d), order="F")
     Z[:M0] = Z0
     M, chain, lobj, changed = O.run(prob, X, lp, Z, M0, 1, G, gamma, temperature=temperature, schedule=schedule,
-                                     rng_offset=rng_offset)
+                                     rng_offset=rng_offset, threads=threads)
     return dict(chain=chain, log_obj=lobj, X=X, logp=lp, Z=Z[:M].copy(), M=M, changed=changed, prob=prob)
 
 

@@ -11,7 +11,8 @@ import oracle_py as O
 
 class OracleEngine:
     def __init__(self, *, N, d, K, Mcap, Gcap, blockindex, eps_scale, seed, target, chain_id0=0, device_id=0,
-                 stream=None, lanes_per_chain=0):
+                 stream=None, lanes_per_chain=0, threads=0):
+        self.threads = int(threads)        # > 0: the oracle's OpenMP loop over chains (same bits; for the long full-size cases)
         self.N, self.d, self.K, self.Mcap, self.Gcap = N, d, K, Mcap, Gcap
         self.prob = O.Problem(N, d, K, Mcap, eps_scale, seed, blocks=[list(b) for b in blockindex],
                               chain_id0=chain_id0, target=target.spec())
@@ -37,7 +38,7 @@ class OracleEngine:
 
     def run(self, g_from, g_to, gamma, temperature=None):
         M, ch, lo, cg = O.run(self.prob, self.X, self.lp, self.Z, self.M, g_from, g_to, gamma,
-                              temperature=temperature, do_append=not self.external, rng_offset=self.rng_offset)
+                              temperature=temperature, do_append=not self.external, rng_offset=self.rng_offset, threads=self.threads)
         self.M = M
         self.chain[:, :, g_from - 1:g_to] = ch
         self.log_obj[:, g_from - 1:g_to] = lo

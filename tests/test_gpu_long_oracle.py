@@ -1,0 +1,103 @@
+"""Long runs at the BASELINE shapes compared with the CPU ORACLE directly (not with another HIP kernel), bit for bit:
+the wave-per-chain consumer at d = 20 / 10 / 8 (demcz_kernels_pw.h: LDS-DMA with hand-counted waits, LIVE hand-off),
+the regression kernel with two generations per pass at C5's real shape (demcz_kernels_lr.h, window_kernel_lr8s), and the
+four-wave block-update kernel at C3 (demcz_kernels_ml.h, window_kernel_mlb).  What they stand for in the reference:
+src/demcz.jl:80-93, 167-195 and src/demcz_anneal.jl:149-178.  The oracle runs its OpenMP loop over chains (same bits as its
+single-thread loop: tests/test_oracle_sampler.py), so each case costs a few seconds of host time."""
+import functools
+import os
+
+import numpy as np
+import pytest
+
+from helpers import SPLIT, SPLIT_WAVE, oracle_sample
+
+pytestmark = pytest.mark.gpu
+
+THREADS = max(1, min(len(os.sched_getaffinity(0)), 8))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+BLOCKS_D20 = [list(range(0, 5)), list(range(5, 10)), list(range(10, 15)), list(range(15, 20))]
+
+
+def _hip(demc, w, N, d, K, G, blocks, seed, gamma, lanes=0, temperature=None, pieces=None, lag=0):
+    M0 = w["Zinit"].shape[0]
+    e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K + 1), Gcap=G, blockindex=blocks, eps_scale=w["eps_scale"], seed=seed,
+                       target=w["target"], lanes_per_chain=lanes)
+    if lag:
+        e.set_append_lag(lag)
+    e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+    g = 1
+    for n in (pieces or [G]):
+        e.run(g, g + n - 1, gamma, None if temperature is None else temperature[g - 1:g + n - 1])
+        g += n
+    assert g == G + 1
+    ch, lo = e.get_history(1, G)
+    X, lp, Z, M = e.get_state()
+    info, live = e.info(), e.live_status()
+    tot = e.changed_total(1, G)
+    e.close()
+    return dict(chain=ch, log_obj=lo, X=X, logp=lp, Z=Z, M=M, lanes=info["lanes_per_chain"], launches=info["window_launches"],
+                live=live, changed_total=tot)
+
+
+def _same(a, ref):
+    assert np.array_equal(a["chain"], ref["chain"]), "chain history differs from the oracle"
+    assert np.array_equal(a["log_obj"], ref["log_obj"]), "log_obj history differs from the oracle"
+    assert np.array_equal(a["X"], ref["X"]) and np.array_equal(a["logp"], ref["logp"])
+    assert a["M"] == ref["M"] and np.array_equal(a["Z"], ref["Z"]), "archive differs from the oracle"
+    assert a["changed_total"] == int(np.sum(ref["changed"]))
+
+
+@pytest.mark.parametrize("d,G", [(20, 3000), (10, 2000), (8, 2000)])
+def test_wave_per_chain_live_long_run_equals_oracle(demc, oracle, d, G):
+    """window_kernel_pw<0, d, LIVE> at N = 1024, K = 10 (d = 20: C4's per-GPU shard): a few launches of up to ~370-1000
+    generations each, rows handed from wave to wave inside them."""
+    N, K, seed = 1024, 10, 4100 + d
+    w = demc.workloads.mvnormal_problem(d, N)
+    a = _hip(demc, w, N, d, K, G, [range(d)], seed, w["gamma"], pieces=[G // 3, 1, G - G // 3 - 1])
+    assert a["lanes"] == SPLIT_WAVE and a["live"] == (True, 0), (a["lanes"], a["live"])
+    assert a["launches"] < G // K // 4              # LIVE launches: far fewer than one per K-window
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed, threads=THREADS)
+    _same(a, ref)
+
+
+def test_c4_shard_deferred_visibility_long_run_equals_oracle(demc, oracle):
+    """C4's per-GPU shard with append_lag = 2 (the non-LIVE instantiation of window_kernel_pw, one launch per two K-windows, its
+    producer half riding in the same grid) against the oracle-backed emulation of the same visibility rule."""
+    from oracle_engine import OracleEngine
+    d, N, K, G, E, seed = 20, 1024, 10, 1000, 2, 77
+    w = demc.workloads.mvnormal_problem(d, N)
+    a = _hip(demc, w, N, d, K, G, [range(d)], seed, w["gamma"], lag=E, pieces=[333, 667])
+    assert a["lanes"] == SPLIT_WAVE
+    opts = demc.demcopt(d, N=N, K=K, Ngeneration=G, eps_scale=w["eps_scale"], verbose=False, autostop="no")
+    sh = demc.Sharding(mode="host", local_shards=1, host_exchange_always=True)
+    mc, Z = demc.demcz_sample(w["target"], w["Zinit"], opts, seed=seed, sharding=sh, append_lag=E,
+                              engine_factory=functools.partial(OracleEngine, threads=THREADS))
+    assert np.array_equal(a["chain"], mc.chain) and np.array_equal(a["log_obj"], mc.log_obj)
+    assert np.array_equal(a["X"], mc.Xcurrent) and np.array_equal(a["Z"], Z)
+
+
+@pytest.mark.parametrize("gamma,G", [(0.5, 1000), (2.0, 400)])
+def test_c5_regression_two_generations_per_pass_long_run_equals_oracle(demc, oracle, gamma, G):
+    """window_kernel_lr8s<10, LIVE> at C5's real shape (nobs = 1000, N = 2048, tempered).  gamma = 0.5 gives the ~22 %
+    acceptance the annealer's adaptation steers for (second columns are discarded often); gamma = 2.0 is
+    test/example_linreg.jl's (~1 %: nearly every pass resolves two generations)."""
+    d, N, K, seed = 10, 2048, 10, 319531501
+    w = demc.workloads.linreg_problem(d, N)
+    T = np.array([demc.tempbaseline(g, 10000, 3, 1e-3) for g in range(1, G + 1)])
+    a = _hip(demc, w, N, d, K, G, [range(d)], seed, gamma, temperature=T, pieces=[G // 2 + 3, G - G // 2 - 3])
+    assert a["lanes"] == SPLIT
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], gamma, seed, temperature=T, threads=THREADS)
+    _same(a, ref)
+    acc = np.mean(ref["changed"][1:]) / N
+    assert (0.1 < acc < 0.45) if gamma == 0.5 else (acc < 0.1), acc
+
+
+def test_c3_block_updates_long_run_equals_oracle(demc, oracle):
+    """window_kernel_mlb<0, 20, 16, REC, LIVE> with four-wave workgroups at C3 (d = 20 in four blocks of five, N = 4096)."""
+    d, N, K, G, seed = 20, 4096, 10, 1000, 31953150
+    w = demc.workloads.mvnormal_problem(d, N)
+    a = _hip(demc, w, N, d, K, G, BLOCKS_D20, seed, w["gamma"], pieces=[211, 789])
+    assert a["lanes"] == SPLIT
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, BLOCKS_D20, w["eps_scale"], w["gamma"], seed, threads=THREADS)
+    _same(a, ref)
