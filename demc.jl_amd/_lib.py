@@ -40,7 +40,7 @@ SYMBOLS = [
     "demcz_rhat_partial", "demcz_set_rng_offset", "demcz_rhat_array", "demcz_accept_ratio_array",
     "demcz_mean_cov_array", "demcz_set_append_lag", "demcz_run_checked", "demcz_set_kernel_timing",
     "demcz_get_kernel_time", "demcz_set_live_spin_limit", "demcz_get_live_status",
-    "demcz_debug_append_slab", "demcz_get_changed_total",
+    "demcz_debug_append_slab", "demcz_get_changed_total", "demcz_debug_set_live_fault",
 ]
 
 
@@ -131,6 +131,7 @@ def load():
                                        C.POINTER(C.c_uint64), _dp, _dp]
     L.demcz_set_live_spin_limit.argtypes = [C.c_void_p, C.c_int32]
     L.demcz_get_live_status.argtypes = [C.c_void_p, _ip, _ip]
+    L.demcz_debug_set_live_fault.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
     L.demcz_debug_append_slab.argtypes = [C.c_void_p, _dp, C.c_int32, C.c_int32, C.c_int32]
     for name in SYMBOLS:
         fn = getattr(L, name)

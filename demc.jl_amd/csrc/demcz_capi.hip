@@ -104,6 +104,9 @@ struct demcz_handle {
     bool no_live = false;             // a LIVE hand-off failed on this handle: one launch per K-window from then on
     bool live_claimed = false;        // this handle holds its device's LIVE slot (one handle per device at a time)
     unsigned int live_spin_limit = 0; // polls before a LIVE wait gives up (0: the default, demcz_kernels_rec.h)
+    int32_t live_fault_polls = 0;     // demcz_debug_set_live_fault: this poll limit instead of live_spin_limit ...
+    int64_t live_fault_g = 0;         // ... in launches that start at this generation or later (0 polls: off)
+    bool in_checked = false;          // inside demcz_run_checked: the call verifies (and, if need be, redoes) itself as a whole
     // LIVE launches are verified at the next synchronising call; until then the state they started from and the
     // calls made since are kept, so that a failed hand-off is redone with one launch per K-window (live_verify)
     struct RunCall { int64_t g_from, g_to; double gamma; bool tempered; std::vector<double> temperature; };
@@ -1441,7 +1444,10 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     if (!h->replaying && live_span(h) > 0) {
         // this call may issue LIVE launches: they are verified at the next synchronising entry point, and redone
         // from here (live_verify) should a row hand-off inside one of them fail
-        if (h->live_log.size() >= 256) {            // bound the redo: verify now (a synchronisation every 256 calls)
+        // bound the redo: verify now (a synchronisation every 256 calls).  Not inside demcz_run_checked: that call rolls back
+        // to ITS entry and redoes itself from there (statistics and stop decisions included), so the snapshot must not move
+        // into the middle of it.
+        if (h->live_log.size() >= 256 && !h->in_checked) {
             int32_t rcv = live_verify(h);
             if (rcv) return rcv;
         }
@@ -1530,6 +1536,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         const bool live = live_max > 0 && ((w_end - 1) / K - (g - 1) / K) > 0;
         P.live_err = h->d_live_err;
         P.live_spin_limit = h->live_spin_limit ? (int32_t)h->live_spin_limit : LIVE_SPIN_LIMIT;
+        if (h->live_fault_polls > 0 && g >= h->live_fault_g) P.live_spin_limit = h->live_fault_polls;
         P.acc_out = h->d_acc ? h->d_acc + (size_t)h->acc_next * (size_t)h->acc_waves * 2 : nullptr;
         rc = launch_window(h, P, live);
         h->after_launch_ev = nullptr;         // (whatever was recorded before this launch says nothing about it)
@@ -2407,8 +2414,10 @@ extern "C" int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_
     int32_t rc = live_verify(h);
     if (rc) return rc;
     h->host_paced = (getenv("DEMCZ_NO_HOST_PACING") == nullptr);
+    h->in_checked = true;
     rc = run_checked_body(h, g_from, g_to, gamma, temperature, every, threshold, g_stop, n_checks, rhat_max, n_max, rhat_last);
     h->host_paced = false;
+    h->in_checked = false;
     if (h->live_log.empty()) return rc;
     // the statistics and the stop decision above may rest on a slab whose row hand-off failed: look, and if so
     // undo the whole call and make it again with one launch per K-window (the handle stays in that mode)
@@ -2427,6 +2436,14 @@ extern "C" int32_t demcz_set_live_spin_limit(demcz_handle* h, int32_t polls)
 {
     if (!h || polls < 0) return DEMCZ_ERR_INVALID_ARGUMENT;
     h->live_spin_limit = (unsigned int)polls;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_debug_set_live_fault(demcz_handle* h, int32_t polls, int64_t g_from)
+{
+    if (!h || polls < 0 || g_from < 0) return DEMCZ_ERR_INVALID_ARGUMENT;
+    h->live_fault_polls = polls;
+    h->live_fault_g = g_from;
     return DEMCZ_OK;
 }
 

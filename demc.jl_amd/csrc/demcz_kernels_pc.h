@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(LIVE ? 64 * PC8_LIVE_WAVES : 64) window_kernel
         if (threadIdx.x >= 64) {
             const int l = (int)threadIdx.x - 64;
             const int64_t c0 = (int64_t)blockIdx.x * G;
-            unsigned int done = 0u, idle = 0u;
+            unsigned int done = 0u;
             while (true) {
                 const unsigned int seq = __hip_atomic_load(&pub_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (seq != done) {
@@ -89,7 +89,6 @@ __global__ void __launch_bounds__(LIVE ? 64 * PC8_LIVE_WAVES : 64) window_kernel
                     asm volatile("" ::: "memory");
                     ++done;
                     if (l == 0) __hip_atomic_store(&pub_done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    idle = 0u;
                     continue;
                 }
                 if (__hip_atomic_load(&pub_exit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {
@@ -97,8 +96,8 @@ __global__ void __launch_bounds__(LIVE ? 64 * PC8_LIVE_WAVES : 64) window_kernel
                     if (__hip_atomic_load(&pub_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == done) break;
                     continue;
                 }
-                // safety net: a launch that is being abandoned drains even if wave 0 could not say so
-                if ((++idle & 4095u) == 0u && __hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                // (never before wave 0 has said so, not even in a launch that is being abandoned: wave 0 waits for room in
+                //  pub_rows without a poll limit, bounded by this loop's progress -- demcz_kernels_ps.h)
                 __builtin_amdgcn_s_sleep(1);
             }
             return;

@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             const bool pl = lane < PS_CHAINS * D;
             const int cw = pl ? lane / D : 0, pp = pl ? lane % D : 0;
             const int64_t cl = (int64_t)blockIdx.x * PS_CHAINS + cw;
-            unsigned int done = 0u, idle = 0u;
+            unsigned int done = 0u;
             while (true) {
                 // The chain waves reach their boundaries at different moments.  Looking for ready rows only once the
                 // store before this one is complete lets the rows that arrived during its flight leave TOGETHER (a store
@@ -132,15 +132,16 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
                     }
                     asm volatile("" ::: "memory");
                     if (ready && pp == 0) __hip_atomic_store(&pub_done[cw], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    idle = 0u;
                     continue;
                 }
                 // (pub_seq is written before pub_exit: what is read after pub_exit shows set is final)
                 const bool gone = !pl || (__hip_atomic_load(&pub_exit[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u &&
                                           __hip_atomic_load(&pub_seq[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == done);
                 if (__builtin_amdgcn_ballot_w64(!gone) == 0ull) break;
-                // safety net: a launch that is being abandoned drains even if a chain wave could not say so
-                if ((++idle & 4095u) == 0u && __hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                // (The publisher never leaves before its chain waves, not even in a launch that is being abandoned: a chain
+                //  wave that has not seen the error word yet may still be filling the ring, and it waits for room in it
+                //  without a poll limit -- that wait is bounded by THIS loop making progress.  Every way out of a chain wave
+                //  passes through leave(), so `gone` always comes.)
                 __builtin_amdgcn_s_sleep(1);
             }
             return;

@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     if constexpr (LIVE) {
         if (w == PS_CHAINS) {       // the publisher (demcz_kernels_ps.h): element e = (chain wave, p), in rounds of 64
             constexpr int NPL = (PS_CHAINS * D + 63) / 64;
-            unsigned int done[NPL], idle = 0u;
+            unsigned int done[NPL];
 #pragma unroll
             for (int t = 0; t < NPL; ++t) done[t] = 0u;
             while (true) {
@@ -91,9 +91,8 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
                                               __hip_atomic_load(&pub_seq[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == done[t]);
                     allgone &= __builtin_amdgcn_ballot_w64(!gone) == 0ull;
                 }
-                if (any) { idle = 0u; continue; }
-                if (allgone) break;
-                if ((++idle & 4095u) == 0u && __hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                if (any) continue;
+                if (allgone) break;             // (never before its chain waves: demcz_kernels_ps.h)
                 __builtin_amdgcn_s_sleep(1);
             }
             return;

@@ -137,7 +137,9 @@ __device__ __forceinline__ void pcb_produce(const WindowParams& P, int64_t pb)
 //     a stale cached copy can only show the sentinel where the final double is not yet seen, never a wrong value.
 // A wave only ever waits for rows of an EARLIER boundary than the one it is working towards, so the
 // waits cannot form a cycle; all consumer workgroups are single waves and co-resident (N <= 8192:
-// at most 1024 of them on 256 CUs).  A bounded spin turns a lost row into an error word, not a hang.
+// at most 1024 of them on 256 CUs).  A bounded spin turns a lost row into an error word, not a hang.  The one wait
+// without a poll limit -- a chain wave waiting for room in the LDS ring its publisher wave empties -- is bounded by the
+// publisher, which waits for nothing but its own stores and never leaves before its chain waves have.
 constexpr unsigned long long LIVE_SENTINEL = 0xFFF4DEADC0DE5EEDull;
 constexpr int LIVE_SPIN_LIMIT = 1 << 18;      // ~0.1-0.3 s of polling (the default of WindowParams::live_spin_limit)
 

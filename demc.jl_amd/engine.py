@@ -162,6 +162,10 @@ class HipEngine:
         """Diagnostic: polls before a LIVE row wait gives up (tests force the fall-back path with 1)."""
         self._chk(self._L.demcz_set_live_spin_limit(self._h, C.c_int32(int(polls))))
 
+    def debug_set_live_fault(self, polls: int, g_from: int = 0):
+        """Diagnostic: LIVE launches starting at generation g_from or later use the poll limit `polls` (0: off)."""
+        self._chk(self._L.demcz_debug_set_live_fault(self._h, C.c_int32(int(polls)), C.c_int64(int(g_from))))
+
     def live_status(self):
         """Diagnostic: (LIVE launches in use, number of fall-backs to one launch per K-window)."""
         on, redos = C.c_int32(0), C.c_int32(0)

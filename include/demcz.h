@@ -273,6 +273,11 @@ int32_t demcz_selftest_draws(int32_t device_id, uint64_t seed, uint64_t chain, u
 int32_t demcz_set_live_spin_limit(demcz_handle* h, int32_t polls);
 int32_t demcz_get_live_status(const demcz_handle* h, int32_t* live_enabled, int32_t* redos);
 
+/* Fault injection for the LIVE hand-off: LIVE launches whose first generation is >= g_from use the poll limit `polls` instead
+ * of the handle's (demcz_set_live_spin_limit), so that a test can make a hand-off fail LATE in a long call (e.g. in slab 280 of
+ * a 300-slab demcz_run_checked).  polls = 0 switches it off. */
+int32_t demcz_debug_set_live_fault(demcz_handle* h, int32_t polls, int64_t g_from);
+
 /* The scatter step of the sharded K-boundary exchange on caller data: `slab` (host) has the layout an all-gather
  * over R ranks delivers, [R][cnt][d][n_loc] doubles with n_loc = the handle's N; its R*cnt*n_loc rows are appended
  * in the order an unsharded run appends them (boundary, then rank, then chain).  batched = 0: the kernel of the

@@ -196,3 +196,59 @@ def test_ballot_counts_without_a_history_window(demc, oracle):
     assert e.changed_total(52, 100, with_source=True) == (int(ref["changed"][51:].sum()), True)
     assert e.changed_total(1, 100) == int(ref["changed"].sum())
     e.close()
+
+
+@pytest.mark.parametrize("layout,d", [(SPLIT_WAVE, 5), (SPLIT_WAVE, 20), (SPLIT, 5)])
+@pytest.mark.parametrize("polls", [2, 6, 24])
+def test_partial_timeouts_drain_and_are_redone(demc, oracle, layout, d, polls):
+    """A poll limit of a few polls (not 1): short waits succeed, longer ones give up, so SOME waves abandon the launch while the
+    others carry on -- through more boundaries, filling their publisher's LDS ring -- until they see the error word at a later
+    wait or reach the launch's end.  The interleaving ADVICE r2 describes (a chain wave still going after the launch has been
+    given up) must drain: the ring wait is bounded by the publisher wave, which never leaves before its chain waves
+    (demcz_kernels_ps.h), and every row wait is bounded by its poll limit.  K = 2: a boundary every other generation."""
+    N, K, G, seed = 1024, 2, 300, 47
+    w = demc.workloads.mvnormal_problem(d, N)
+    e = _engine(demc, w, N, d, K, G, seed, layout)
+    assert e.info()["lanes_per_chain"] == layout
+    e.set_live_spin_limit(polls)
+    e.run(1, G, w["gamma"])
+    e.synchronize()
+    on, redos = e.live_status()
+    assert redos in (0, 1) and on == (redos == 0)
+    chain, lobj = e.get_history(1, G)
+    X, lp, Z, M = e.get_state()
+    e.close()
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed)
+    assert np.array_equal(chain, ref["chain"]) and np.array_equal(lobj, ref["log_obj"])
+    assert np.array_equal(X, ref["X"]) and M == ref["M"] and np.array_equal(Z, ref["Z"])
+
+
+@pytest.mark.parametrize("threshold", [0.0, 1.5])
+def test_run_checked_of_more_than_256_slabs_redoes_from_its_entry(demc, oracle, threshold):
+    """A demcz_run_checked call of 300 slabs (every = 4) whose hand-off fails in slab 280: the call must roll back to ITS entry
+    and redo itself, not to a snapshot taken by a mid-call verification after 256 logged demcz_run calls.  With a
+    threshold the speculative slab and the stop decision are part of what is redone."""
+    N, d, K, every, seed = 256, 5, 10, 4, 53
+    G = every * 300
+    w = demc.workloads.mvnormal_problem(d, N)
+    res = []
+    for fault in (True, False):
+        e = _engine(demc, w, N, d, K, G, seed, SPLIT_WAVE)
+        if fault:
+            e.debug_set_live_fault(1, every * 280)            # poll limit 1 from slab 280 on
+        g_stop, trace, last = e.run_checked(1, G, w["gamma"], every, threshold)
+        on, redos = e.live_status()
+        assert (redos, on) == ((1, False) if fault else (0, True))
+        ch, lo = e.get_history(1, g_stop)
+        X, lp, Z, M = e.get_state()
+        e.close()
+        res.append((g_stop, trace, last, ch, lo, X, lp, Z, M))
+    a, b = res
+    assert a[0] == b[0] and a[8] == b[8]
+    for x, y in zip(a[1:8], b[1:8]):
+        assert np.array_equal(x, y, equal_nan=True)
+    if threshold == 0.0:
+        ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed)
+        assert np.array_equal(a[3], ref["chain"]) and np.array_equal(a[7], ref["Z"])
+    else:
+        assert a[0] < every * 280 or a[0] == G      # (wherever it stopped, both runs agree; see above)
