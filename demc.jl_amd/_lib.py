@@ -23,7 +23,7 @@ LAYOUT_SPLIT = 100          # producer / consumer split, eight replicated (d <= 
 LAYOUT_SPLIT_WAVE = 164     # the split with one wavefront per chain, five generations per pass (MvNormal, d = 2..5, 8, 10, 20)
 
 TARGET_MVNORMAL, TARGET_ISO_QUAD, TARGET_LINREG_SSE, TARGET_HOST_CALLBACK = 0, 1, 2, 3
-OK, ERR_INVALID_ARGUMENT, ERR_HIP, ERR_CAPACITY, ERR_STATE, ERR_NO_DEVICE = range(6)
+OK, ERR_INVALID_ARGUMENT, ERR_HIP, ERR_CAPACITY, ERR_STATE, ERR_NO_DEVICE, ERR_COMM = range(7)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -41,6 +41,7 @@ SYMBOLS = [
     "demcz_mean_cov_array", "demcz_set_append_lag", "demcz_run_checked", "demcz_set_kernel_timing",
     "demcz_get_kernel_time", "demcz_set_live_spin_limit", "demcz_get_live_status",
     "demcz_debug_append_slab", "demcz_get_changed_total", "demcz_debug_set_live_fault",
+    "demcz_set_comm_timeout", "demcz_debug_stall_exchange",
 ]
 
 
@@ -131,6 +132,8 @@ def load():
                                        C.POINTER(C.c_uint64), _dp, _dp]
     L.demcz_set_live_spin_limit.argtypes = [C.c_void_p, C.c_int32]
     L.demcz_get_live_status.argtypes = [C.c_void_p, _ip, _ip]
+    L.demcz_set_comm_timeout.argtypes = [C.c_void_p, C.c_int64]
+    L.demcz_debug_stall_exchange.argtypes = [C.c_void_p, C.c_int32]
     L.demcz_debug_set_live_fault.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
     L.demcz_debug_append_slab.argtypes = [C.c_void_p, _dp, C.c_int32, C.c_int32, C.c_int32]
     for name in SYMBOLS:

@@ -13,6 +13,8 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <cstdlib>
 #include <deque>
 #include <mutex>
@@ -158,6 +160,12 @@ struct demcz_handle {
     int64_t xseq = 0, xseq_waited = 0, buf_xseq[2] = {0, 0};
     int batch_buf = 0, batch_cnt = 0;
     int64_t batch_base = 0;
+    // comm failure path: every host-side wait of a sharded handle has a deadline (demcz_set_comm_timeout); on expiry, or on an
+    // asynchronous RCCL error, both communicators are aborted and the handle is dead (DEMCZ_ERR_COMM from every call)
+    int64_t comm_timeout_ms = 60000;
+    bool comm_dead = false;
+    int* stall_flag = nullptr;         // pinned; demcz_debug_stall_exchange: the stall kernel spins until it is set
+    int32_t stall_next_ms = 0;
 };
 
 #define HIPCHK(h, expr)                                                                          \
@@ -174,14 +182,121 @@ struct demcz_handle {
         ncclResult_t r_ = (expr);                                                                \
         if (r_ != ncclSuccess) {                                                                 \
             (h)->err = std::string(#expr) + ": " + ncclGetErrorString(r_);                       \
-            return DEMCZ_ERR_HIP;                                                                \
+            return DEMCZ_ERR_COMM;                                                               \
         }                                                                                        \
+    } while (0)
+
+
+#define DEADCHK(h)                                                                               \
+    do {                                                                                         \
+        if ((h)->comm_dead) return DEMCZ_ERR_COMM;                                               \
     } while (0)
 
 static int32_t fail(demcz_handle* h, int32_t code, const std::string& msg)
 {
     if (h) h->err = msg; else g_create_error = msg;
     return code;
+}
+
+// ---- comm failure path ---------------------------------------------------------------------------------------------
+// A sharded handle's streams carry RCCL kernels that wait for PEERS: a dead or wedged peer would make every blocking
+// wait on such a stream (or on an event behind one) wait for ever, on every rank -- the worst failure mode on a shared
+// pool.  So a sharded handle never blocks in the runtime: it polls (hipStreamQuery / hipEventQuery), looks at
+// ncclCommGetAsyncError of both communicators about once a millisecond, and gives up at the deadline
+// (demcz_set_comm_timeout, default 60 s; DEMCZ_COMM_TIMEOUT_MS): ncclCommAbort on both communicators (their kernels
+// leave, the streams drain), the handle is marked dead and DEMCZ_ERR_COMM is returned from this and every later call.
+// A fresh process is the only retry.  Unsharded handles wait in the runtime as before.
+namespace demcz {
+__global__ void stall_kernel(volatile int* release, unsigned long long max_ticks)
+{
+    const unsigned long long t0 = wall_clock64();           // 100 MHz
+    while (*release == 0 && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace demcz
+
+static int32_t comm_fail(demcz_handle* h, const std::string& why)
+{
+    h->comm_dead = true;
+    if (h->stall_flag) *h->stall_flag = 1;                    // (a test's stall kernel leaves at once)
+    if (h->comm_side) (void)ncclCommAbort(h->comm_side);
+    if (h->comm) (void)ncclCommAbort(h->comm);
+    h->comm_side = nullptr;                                   // (abort frees them; `comm` stays non-null as the "sharded" mark
+    // bounded drain: with the collectives gone the streams should run dry; do not wait for ever for that either
+    const auto t0 = std::chrono::steady_clock::now();
+    hipStream_t ss[4] = {h->stream, h->comm_stream, h->prod_stream, h->diag_stream};
+    for (hipStream_t st : ss) {
+        if (!st) continue;
+        while (hipStreamQuery(st) == hipErrorNotReady &&
+               std::chrono::steady_clock::now() - t0 < std::chrono::seconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    h->err = "communication failure (" + why + "): both RCCL communicators aborted; the handle is dead -- restart the job in fresh processes";
+    return DEMCZ_ERR_COMM;
+}
+
+template <class Query>
+static int32_t wait_deadline(demcz_handle* h, Query query, const char* what)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    auto last_check = t0;
+    for (unsigned long long polls = 0;; ++polls) {
+        const hipError_t e = query();
+        if (e == hipSuccess) return DEMCZ_OK;
+        if (e != hipErrorNotReady) { h->err = std::string(what) + ": " + hipGetErrorString(e); return DEMCZ_ERR_HIP; }
+        const auto now = std::chrono::steady_clock::now();
+        if (now - last_check >= std::chrono::milliseconds(1)) {
+            last_check = now;
+            for (ncclComm_t c : {h->comm, h->comm_side}) {
+                if (!c) continue;
+                ncclResult_t ar = ncclSuccess;
+                const ncclResult_t qr = ncclCommGetAsyncError(c, &ar);
+                if (qr != ncclSuccess || (ar != ncclSuccess && ar != ncclInProgress))
+                    return comm_fail(h, std::string(what) + ": RCCL reports " + ncclGetErrorString(qr != ncclSuccess ? qr : ar));
+            }
+            if (h->comm_timeout_ms > 0 && now - t0 >= std::chrono::milliseconds(h->comm_timeout_ms))
+                return comm_fail(h, std::string(what) + ": no progress within " + std::to_string(h->comm_timeout_ms) + " ms -- a peer rank is dead or stalled");
+        }
+        if (polls > 2000) std::this_thread::sleep_for(std::chrono::microseconds(20));      // (spin first: most waits are short)
+    }
+}
+
+static int32_t sync_stream(demcz_handle* h, hipStream_t s, const char* what)
+{
+    if (h->comm_dead) return DEMCZ_ERR_COMM;
+    if (!h->comm) {
+        const hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { h->err = std::string(what) + ": hipStreamSynchronize: " + hipGetErrorString(e); return DEMCZ_ERR_HIP; }
+        return DEMCZ_OK;
+    }
+    return wait_deadline(h, [s]() { return hipStreamQuery(s); }, what);
+}
+
+static int32_t sync_event(demcz_handle* h, hipEvent_t ev, const char* what)
+{
+    if (h->comm_dead) return DEMCZ_ERR_COMM;
+    if (!h->comm) {
+        const hipError_t e = hipEventSynchronize(ev);
+        if (e != hipSuccess) { h->err = std::string(what) + ": hipEventSynchronize: " + hipGetErrorString(e); return DEMCZ_ERR_HIP; }
+        return DEMCZ_OK;
+    }
+    return wait_deadline(h, [ev]() { return hipEventQuery(ev); }, what);
+}
+
+#define SYNCCHK(h, s)                                                                            \
+    do {                                                                                         \
+        int32_t rcs_ = sync_stream((h), (s), __func__);                                          \
+        if (rcs_) return rcs_;                                                                   \
+    } while (0)
+
+// test hook (demcz_debug_stall_exchange): a kernel that holds the stream the next collective goes to
+static int32_t maybe_stall(demcz_handle* h, hipStream_t s)
+{
+    if (h->stall_next_ms <= 0) return DEMCZ_OK;
+    if (!h->stall_flag) HIPCHK(h, hipHostMalloc((void**)&h->stall_flag, sizeof(int), hipHostMallocDefault));
+    *h->stall_flag = 0;
+    hipLaunchKernelGGL(stall_kernel, dim3(1), dim3(1), 0, s, (volatile int*)h->stall_flag, (unsigned long long)h->stall_next_ms * 100000ull);
+    HIPCHK(h, hipGetLastError());
+    h->stall_next_ms = 0;
+    return DEMCZ_OK;
 }
 
 static int64_t blockstep_nblk(int b)
@@ -246,7 +361,7 @@ static void free_all(demcz_handle* h)
         if (h->buf_done[b]) (void)hipEventDestroy(h->buf_done[b]);
     }
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
-    if (h->prod_stream) { (void)hipStreamSynchronize(h->prod_stream); (void)hipStreamDestroy(h->prod_stream); }
+    if (h->prod_stream) { if (!h->comm_dead) (void)hipStreamSynchronize(h->prod_stream); (void)hipStreamDestroy(h->prod_stream); }
     for (int b = 0; b < 2; ++b) if (h->prod_done[b]) (void)hipEventDestroy(h->prod_done[b]);
     if (h->prod_gate) (void)hipEventDestroy(h->prod_gate);
     if (h->d_stage) (void)hipHostFree(h->d_stage);
@@ -259,8 +374,11 @@ static void free_all(demcz_handle* h)
     if (h->spec_ev) (void)hipEventDestroy(h->spec_ev);
     if (h->diag_ev) (void)hipEventDestroy(h->diag_ev);
     if (h->diag_stream) (void)hipStreamDestroy(h->diag_stream);
-    if (h->comm_side) (void)ncclCommDestroy(h->comm_side);
-    if (h->comm) (void)ncclCommDestroy(h->comm);
+    if (h->stall_flag) (void)hipHostFree(h->stall_flag);
+    if (!h->comm_dead) {                 // (a dead handle's communicators were aborted, which frees them)
+        if (h->comm_side) (void)ncclCommDestroy(h->comm_side);
+        if (h->comm) (void)ncclCommDestroy(h->comm);
+    }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
 }
 
@@ -506,11 +624,10 @@ extern "C" int32_t demcz_destroy(demcz_handle* h)
 {
     if (!h) return DEMCZ_OK;
     (void)hipSetDevice(h->cfg.device_id);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
-    // (side streams: a producer kernel for a launch that never came, monitoring checks, a batched exchange)
-    if (h->prod_stream) (void)hipStreamSynchronize(h->prod_stream);
-    if (h->diag_stream) (void)hipStreamSynchronize(h->diag_stream);
-    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+    // (side streams: a producer kernel for a launch that never came, monitoring checks, a batched exchange.  A sharded handle
+    //  waits with its deadline here too -- a peer may have died -- and a dead one has already been given its time to drain)
+    for (hipStream_t st : {h->stream, h->prod_stream, h->diag_stream, h->comm_stream})
+        if (st && !h->comm_dead) (void)sync_stream(h, st, "demcz_destroy");
     live_release(h);
     free_all(h);
     delete h;
@@ -528,9 +645,9 @@ static TargetParams target_params(const demcz_handle* h)
 static int32_t ensure_scratch(demcz_handle* h, int64_t n)
 {
     if (n <= h->scratch_cap) return DEMCZ_OK;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->diag_stream) HIPCHK(h, hipStreamSynchronize(h->diag_stream));      // a check may still be reading the old buffer
-    if (h->prod_stream) HIPCHK(h, hipStreamSynchronize(h->prod_stream));      // (the checks of a wave-per-chain handle run there)
+    SYNCCHK(h, h->stream);
+    if (h->diag_stream) SYNCCHK(h, h->diag_stream);      // a check may still be reading the old buffer
+    if (h->prod_stream) SYNCCHK(h, h->prod_stream);      // (the checks of a wave-per-chain handle run there)
     if (h->d_scratch) HIPCHK(h, hipFree(h->d_scratch));
     h->d_scratch = nullptr; h->scratch_cap = 0;
     HIPCHK(h, hipMalloc((void**)&h->d_scratch, (size_t)n * sizeof(double)));
@@ -560,6 +677,7 @@ extern "C" int32_t demcz_set_state(demcz_handle* h, const double* X, const doubl
                                    int64_t ldZ, int64_t M0)
 {
     if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    DEADCHK(h);
     if (!X || !Z) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_set_state: X and Z are required");
     if (M0 < 2) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_set_state: M0 >= 2 needed (two distinct archive rows, demcz.jl:176-179)");
     if (M0 > h->cfg.Mcap || ldZ < M0) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_set_state: M0 exceeds Mcap or ldZ < M0");
@@ -593,7 +711,7 @@ extern "C" int32_t demcz_set_state(demcz_handle* h, const double* X, const doubl
         if (rc) return rc;
     }
     HIPCHK(h, hipMemcpyAsync(h->dlp_origin, h->dlp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    SYNCCHK(h, h->stream);
     h->M = M0;
     h->M_app = M0;
     h->live_log.clear();
@@ -613,6 +731,7 @@ extern "C" int32_t demcz_set_state(demcz_handle* h, const double* X, const doubl
 extern "C" int32_t demcz_get_state(demcz_handle* h, double* X, double* logp, double* Z, int64_t ldZ, int64_t* M)
 {
     if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    DEADCHK(h);
     if (!h->has_state) return fail(h, DEMCZ_ERR_STATE, "demcz_get_state: no state set");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     {
@@ -637,7 +756,7 @@ extern "C" int32_t demcz_get_state(demcz_handle* h, double* X, double* logp, dou
         HIPCHK(h, hipMemcpy2DAsync(Z, (size_t)ldZ * sizeof(double), h->d_scratch, (size_t)Mall * sizeof(double),
                                    (size_t)Mall * sizeof(double), (size_t)d, hipMemcpyDeviceToHost, h->stream));
     }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    SYNCCHK(h, h->stream);
     if (M) *M = h->M_app;
     return DEMCZ_OK;
 }
@@ -852,7 +971,7 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
                 // before the consumer that is running does, so the host is still ahead of the GPU -- and the window launch goes
                 // into the queue with nothing in front of it.  A wait enqueued while its event is still pending is a barrier
                 // packet between two window kernels (~ 10 us of an idle queue per 1000-generation step, scripts/probes/fixed_cost.py).
-                if (h->host_paced) HIPCHK(h, hipEventSynchronize(h->prod_done[bin]));
+                if (h->host_paced) { int32_t rcw = sync_event(h, h->prod_done[bin], "launch_window_pc"); if (rcw) return rcw; }
                 else HIPCHK(h, hipStreamWaitEvent(h->stream, h->prod_done[bin], 0));
                 h->prod_pending[bin] = false;
             }
@@ -935,8 +1054,8 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
 static int32_t rec_reserve(demcz_handle* h, int64_t gens)
 {
     if (gens <= h->rec_cap) return DEMCZ_OK;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->prod_stream) HIPCHK(h, hipStreamSynchronize(h->prod_stream));
+    SYNCCHK(h, h->stream);
+    if (h->prod_stream) SYNCCHK(h, h->prod_stream);
     h->prod_pending[0] = h->prod_pending[1] = false;
     for (int b = 0; b < 2; ++b) {
         if (h->d_rec[b]) HIPCHK(h, hipFree(h->d_rec[b]));
@@ -1091,6 +1210,7 @@ static int32_t append_after_window(demcz_handle* h)
     if (h->comm) {   // also at nranks == 1, so the collective path is exercised on a one-GPU box
         const int64_t total = N * h->nranks;
         if (h->M_app + total > h->cfg.Mcap) return fail(h, DEMCZ_ERR_CAPACITY, "demcz_run: Z capacity exceeded");
+        { int32_t rcs = maybe_stall(h, h->stream); if (rcs) return rcs; }
         NCCLCHK(h, ncclAllGather(h->dX, h->d_gather, (size_t)N * d, ncclDouble, h->comm, h->stream));
         const int64_t tot = total * d;
         hipLaunchKernelGGL(append_gathered_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->dZ,
@@ -1115,6 +1235,7 @@ static int32_t exchange_batch(demcz_handle* h)
     HIPCHK(h, hipEventRecord(ready, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->comm_stream, ready, 0));
     HIPCHK(h, hipEventDestroy(ready));
+    { int32_t rcs = maybe_stall(h, h->comm_stream); if (rcs) return rcs; }
     NCCLCHK(h, ncclAllGather(h->d_send[buf], h->d_recv[buf], (size_t)N * d * cnt, ncclDouble, h->comm_side, h->comm_stream));
     const int64_t tot = N * d * cnt * h->nranks;
     hipLaunchKernelGGL(append_batch_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->comm_stream, h->dZ, h->ZS,
@@ -1141,7 +1262,7 @@ static int32_t admit_pending(demcz_handle* h, int64_t g)
         if (pe.ev) {
             // (a blocking caller waits on the host: see launch_window_pc -- the exchange of a batch has the whole next batch to
             //  finish, and the batch after that is only enqueued now)
-            if (h->host_paced) HIPCHK(h, hipEventSynchronize(pe.ev));
+            if (h->host_paced) { int32_t rcw = sync_event(h, pe.ev, "admit_pending (exchange of a batch)"); if (rcw) return rcw; }
             else HIPCHK(h, hipStreamWaitEvent(h->stream, pe.ev, 0));
             HIPCHK(h, hipEventDestroy(pe.ev));
             h->xseq_waited = std::max(h->xseq_waited, pe.xseq);      // (the side stream runs its exchanges in order)
@@ -1186,9 +1307,9 @@ static int32_t live_rollback(demcz_handle* h, std::vector<demcz_handle::RunCall>
     h->live_log.clear();
     const int64_t N = h->cfg.N;
     const int d = h->cfg.d;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->diag_stream) HIPCHK(h, hipStreamSynchronize(h->diag_stream));
-    if (h->prod_stream) HIPCHK(h, hipStreamSynchronize(h->prod_stream));
+    SYNCCHK(h, h->stream);
+    if (h->diag_stream) SYNCCHK(h, h->diag_stream);
+    if (h->prod_stream) SYNCCHK(h, h->prod_stream);
     HIPCHK(h, hipMemcpyAsync(h->dX, h->d_safe_X, (size_t)N * d * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->dlp, h->d_safe_lp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     if (h->M_app > h->safe_M_app) {
@@ -1198,7 +1319,7 @@ static int32_t live_rollback(demcz_handle* h, std::vector<demcz_handle::RunCall>
         HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipMemsetAsync(h->d_live_err, 0, 4 * sizeof(unsigned int), h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    SYNCCHK(h, h->stream);
     h->M = h->safe_M;
     h->M_app = h->safe_M_app;
     h->g_done = h->safe_g_done;
@@ -1215,8 +1336,9 @@ static int32_t live_rollback(demcz_handle* h, std::vector<demcz_handle::RunCall>
 // per K-window (bit-identical results; the handle stays in that mode).  DEMCZ_OK afterwards means the results are valid.
 static int32_t live_verify(demcz_handle* h)
 {
+    DEADCHK(h);
     if (h->live_log.empty() || h->replaying) return check_live_err(h);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    SYNCCHK(h, h->stream);
     unsigned int e[4] = {0, 0, 0, 0};
     HIPCHK(h, hipMemcpy(e, h->d_live_err, sizeof(e), hipMemcpyDeviceToHost));
     if (!e[0]) { h->live_log.clear(); return DEMCZ_OK; }
@@ -1230,7 +1352,7 @@ static int32_t live_verify(demcz_handle* h)
     }
     h->replaying = false;
     if (rc) return rc;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    SYNCCHK(h, h->stream);
     return check_live_err(h);
 }
 
@@ -1371,6 +1493,7 @@ static int64_t live_span(demcz_handle* h)
 extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, double gamma, const double* temperature)
 {
     if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    DEADCHK(h);
     if (!h->has_state) return fail(h, DEMCZ_ERR_STATE, "demcz_run: call demcz_set_state first");
     if (g_from < 1 || g_to < g_from) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_run: need 1 <= g_from <= g_to");
     if (h->cfg.target_kind == DEMCZ_TARGET_HOST_CALLBACK)
@@ -1396,7 +1519,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     }
     if (temperature) {
         if (G > h->temp_cap) {
-            HIPCHK(h, hipStreamSynchronize(h->stream));
+            SYNCCHK(h, h->stream);
             if (h->dtemp) HIPCHK(h, hipFree(h->dtemp));
             h->dtemp = nullptr; h->temp_cap = 0;
             // (+ 8: the wave-per-chain consumer fetches a pass's temperatures as whole 16-byte pieces, demcz_kernels_ps.h)
@@ -1406,7 +1529,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         }
         // stream-ordered behind earlier windows that still read dtemp
         HIPCHK(h, hipMemcpyAsync(h->dtemp, temperature, (size_t)G * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));   // the caller may reuse its buffer on return
+        SYNCCHK(h, h->stream);   // the caller may reuse its buffer on return
     }
     WindowParams P;
     P.Z = h->dZ; P.Zw = h->dZ; P.ZS = h->ZS;
@@ -1591,10 +1714,11 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
 extern "C" int32_t demcz_synchronize(demcz_handle* h)
 {
     if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    DEADCHK(h);
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
-    if (h->prod_stream) HIPCHK(h, hipStreamSynchronize(h->prod_stream));      // (the next launch's draws, monitoring checks)
+    SYNCCHK(h, h->stream);
+    if (h->comm_stream) SYNCCHK(h, h->comm_stream);
+    if (h->prod_stream) SYNCCHK(h, h->prod_stream);      // (the next launch's draws, monitoring checks)
     return live_verify(h);
 }
 
@@ -1609,6 +1733,7 @@ static int32_t check_hist_range(demcz_handle* h, int64_t g_from, int64_t g_to, c
 extern "C" int32_t demcz_get_history(demcz_handle* h, int64_t g_from, int64_t g_to, double* chain, double* log_obj)
 {
     if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    DEADCHK(h);
     int32_t rc = check_hist_range(h, g_from, g_to, "demcz_get_history");
     if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
@@ -1622,7 +1747,7 @@ extern "C" int32_t demcz_get_history(demcz_handle* h, int64_t g_from, int64_t g_
     if (log_obj)
         HIPCHK(h, hipMemcpyAsync(log_obj, h->dlogobj + (size_t)N * s0, (size_t)N * G * sizeof(double),
                                  hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    SYNCCHK(h, h->stream);
     return DEMCZ_OK;
 }
 
@@ -1646,7 +1771,7 @@ extern "C" int32_t demcz_get_changed(demcz_handle* h, int64_t g_from, int64_t g_
     HIPCHK(h, hipGetLastError());
     static_assert(sizeof(int64_t) == sizeof(long long), "int64 layout");
     HIPCHK(h, hipMemcpyAsync(changed, h->d_scratch, (size_t)G * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    SYNCCHK(h, h->stream);
     return DEMCZ_OK;
 }
 
@@ -1701,7 +1826,7 @@ extern "C" int32_t demcz_get_changed_total(demcz_handle* h, int64_t g_from, int6
         HIPCHK(h, hipGetLastError());
         long long v = 0;
         HIPCHK(h, hipMemcpyAsync(&v, h->d_scratch, sizeof(v), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        SYNCCHK(h, h->stream);
         *total = (int64_t)v;
         if (from_ballots) *from_ballots = 1;
         return DEMCZ_OK;
@@ -1768,7 +1893,7 @@ extern "C" int32_t demcz_rhat_partial(demcz_handle* h, int64_t g_from, int64_t g
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipMemcpyAsync(out, r.sums + d, (size_t)2 * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    SYNCCHK(h, h->stream);
     return DEMCZ_OK;
 }
 
@@ -1840,7 +1965,7 @@ extern "C" int32_t demcz_rhat(demcz_handle* h, int64_t g_from, int64_t g_to, dou
     if (rc) return rc;
     rc = rhat_enqueue(h, g_from, g_to, rhat);
     if (rc) return rc;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    SYNCCHK(h, h->stream);
     return DEMCZ_OK;
 }
 
@@ -1866,7 +1991,7 @@ extern "C" int32_t demcz_accept_ratio(demcz_handle* h, int64_t g_from, int64_t g
     }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(ratio, h->d_scratch, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    SYNCCHK(h, h->stream);
     return DEMCZ_OK;
 }
 
@@ -1897,7 +2022,7 @@ extern "C" int32_t demcz_mean_cov(demcz_handle* h, int64_t g_from, int64_t g_to,
     HIPCHK(h, hipMemcpyAsync(hs.data(), sums, hs.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpy2DAsync(ref.data(), sizeof(double), h->dchain + (size_t)N * d * s0, (size_t)N * sizeof(double),
                                sizeof(double), (size_t)d, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    SYNCCHK(h, h->stream);
     const double cnt = (double)(N * w);
     std::vector<double> dm((size_t)d);      // mean - ref
     for (int p = 0; p < d; ++p) { dm[p] = hs[(size_t)p + (size_t)d * d] / cnt; mean[p] = ref[p] + dm[p]; }
@@ -2001,7 +2126,7 @@ extern "C" int32_t demcz_propose(demcz_handle* h, int64_t g, int32_t ib, double 
                        (size_t)(d + 1) * WINDOW_BS * sizeof(double), h->stream, P, (int)ib, blk0, h->dXprop, h->dlogu);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(Xprop, h->dXprop, (size_t)N * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    SYNCCHK(h, h->stream);
     h->proposal_pending = true;
     return DEMCZ_OK;
 }
@@ -2018,7 +2143,7 @@ extern "C" int32_t demcz_accept_commit(demcz_handle* h, const double* logp_prop,
     hipLaunchKernelGGL(accept_commit_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, N, h->cfg.d, h->dX,
                        h->dlp, h->dXprop, h->d_scratch, h->dlogu, temperature ? 1 : 0, temperature ? *temperature : 1.0);
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    SYNCCHK(h, h->stream);
     h->proposal_pending = false;
     return DEMCZ_OK;
 }
@@ -2072,7 +2197,23 @@ extern "C" int32_t demcz_comm_init(demcz_handle* h, const void* unique_id_128B, 
     NCCLCHK(h, ncclCommInitRank(&h->comm, nranks, id, rank));
     h->nranks = nranks;
     h->rank = rank;
+    if (const char* tenv = getenv("DEMCZ_COMM_TIMEOUT_MS")) h->comm_timeout_ms = std::max<long long>(0, atoll(tenv));
     HIPCHK(h, hipMalloc((void**)&h->d_gather, (size_t)h->cfg.N * h->cfg.d * nranks * sizeof(double)));
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_set_comm_timeout(demcz_handle* h, int64_t milliseconds)
+{
+    if (!h || milliseconds < 0) return DEMCZ_ERR_INVALID_ARGUMENT;
+    h->comm_timeout_ms = milliseconds;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_debug_stall_exchange(demcz_handle* h, int32_t milliseconds)
+{
+    if (!h || milliseconds < 0 || milliseconds > 10000) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (!h->comm) return fail(h, DEMCZ_ERR_STATE, "demcz_debug_stall_exchange: not a sharded handle (demcz_comm_init)");
+    h->stall_next_ms = milliseconds;
     return DEMCZ_OK;
 }
 
@@ -2116,7 +2257,7 @@ extern "C" int32_t demcz_append_rows(demcz_handle* h, const double* rows, int64_
     hipLaunchKernelGGL(append_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->dZ, h->ZS, h->M_app,
                        (const double*)h->d_scratch, nrows, nrows, h->cfg.d);
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipStreamSynchronize(h->stream));   // the caller may reuse `rows` on return
+    SYNCCHK(h, h->stream);   // the caller may reuse `rows` on return
     h->M_app += nrows;
     h->M = h->M_app;
     return DEMCZ_OK;
@@ -2141,10 +2282,11 @@ extern "C" int32_t demcz_set_append_lag(demcz_handle* h, int32_t batches)
         // side stream + double-buffered batch slabs: [E][d][n_loc] out, [R][E][d][n_loc] in
         if (!h->comm_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
         // a communicator of its own for the side stream (collective over the parent: every rank makes this call)
+        // (nothing of the parent communicator may still be queued on the compute stream when it is split)
+        SYNCCHK(h, h->stream);
+        SYNCCHK(h, h->comm_stream);
         if (!h->comm_side) NCCLCHK(h, ncclCommSplit(h->comm, 0, h->rank, &h->comm_side, nullptr));
         const size_t one = (size_t)h->cfg.N * h->cfg.d * sizeof(double);
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->comm_stream));
         for (int b = 0; b < 2; ++b) {
             if (h->d_send[b]) HIPCHK(h, hipFree(h->d_send[b]));
             if (h->d_recv[b]) HIPCHK(h, hipFree(h->d_recv[b]));
@@ -2277,7 +2419,7 @@ extern "C" int32_t demcz_selftest_draws(int32_t device_id, uint64_t seed, uint64
 extern "C" int32_t demcz_debug_read_stamps(demcz_handle* h, unsigned long long* out, int64_t n_wg)
 {
     if (!h || !out || n_wg < 0 || n_wg > DEMCZ_STAMP_WGS || !h->d_stamps) return DEMCZ_ERR_INVALID_ARGUMENT;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    SYNCCHK(h, h->stream);
     HIPCHK(h, hipMemcpy(out, h->d_stamps, (size_t)n_wg * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return DEMCZ_OK;
 }
@@ -2297,7 +2439,7 @@ static int32_t run_checked_body(demcz_handle* h, int64_t g_from, int64_t g_to, d
     const int64_t max_checks = (g_to - g_from + 1) / every + 2;
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     if (max_checks * d > h->pinned_cap) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        SYNCCHK(h, h->stream);
         if (h->pinned_rhat) (void)hipHostFree(h->pinned_rhat);
         h->pinned_rhat = nullptr; h->pinned_cap = 0;
         const int64_t cap = std::max<int64_t>(max_checks, 1024) * d;       // (no reallocation between calls of different length)
@@ -2347,15 +2489,14 @@ static int32_t run_checked_body(demcz_handle* h, int64_t g_from, int64_t g_to, d
                     rc = demcz_run(h, nxt + 1, nn, gamma, nullptr);
                     if (rc) break;
                     ahead = true;
-                    if (hipEventSynchronize(h->spec_ev) != hipSuccess) { rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: synchronise failed"); break; }
-                } else if (hipStreamSynchronize(h->stream) != hipSuccess) {
-                    rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: synchronise failed");
+                    if ((rc = sync_event(h, h->spec_ev, "demcz_run_checked")) != DEMCZ_OK) break;
+                } else if ((rc = sync_stream(h, h->stream, "demcz_run_checked")) != DEMCZ_OK) {
                     break;
                 }
                 if (max_of(slot) < threshold) {                  // demcz.jl:43
                     if (g_stop) *g_stop = nxt;
                     if (ahead) {        // discard the slab that ran ahead
-                        if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: synchronise failed"); break; }
+                        if ((rc = sync_stream(h, h->stream, "demcz_run_checked")) != DEMCZ_OK) break;
                         rc = check_live_err(h);
                         if (rc) break;
                         if (hipMemcpyAsync(h->dX, h->d_spec_X, (size_t)N * d * sizeof(double), hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
@@ -2390,9 +2531,9 @@ static int32_t run_checked_body(demcz_handle* h, int64_t g_from, int64_t g_to, d
         }
         g = nxt + 1;
     }
-    if (rc == DEMCZ_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: synchronise failed");
-    if (rc == DEMCZ_OK && h->diag_stream && hipStreamSynchronize(h->diag_stream) != hipSuccess) rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: synchronise failed");
-    if (rc == DEMCZ_OK && h->prod_stream && hipStreamSynchronize(h->prod_stream) != hipSuccess) rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: synchronise failed");
+    if (rc == DEMCZ_OK) rc = sync_stream(h, h->stream, "demcz_run_checked");
+    if (rc == DEMCZ_OK && h->diag_stream) rc = sync_stream(h, h->diag_stream, "demcz_run_checked");
+    if (rc == DEMCZ_OK && h->prod_stream) rc = sync_stream(h, h->prod_stream, "demcz_run_checked");
     if (rc == DEMCZ_OK) {
         for (int32_t i = 0; i < checks; ++i)
             if (rhat_max && i < n_max) rhat_max[i] = max_of(pinned + (size_t)i * d);
@@ -2407,6 +2548,7 @@ extern "C" int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_
                                      double* rhat_max, int32_t n_max, double* rhat_last)
 {
     if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    DEADCHK(h);
     if (every < 4 || g_from < 1 || g_to < g_from) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_run_checked: need every >= 4 and 1 <= g_from <= g_to");
     if (!h->has_state) return fail(h, DEMCZ_ERR_STATE, "demcz_run_checked: call demcz_set_state first");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
@@ -2421,7 +2563,7 @@ extern "C" int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_
     if (h->live_log.empty()) return rc;
     // the statistics and the stop decision above may rest on a slab whose row hand-off failed: look, and if so
     // undo the whole call and make it again with one launch per K-window (the handle stays in that mode)
-    if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: synchronise failed");
+    SYNCCHK(h, h->stream);
     unsigned int e[4] = {0, 0, 0, 0};
     HIPCHK(h, hipMemcpy(e, h->d_live_err, sizeof(e), hipMemcpyDeviceToHost));
     if (!e[0]) { h->live_log.clear(); return rc; }
@@ -2478,7 +2620,7 @@ extern "C" int32_t demcz_debug_append_slab(demcz_handle* h, const double* slab, 
         hipLaunchKernelGGL(append_gathered_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->dZ, h->ZS,
                            h->M_app, (const double*)h->d_scratch, N, (int)R, d);
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    SYNCCHK(h, h->stream);
     h->M_app += rows;
     h->M = h->M_app;
     rec_invalidate(h);
@@ -2496,7 +2638,7 @@ extern "C" int32_t demcz_get_kernel_time(demcz_handle* h, int64_t* launches, dou
 {
     if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    SYNCCHK(h, h->stream);
     double total = 0.0;
     h->after_launch_ev = nullptr;         // (may be one of the events destroyed below)
     for (auto& pr : h->timed) {

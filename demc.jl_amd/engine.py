@@ -254,6 +254,15 @@ class HipEngine:
         buf = C.create_string_buffer(unique_id, 128)
         self._chk(self._L.demcz_comm_init(self._h, buf, int(nranks), int(rank)))
 
+    def set_comm_timeout(self, milliseconds: int):
+        """Deadline of every host-side wait of a sharded handle; past it the communicators are aborted and calls raise
+        DemczError with code ERR_COMM (0 = wait for ever)."""
+        self._chk(self._L.demcz_set_comm_timeout(self._h, C.c_int64(int(milliseconds))))
+
+    def debug_stall_exchange(self, milliseconds: int):
+        """Diagnostic: hold the next collective back on its stream for `milliseconds` (what a stalled peer looks like)."""
+        self._chk(self._L.demcz_debug_stall_exchange(self._h, C.c_int32(int(milliseconds))))
+
     def set_external_append(self, enabled: bool):
         self._chk(self._L.demcz_set_external_append(self._h, 1 if enabled else 0))
 

@@ -46,7 +46,11 @@ enum demcz_status {
     DEMCZ_ERR_HIP = 2,            /* a HIP runtime call failed (message has hipGetErrorString) */
     DEMCZ_ERR_CAPACITY = 3,       /* Z row capacity or history capacity exceeded               */
     DEMCZ_ERR_STATE = 4,          /* call order: e.g. run before set_state                      */
-    DEMCZ_ERR_NO_DEVICE = 5       /* no gfx950 device visible: there is NO CPU fallback         */
+    DEMCZ_ERR_NO_DEVICE = 5,      /* no gfx950 device visible: there is NO CPU fallback         */
+    DEMCZ_ERR_COMM = 6            /* sharded run: an RCCL call failed, RCCL reported an asynchronous error, or a wait on the
+                                     exchange made no progress within the deadline (demcz_set_comm_timeout) -- a peer rank is
+                                     dead or stalled.  Both communicators have been aborted; the handle only accepts
+                                     demcz_destroy / demcz_last_error from now on.  Restart the job in fresh processes.  */
 };
 
 /* User log-densities the device can evaluate (the reference takes an arbitrary Julia closure,
@@ -190,6 +194,12 @@ int32_t demcz_end_generation(demcz_handle* h, int64_t g);
 int32_t demcz_comm_unique_id(void* unique_id_128B);
 int32_t demcz_comm_init(demcz_handle* h, const void* unique_id_128B, int32_t nranks, int32_t rank);
 
+/* Deadline of every host-side wait of a sharded handle (a stream or event behind an RCCL collective): default 60 000 ms, or
+ * the environment variable DEMCZ_COMM_TIMEOUT_MS at demcz_comm_init; 0 = wait for ever.  While it waits the library polls
+ * ncclCommGetAsyncError about once a millisecond.  On expiry or on an asynchronous error: ncclCommAbort on the handle's
+ * communicators and DEMCZ_ERR_COMM (the reference's counterpart: pmap at src/demcz.jl:137 throws when a worker dies). */
+int32_t demcz_set_comm_timeout(demcz_handle* h, int64_t milliseconds);
+
 /* Device-pointer access for hosts that do the exchange themselves (e.g. torch.distributed):
  * copy the current N x d states into caller device memory, and append `nrows` rows given as an
  * nrows x d column-major device matrix (ld = ldrows) to Z, bumping M. */
@@ -277,6 +287,11 @@ int32_t demcz_get_live_status(const demcz_handle* h, int32_t* live_enabled, int3
  * of the handle's (demcz_set_live_spin_limit), so that a test can make a hand-off fail LATE in a long call (e.g. in slab 280 of
  * a 300-slab demcz_run_checked).  polls = 0 switches it off. */
 int32_t demcz_debug_set_live_fault(demcz_handle* h, int32_t polls, int64_t g_from);
+
+/* Fault injection for the exchange: the next collective of this (sharded) handle is held back on its stream for `milliseconds`
+ * (at most 10 000; a one-thread kernel that watches a host flag and the clock, so it always ends) -- to a waiting rank exactly
+ * what a stalled peer looks like.  Lets a one-GPU box walk the deadline -> abort -> DEMCZ_ERR_COMM path. */
+int32_t demcz_debug_stall_exchange(demcz_handle* h, int32_t milliseconds);
 
 /* The scatter step of the sharded K-boundary exchange on caller data: `slab` (host) has the layout an all-gather
  * over R ranks delivers, [R][cnt][d][n_loc] doubles with n_loc = the handle's N; its R*cnt*n_loc rows are appended
