@@ -90,7 +90,7 @@ def throughput_point(demc, N, d, K, seed, gens, device_id):
     return {"chains": N, "lanes_per_chain": lanes, "value": N * gens / dt, "achieved_GBps": gbs, "frac_of_8TBps": gbs / 8000.0}
 
 
-def cpu_baseline(w, N, d, K, seed, budget_updates):
+def cpu_baseline(w, N, d, K, seed, budget_updates, M_final):
     """Time the oracle (test infrastructure, used here only as the reported CPU baseline)."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import oracle_py as O
@@ -114,6 +114,33 @@ def cpu_baseline(w, N, d, K, seed, budget_updates):
     out = {"value": N * G / dt, "unit": "chain-updates/s", "cores": 1, "kind": "port",
            "sample": f"oracle/demcz_oracle.c ({'-O3 -march=native' if native else '-O2'}), synchronous schedule, "
                      f"O(1) index draw, N={N} d={d} K={K}, {G} generations incl. history writes, {dt:.1f} s"}
+    # the reference's own order (chain ic+1 sees chain ic's fresh row inside a generation
+    # divisible by K, src/demcz.jl:30-33, 88-91), one thread; and the same with the reference's O(M) index draw
+    # (collect(1:M) + deleteat!, src/demcz.jl:176-178) costed at the archive size this bench run ends with
+    try:
+        Gs = max(K, G // 2 // K * K)
+        Mcap_s = M0 + -(-N * Gs // K)
+        prob_s = O.Problem(N, d, K, Mcap_s, w["eps_scale"], seed, target=w["target"].spec())
+        Xs = np.array(Z0[M0 - N:], order="F")
+        lps = O.logp(prob_s, Xs)
+        Zs = np.zeros((Mcap_s, d), order="F")
+        Zs[:M0] = Z0
+        t0 = time.perf_counter()
+        O.run(prob_s, Xs, lps, Zs, M0, 1, Gs, w["gamma"], history=True, native=native, schedule=O.SCHED_SEQUENTIAL)
+        dts = time.perf_counter() - t0
+        seq = N * Gs / dts
+        out["sequential"] = {"value": seq, "cores": 1, "sample": f"reference order (Gauss-Seidel within a generation), O(1) index draw, {Gs} generations, {dts:.1f} s"}
+        L = O.lib(native)
+        n_rep = max(3, int(1.5e8 // max(M_final, 1)))
+        t0 = time.perf_counter()
+        for i in range(n_rep):
+            L.oracle_faithful_index_cost(int(M_final), (i * 7919) % int(M_final))
+        per = (time.perf_counter() - t0) / n_rep
+        out["faithful"] = {"value": 1.0 / (1.0 / seq + per), "cores": 1, "archive_rows": int(M_final), "index_draw_us": per * 1e6,
+                           "sample": f"sequential row + the reference's O(M) index draw (collect(1:M); deleteat!) emulated at M = {int(M_final)} "
+                                     f"rows (the archive at the end of this bench run): {per * 1e6:.0f} us per proposal, {n_rep} repetitions"}
+    except Exception as e:
+        out["sequential"] = {"value": None, "error": str(e)[:200]}
     # the same loop spread over the host's cores (OpenMP over chains): the "CPU-omp" row, reported beside the
     # single-core figure (`value`/`cores` stay the scalar port)
     try:
@@ -175,7 +202,8 @@ def tune_append_lag(dist, torch, n_loc, d, K, every, device):
         rows.append((E, float(t.item()) * 1e6))
     chosen = cands[-1]
     for E, us in rows:
-        if us * 1.25 < deferred_batch_us(E, n_loc):
+        # (the batch-time model was measured at d = 5; other dimensions keep the largest batch)
+        if d == 5 and us * 1.25 < deferred_batch_us(E, n_loc):
             chosen = E
             break
     return chosen, rows
@@ -193,8 +221,9 @@ def main():
     ap.add_argument("--no-sweep", action="store_true", help="skip the chain-count sweep object")
     ap.add_argument("--lanes-per-chain", type=int, default=0)
     ap.add_argument("--append-lag", type=int, default=-1,
-                    help="demcz_set_append_lag batches; default 0 on one GPU (the reference's schedule), 10 when sharded "
-                         "(the K-boundary all-gather overlaps the next windows)")
+                    help="demcz_set_append_lag batches for `value`.  Default: 0 (rows visible from the next generation on -- the "
+                         "reference's schedule with a synchronous exchange); when sharded the tuned deferred schedule is measured "
+                         "as well and reported as `value_deferred`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the rendezvous (nccl = RCCL; gloo with --dry-run)")
     ap.add_argument("--dry-run", action="store_true",
                     help="everything up to the first GPU call: arguments, rendezvous, sharding plan, the exchange of the 128-byte "
@@ -238,10 +267,21 @@ def main():
         lag = 0
     else:
         lag = 25 if (args.slab_generations // K) % 25 == 0 else 10
+        ok = 1
         try:      # (a failed probe leaves the documented default; a probe cannot change results, only the schedule that is reported)
-            lag, lag_probe = tune_append_lag(dist, torch, n_loc, d, K, args.slab_generations, "cpu" if args.dry_run else "cuda")
+            cand, lag_probe = tune_append_lag(dist, torch, n_loc, d, K, args.slab_generations, "cpu" if args.dry_run else "cuda")
         except Exception as e:
-            lag_probe = f"failed: {e}"
+            ok, cand, lag_probe = 0, lag, f"failed: {e}"
+        # Every rank must run the same batch size (mismatched all-gather counts hang): the probe counts only if it worked on ALL
+        # ranks, and then rank 0's choice is the one taken.
+        dev = "cpu" if args.dry_run else "cuda"
+        flag = torch.tensor([ok], dtype=torch.int64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        pick = torch.tensor([cand if int(flag.item()) == 1 else lag], dtype=torch.int64, device=dev)
+        dist.broadcast(pick, src=0)
+        lag = int(pick.item())
+        if int(flag.item()) != 1 and not isinstance(lag_probe, str):
+            lag_probe = "failed on another rank"
     N = n_loc * world
     every = args.slab_generations
     S = args.steps
@@ -272,57 +312,85 @@ def main():
         return
     stream = torch.cuda.Stream()
     X, logp = demc.initial_state(w["target"], w["Zinit"], N, G, K, None, "last_rows")
-    runner = demc.make_runner(w["target"], w["Zinit"], N, K, G, [range(d)], w["eps_scale"], X, logp, seed=seed,
-                              sharding=sharding, device_id=local_rank, engine_factory=None,
-                              lanes_per_chain=args.lanes_per_chain, stream=stream.cuda_stream, append_lag=lag)
-    eng = runner.engines[0]
-    gens_to_rhat = None
-    rhat_trace = []
 
-    def advance(g_from, g_to, timed):
-        """Generations g_from..g_to with the R-hat check every `every` generations: one library call
-        (demcz_run_checked = the driver loop demcz.jl:30-55 without its stop), the window kernels timed by
-        HIP events on their own stream inside the library.  Returns (ms spent in window kernels, launches)."""
-        nonlocal gens_to_rhat
-        if timed:
-            eng.set_kernel_timing(True)
-        _, trace, _ = runner.run_checked(g_from, g_to, w["gamma"], every, 0.0)
-        first = ((g_from - 1) // every + 1) * every
-        for i, mx in enumerate(trace):
-            gchk = first + i * every
-            rhat_trace.append((gchk, float(mx)))
-            if gens_to_rhat is None and mx < thr:
-                gens_to_rhat = gchk
-        runner.synchronize()
-        if not timed:
-            return 0.0, 0
-        n, ms = eng.get_kernel_time()
-        eng.set_kernel_timing(False)
-        return ms, n
+    def measure(lag_m):
+        """One complete measurement with `lag_m` boundaries per exchange (0: the north star's schedule -- rows visible from the
+        next generation on): runner, W untimed slabs, the fenced timed region of S slabs.  Returns a dict."""
+        runner = demc.make_runner(w["target"], w["Zinit"], N, K, G, [range(d)], w["eps_scale"], X, logp, seed=seed,
+                                  sharding=sharding, device_id=local_rank, engine_factory=None,
+                                  lanes_per_chain=args.lanes_per_chain, stream=stream.cuda_stream, append_lag=lag_m)
+        eng = runner.engines[0]
+        res = {"gens_to_rhat": None, "rhat_trace": []}
 
-    def fence():
-        runner.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        def advance(g_from, g_to, timed):
+            """Generations g_from..g_to with the R-hat check every `every` generations: one library call
+            (demcz_run_checked = the driver loop demcz.jl:30-55 without its stop), the window kernels timed by
+            HIP events on their own stream inside the library.  Returns (ms spent in window kernels, launches)."""
+            if timed:
+                eng.set_kernel_timing(True)
+            _, trace, _ = runner.run_checked(g_from, g_to, w["gamma"], every, 0.0)
+            first = ((g_from - 1) // every + 1) * every
+            for i, mx in enumerate(trace):
+                gchk = first + i * every
+                res["rhat_trace"].append((gchk, float(mx)))
+                if res["gens_to_rhat"] is None and mx < thr:
+                    res["gens_to_rhat"] = gchk
+            runner.synchronize()
+            if not timed:
+                return 0.0, 0
+            n, ms = eng.get_kernel_time()
+            eng.set_kernel_timing(False)
+            return ms, n
+
+        def fence():
+            runner.synchronize()
             torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+                torch.cuda.synchronize()
 
-    advance(1, W * every, False)
-    fence()
-    t0 = time.perf_counter()
-    ev_ms, launches = advance(W * every + 1, G, True)
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        advance(1, W * every, False)
+        fence()
+        t0 = time.perf_counter()
+        ev_ms, launches = advance(W * every + 1, G, True)
+        fence()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        # per-step times as the GPU saw them: start-to-start of consecutive slabs' brackets (device clock; gaps between
+        # launches and the R-hat kernels beside them included), the last step by its own bracket -- SURVEY 8(d): median of repeats
+        try:
+            st, du = eng.get_kernel_time_series()
+            steps_ms = [float(x) for x in np.diff(st)] + ([float(du[-1])] if len(du) else [])
+        except Exception:
+            steps_ms = []
+        res.update(dt=dt, ev_ms=ev_ms, launches=launches, steps_ms=steps_ms,
+                   acc=runner.accept_ratio_mean(G - every + 1, G))          # (a cheap end-of-run sanity check, not timed)
+        res["live_on"], res["live_redos"] = eng.live_status()
+        res["lanes"] = eng.info()["lanes_per_chain"]
+        runner.close()        # (frees the device's LIVE slot for the next measurement / the sweep's handles)
+        return res
 
-    # a cheap end-of-run sanity check on the sampler output (not timed)
-    acc = runner.accept_ratio_mean(G - every + 1, G)
-    live_on, live_redos = eng.live_status()
-    lanes = eng.info()["lanes_per_chain"]
-    runner.close()        # (frees the device's LIVE slot for the sweep's handles)
+    from demc_jl_amd._lib import DemczError, ERR_COMM
+    try:
+        # N > 1: `value` is the north star's schedule ("all-gather ... every K steps": synchronous exchange, rows visible in the
+        # next generation, the sampler the N = 1 line runs); the tuned deferred schedule is measured right after it and reported
+        # beside it as `value_deferred` -- a different sampler (rows visible lag..2 lag windows late), so it never is `value`.
+        both = world > 1 and args.append_lag < 0
+        m = measure(0 if both else lag)
+        md = measure(lag) if both else None
+    except DemczError as e:
+        if e.code == ERR_COMM:
+            # a peer died or stalled: the handle's communicators are aborted.  A fresh process is the only retry -- and no
+            # torch.distributed call here: the other ranks may be gone
+            print(json.dumps({"error": "DEMCZ_ERR_COMM", "rank": rank, "detail": str(e)}), file=sys.stderr, flush=True)
+            os._exit(3)
+        raise
+    dt, ev_ms, launches, lanes = m["dt"], m["ev_ms"], m["launches"], m["lanes"]
+    gens_to_rhat, rhat_trace, acc, live_on, live_redos = m["gens_to_rhat"], m["rhat_trace"], m["acc"], m["live_on"], m["live_redos"]
+    lag_value = 0 if both else lag
 
     if rank == 0:
         B = algorithmic_bytes_per_update(d, K)
@@ -339,18 +407,28 @@ def main():
         out = {
             "metric": "chain-updates/sec (N x gens/s) + gens-to-Rhat<1.05, MvNormal d=5 N=1024",
             "value": N * gens / dt, "unit": "chain-updates/s", "n_gpus": world, "steps": S, "warmup": W,
-            "ms_per_step": dt / S * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / S * 1e3,
+            "ms_per_step_median": float(np.median(m["steps_ms"])) if m["steps_ms"] else None,
+            "ms_per_step_device": {"n": len(m["steps_ms"]), "min": float(np.min(m["steps_ms"])) if m["steps_ms"] else None,
+                                   "median": float(np.median(m["steps_ms"])) if m["steps_ms"] else None,
+                                   "max": float(np.max(m["steps_ms"])) if m["steps_ms"] else None,
+                                   "what": "start-to-start of consecutive slabs on the kernel's stream (HIP events), last slab by its own bracket"},
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"C2: MvNormal d={d} correlated Sigma, N={n_loc} chains/GPU x {world} GPU, K={K}, "
                                    f"gamma=2.38, eps=1e-5; step = one autostop slab = {every} generations with full "
-                                   f"history + Z append every K + the slab's split-Rhat check (demcz.jl:30-55)",
+                                   f"history + Z append every K + the slab's split-Rhat check (demcz.jl:30-55); "
+                                   + ("`value`: rows visible from the next generation on (append_lag 0"
+                                      + (", synchronous RCCL all-gather every K generations)" if world > 1 else ")")
+                                      if lag_value == 0 else f"`value`: deferred visibility, append_lag {lag_value}"),
                        "chains_total": N, "dim": d, "K": K, "generations_per_step": every, "generations_timed": gens,
-                       "lanes_per_chain": lanes, "append_lag": lag, "append_lag_probe_us": lag_probe,
+                       "lanes_per_chain": lanes, "append_lag": lag_value, "append_lag_probe_us": lag_probe,
                        "live_launches": live_on, "live_redos": live_redos,
                        "parallelism": f"chains sharded x{world}, Z replicated" if world > 1 else "single GPU"},
             "gens_to_rhat_1p05": gens_to_rhat, "rhat_trace": rhat_trace[-12:], "accept_ratio_mean": acc,
             "value_window_kernels_only": N * gens / (ev_ms / 1e3) if ev_ms > 0 else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "frac_of_measured_copy": achieved / 6290.0,        # MI355X_MICROARCH.md: 6.29 TB/s measured copy rate
                          "traffic": traffic[0], "traffic_fetch_x2": traffic[1], "traffic_source": traffic[2],
                          "kernel": (f"demcz::window_kernel_ps<MVNORMAL, {d}, LIVE={'true' if live_on else 'false'}> (+ demcz::produce_kernel<{d}> beside it)"
                                     if lanes == 164 else
@@ -360,6 +438,14 @@ def main():
                          "avg_launch_us": avg_launch_s * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_chain_update": B},
         }
+        if md is not None:
+            out["value_deferred"] = N * gens / md["dt"]
+            out["deferred"] = {"append_lag": lag, "ms_per_step": md["dt"] / S * 1e3, "gens_to_rhat_1p05": md["gens_to_rhat"],
+                               "rhat_trace": md["rhat_trace"][-6:], "accept_ratio_mean": md["acc"],
+                               "ms_per_step_median": float(np.median(md["steps_ms"])) if md["steps_ms"] else None,
+                               "what": f"the same run with the K-boundary rows of {lag} boundaries travelling in one all-gather on a side "
+                                       f"stream and becoming visible {lag}..{2 * lag} windows later (demcz_set_append_lag): a different "
+                                       "sampler from `value`'s -- compare its gens_to_rhat_1p05; `--gpus 1 --append-lag E` is its N = 1 point"}
         if world == 1 and not args.no_sweep and (n_loc, d) == (1024, 5):
             try:     # reporting only: throughput regime of the same path
                 out["chain_count_sweep"] = [throughput_point(demc, n, d, K, seed, g, local_rank)
@@ -368,7 +454,7 @@ def main():
                 out["chain_count_sweep"] = f"failed: {e}"
         if not args.no_cpu_baseline and world == 1:      # (the contract: rank 0 at N = 1 only)
             try:
-                out["cpu_baseline"] = cpu_baseline(demc.workloads.mvnormal_problem(d, n_loc), n_loc, d, K, seed, 1.0e7)
+                out["cpu_baseline"] = cpu_baseline(demc.workloads.mvnormal_problem(d, n_loc), n_loc, d, K, seed, 1.0e7, w["Zinit"].shape[0] + N * (G // K))
             except Exception as e:   # the baseline is reporting only; never fail the bench on it
                 out["cpu_baseline"] = {"value": None, "unit": "chain-updates/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {e}"}

@@ -41,7 +41,7 @@ SYMBOLS = [
     "demcz_mean_cov_array", "demcz_set_append_lag", "demcz_run_checked", "demcz_set_kernel_timing",
     "demcz_get_kernel_time", "demcz_set_live_spin_limit", "demcz_get_live_status",
     "demcz_debug_append_slab", "demcz_get_changed_total", "demcz_debug_set_live_fault",
-    "demcz_set_comm_timeout", "demcz_debug_stall_exchange",
+    "demcz_set_comm_timeout", "demcz_debug_stall_exchange", "demcz_get_kernel_time_series",
 ]
 
 
@@ -132,6 +132,7 @@ def load():
                                        C.POINTER(C.c_uint64), _dp, _dp]
     L.demcz_set_live_spin_limit.argtypes = [C.c_void_p, C.c_int32]
     L.demcz_get_live_status.argtypes = [C.c_void_p, _ip, _ip]
+    L.demcz_get_kernel_time_series.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _ip]
     L.demcz_set_comm_timeout.argtypes = [C.c_void_p, C.c_int64]
     L.demcz_debug_stall_exchange.argtypes = [C.c_void_p, C.c_int32]
     L.demcz_debug_set_live_fault.argtypes = [C.c_void_p, C.c_int32, C.c_int64]

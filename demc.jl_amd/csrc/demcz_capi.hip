@@ -85,6 +85,7 @@ struct demcz_handle {
     int64_t pinned_cap = 0;
     bool timing = false;              // demcz_set_kernel_timing: events around every window-kernel launch
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
+    std::vector<double> series_start_ms, series_dur_ms;     // of the brackets the last demcz_get_kernel_time summed up
     int64_t timed_launches = 0;
     int64_t live_wg_cap = -1;         // consumer workgroups a LIVE launch may have (all must be resident at once); -1: not asked yet
     int split_kind = 0;               // lanes == DEMCZ_LAYOUT_SPLIT: 4 = one wave per chain, speculating (ps); 1 = eight replicated lanes per chain (pc8), 2 = 16 cooperating
@@ -2641,10 +2642,15 @@ extern "C" int32_t demcz_get_kernel_time(demcz_handle* h, int64_t* launches, dou
     SYNCCHK(h, h->stream);
     double total = 0.0;
     h->after_launch_ev = nullptr;         // (may be one of the events destroyed below)
+    h->series_start_ms.clear(); h->series_dur_ms.clear();
     for (auto& pr : h->timed) {
-        float ms = 0.0f;
+        float ms = 0.0f, st = 0.0f;
         HIPCHK(h, hipEventElapsedTime(&ms, pr.first, pr.second));
+        if (&pr != &h->timed.front()) HIPCHK(h, hipEventElapsedTime(&st, h->timed.front().first, pr.first));   // (an event against itself faults in the runtime)
+        h->series_start_ms.push_back(st); h->series_dur_ms.push_back(ms);
         total += ms;
+    }
+    for (auto& pr : h->timed) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
     }
@@ -2652,5 +2658,17 @@ extern "C" int32_t demcz_get_kernel_time(demcz_handle* h, int64_t* launches, dou
     if (milliseconds) *milliseconds = total;
     h->timed.clear();
     h->timed_launches = 0;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_get_kernel_time_series(demcz_handle* h, int32_t cap, double* start_ms, double* duration_ms, int32_t* n)
+{
+    if (!h || cap < 0 || !n) return DEMCZ_ERR_INVALID_ARGUMENT;
+    const int32_t m = (int32_t)std::min<size_t>(h->series_start_ms.size(), (size_t)cap);
+    for (int32_t i = 0; i < m; ++i) {
+        if (start_ms) start_ms[i] = h->series_start_ms[i];
+        if (duration_ms) duration_ms[i] = h->series_dur_ms[i];
+    }
+    *n = (int32_t)h->series_start_ms.size();
     return DEMCZ_OK;
 }

@@ -158,6 +158,14 @@ class HipEngine:
         self._chk(self._L.demcz_get_kernel_time(self._h, C.byref(n), C.byref(ms)))
         return int(n.value), float(ms.value)
 
+    def get_kernel_time_series(self):
+        """(start_ms, duration_ms) arrays of the brackets the last get_kernel_time() summed up: one per demcz_run call."""
+        n = C.c_int32(0)
+        self._chk(self._L.demcz_get_kernel_time_series(self._h, 0, None, None, C.byref(n)))
+        st, du = np.zeros(n.value), np.zeros(n.value)
+        self._chk(self._L.demcz_get_kernel_time_series(self._h, n.value, _lib.ptr(st), _lib.ptr(du), C.byref(n)))
+        return st, du
+
     def set_live_spin_limit(self, polls: int):
         """Diagnostic: polls before a LIVE row wait gives up (tests force the fall-back path with 1)."""
         self._chk(self._L.demcz_set_live_spin_limit(self._h, C.c_int32(int(polls))))

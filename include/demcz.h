@@ -267,6 +267,12 @@ int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_to, double 
 int32_t demcz_set_kernel_timing(demcz_handle* h, int32_t enabled);
 int32_t demcz_get_kernel_time(demcz_handle* h, int64_t* launches, double* milliseconds);
 
+/* The brackets the last demcz_get_kernel_time call summed up, one per demcz_run call (inside demcz_run_checked: one per slab):
+ * start_ms[i] = start of bracket i on the device clock, relative to the first bracket's start; duration_ms[i] = its length.
+ * start_ms[i+1] - start_ms[i] is therefore the wall time of step i as the GPU saw it, gaps between launches included -- what
+ * bench.py takes its median step time from.  At most `cap` entries are written; *n = entries available. */
+int32_t demcz_get_kernel_time_series(demcz_handle* h, int32_t cap, double* start_ms, double* duration_ms, int32_t* n);
+
 /* Device self-test of the draw pipeline: for Philox block blk0+i of the
  * stream of global chain `chain`, words[2i..2i+1] = the two raw 64-bit words,
  * normals[2i..2i+1] = the Box-Muller pair, logu[i] = log(u_open(word 0)).  Lets an integrator
