@@ -250,7 +250,8 @@ class _Runner:
     def changed_total(self, g_from, g_to):
         """sum(diff(log_obj[:, g_from-1:g_to], dims=2) .!= 0) over all chains: the count of demcz_anneal.jl:50, from the
         window kernels' ballot counters (no pass over the history)."""
-        t = float(sum(e.changed_total(g_from, g_to) for e in self.engines))
+        t = float(sum(e.changed_total(g_from, g_to) if hasattr(e, "changed_total") else int(np.sum(e.get_changed(g_from, g_to)))
+                      for e in self.engines))
         if self.sh is not None and self.sh.world_size > 1:
             t = float(self.sh.all_reduce_sum(np.array([t]))[0])
         return int(t)

@@ -79,9 +79,15 @@ def convergence_check(chain, log_obj, figure_path=None, verbose=True, parnames=N
     return acc, Rhat
 
 
-def save_checkpoint(path, mc: MC, Z, generations_done=None, seed=0, opts=None):
+_NO_SEED = object()
+
+
+def save_checkpoint(path, mc: MC, Z, generations_done=None, seed=_NO_SEED, opts=None):
     """Everything a resumed run needs: final states, archive, how far the RNG streams have advanced
-    (`generations_done`; default: what `mc` itself records, MC.generations_drawn)."""
+    (`generations_done`; default: what `mc` itself records, MC.generations_drawn) and the `seed` of the run -- REQUIRED
+    (positionally or by keyword): a checkpoint written with a wrong seed resumes on another Philox stream, silently."""
+    if seed is _NO_SEED:
+        raise TypeError("save_checkpoint: pass the run's seed (the one given to demcz_sample / demcz_anneal)")
     if generations_done is None:
         generations_done = mc.generations_drawn
     np.savez_compressed(path, Xcurrent=mc.Xcurrent, log_objcurrent=mc.log_objcurrent, last_chain=mc.chain[:, :, -1:],

@@ -2,7 +2,7 @@
 # chrished/DEMC.jl: demcopt / demcz_sample / demcz_anneal returning (mc::MC, Z::Matrix{Float64}).
 #
 # STATUS: written against include/demcz.h but NOT executed -- there is no Julia in the build image or
-# on the GPU box.  The identical call sequence is what the Python host (demc.jl_amd/sampler.py) runs
+# on the GPU box (every ccall is checked against the header by tests/test_julia_shim.py).  The identical call sequence is what the Python host (demc.jl_amd/sampler.py) runs
 # and what tests/ verify; keep the two in step.  Field order of DemczConfig must match demcz_config.
 module DEMCHip
 
@@ -60,7 +60,7 @@ chk(rc, h=C_NULL) = rc == 0 ? nothing : throw(DemczError(rc, lasterr(h)))
 # (demcz.jl:189 calls it once per block-step per chain; such a closure runs on the host, see run_closure! below)
 const LogObj = Union{DeviceTarget,Function}
 
-function create(t::LogObj, N, d, K, Mcap, Gcap, blockindex, eps_scale, seed; device_id=0)
+function create(t::LogObj, N, d, K, Mcap, Gcap, blockindex, eps_scale, seed; device_id=0, chain_id0=0)
     offs = Int32[0; cumsum(length.(blockindex))]
     idx = Int32[i - 1 for b in blockindex for i in b]                       # 1-based -> 0-based
     eps = Vector{Float64}(eps_scale)
@@ -71,7 +71,7 @@ function create(t::LogObj, N, d, K, Mcap, Gcap, blockindex, eps_scale, seed; dev
             t isa IsoQuadTarget ? (Int32(1), pointer(t.μ), Ptr{Float64}(C_NULL), 0.0, Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0) :
             t isa LinRegSSETarget ? (Int32(2), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0.0, pointer(t.X), pointer(t.y), size(t.X, 1)) :
             (Int32(3), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0.0, Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0)   # DEMCZ_TARGET_HOST_CALLBACK
-        cfg = DemczConfig(N, 0, d, K, Mcap, Gcap, length(blockindex), pointer(offs), pointer(idx), pointer(eps),
+        cfg = DemczConfig(N, chain_id0, d, K, Mcap, Gcap, length(blockindex), pointer(offs), pointer(idx), pointer(eps),
                           UInt64(seed), device_id, kind, mu, W, c0, design, y, nobs, C_NULL, 0, 0)
         chk(ccall((:demcz_create, libdemcz), Int32, (Ref{Ptr{Cvoid}}, Ref{DemczConfig}), h, cfg))   # config is copied
     end
@@ -167,18 +167,141 @@ function start_state(t::LogObj, Zmat, N, prevrun)
     Matrix{Float64}(prevrun.chain[:, :, end]), Vector{Float64}(prevrun.log_objcurrent[:, end]), size(prevrun.chain, 3)   # :20-21
 end
 
+# ---- multi-GPU: one Julia process per GPU (Distributed.jl workers, MPI.jl ranks ...), chains split in rank order, Z replicated.
+# The role of src/demcz.jl:101-165 (demcz_sample_par: one chain per worker process around a SharedArray Z): the library
+# all-gathers the K-boundary rows over RCCL and all-reduces the R-hat moments itself; the host only carries the 128-byte id.
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    chk(ccall((:demcz_comm_unique_id, libdemcz), Int32, (Ptr{Cvoid},), id)); id
+end
+comm_init(h, id::Vector{UInt8}, nranks, rank) =
+    chk(ccall((:demcz_comm_init, libdemcz), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32), h, id, nranks, rank), h)
+# E = 0: rows appended after generation jK are drawn from generation jK+1 on (a synchronous all-gather every K generations);
+# E >= 1: batches of E boundaries travel in one all-gather on a side stream and become visible E windows after the batch closes
+set_append_lag(h, E) = chk(ccall((:demcz_set_append_lag, libdemcz), Int32, (Ptr{Cvoid}, Int32), h, E), h)
+# deadline of every wait behind a collective; past it the communicators are aborted and calls throw DemczError(6 = DEMCZ_ERR_COMM)
+set_comm_timeout(h, ms) = chk(ccall((:demcz_set_comm_timeout, libdemcz), Int32, (Ptr{Cvoid}, Int64), h, ms), h)
+synchronize(h) = chk(ccall((:demcz_synchronize, libdemcz), Int32, (Ptr{Cvoid},), h), h)
+
+"""
+    demcz_sample_par(t, Zmat, opts; sync_every=1000, prevrun=nothing, rank, nranks, unique_id, device_id=rank, append_lag=0, seed=0)
+
+The sharded counterpart of `demcz_sample_par(logobj, Zmat, opts; sync_every, prevrun)` (src/demcz.jl:101-103): every rank
+(one process per GPU) makes this call with the same arguments; rank `r` runs chains `r*N/nranks+1 : (r+1)*N/nranks` of the
+`opts.N` chains against its own replica of Z.  `unique_id` = `comm_unique_id()` of rank 0, broadcast by the caller's transport
+(`Distributed.remotecall_fetch`, `MPI.Bcast!` ...).  The R-hat test runs every `sync_every` generations over ALL chains, as the
+reference's does per slab (demcz.jl:141-156); every rank takes the same stop decision.  Returns `(mc, Z)` with `mc` holding
+THIS rank's chains and `Z` the full archive (identical on all ranks).  `prevrun` = this rank's shard of an earlier result.
+"""
+function demcz_sample_par(t::DeviceTarget, Zmat, opts::DEMCopt; sync_every=1000, prevrun=nothing, rank::Integer, nranks::Integer,
+                          unique_id::Vector{UInt8}, device_id=rank, append_lag=0, seed=0, comm_timeout_ms=60000)
+    N, K, G = opts.N, opts.K, opts.Ngeneration
+    N % nranks == 0 || error("opts.N must be divisible by the number of ranks")
+    nloc = N ÷ nranks
+    nrowZ, d = size(Zmat)
+    Mcap = nrowZ + Int(ceil(N * G / K))                                                # demcz.jl:109
+    c0 = rank * nloc
+    if prevrun === nothing
+        X = Matrix{Float64}(Zmat[end-N+1+c0:end-N+c0+nloc, :]); lp = nothing; drawn = 0   # demcz.jl:113: the last N rows, this rank's part
+    else
+        X = Matrix{Float64}(prevrun.chain[:, :, end]); lp = Vector{Float64}(prevrun.log_objcurrent[:, end]); drawn = size(prevrun.chain, 3)
+    end
+    h = create(t, nloc, d, K, Mcap, G, opts.blockindex, opts.eps_scale, seed; device_id=device_id, chain_id0=c0)
+    try
+        comm_init(h, unique_id, nranks, rank)
+        set_comm_timeout(h, comm_timeout_ms)
+        append_lag == 0 || set_append_lag(h, append_lag)
+        set_state(h, X, lp, Matrix{Float64}(Zmat))
+        drawn == 0 || set_rng_offset(h, drawn)
+        ig = opts.autostop == :Rhat ? run_checked!(h, 1, G, opts.γ, sync_every, opts.autostop_Rhat) :      # demcz.jl:129-156
+                                      (run!(h, 1, G, opts.γ); synchronize(h); G)
+        chain, log_obj = history(h, nloc, d, 1, ig)
+        Xc, lpc, Z = state(h, nloc, d)
+        mc = prevrun === nothing ? MC(chain, log_obj, Xc, lpc) :
+             MC(cat(prevrun.chain, chain, dims=3), cat(prevrun.log_obj, log_obj, dims=2), Xc, lpc)
+        return mc, Z
+    finally
+        destroy(h)
+    end
+end
+
+# ---- diagnostics of src/utils.jl with the reference's names, reduced on the device ----------------------------------
+# (host arrays in, as the reference's examples pass them: test/example_normpdf.jl:35-47; the arrays are uploaded once and
+#  reduced by the kernels the autostop uses)
+function Rhat_gelman(chain::Array{Float64,3}, Npop=size(chain, 1), Ngeneration=size(chain, 3), Npar=size(chain, 2); device_id=0)   # utils.jl:2-20
+    r = zeros(Npar)
+    c = Ngeneration == size(chain, 3) ? chain : chain[:, :, 1:Ngeneration]
+    chk(ccall((:demcz_rhat_array, libdemcz), Int32, (Int32, Ptr{Float64}, Int64, Int32, Int64, Ptr{Float64}), device_id, c, Npop, Npar, Ngeneration, r)); r
+end
+function flatten_chain(chain, Npop=size(chain, 1), Ngeneration=size(chain, 3), Npar=size(chain, 2))          # utils.jl:22-32
+    reshape(permutedims(chain[:, :, 1:Ngeneration], (2, 1, 3)), Npar, Npop * Ngeneration)                    # column ig, ic -> (ig-1)*Npop + ic
+end
+function accept_ratio(log_obj::Matrix{Float64}; device_id=0)                                                 # utils.jl:61
+    a = zeros(size(log_obj, 1))
+    chk(ccall((:demcz_accept_ratio_array, libdemcz), Int32, (Int32, Ptr{Float64}, Int64, Int64, Ptr{Float64}), device_id, log_obj, size(log_obj, 1), size(log_obj, 2), a)); a
+end
+function mean_cov_chain(chain::Array{Float64,3}, Npop=size(chain, 1), Ngeneration=size(chain, 3), Npar=size(chain, 2); device_id=0)   # utils.jl:96-111
+    @assert size(chain) == (Npop, Npar, Ngeneration)
+    b = zeros(Npar); cov = zeros(Npar, Npar)
+    chk(ccall((:demcz_mean_cov_array, libdemcz), Int32, (Int32, Ptr{Float64}, Int64, Int32, Int64, Ptr{Float64}, Ptr{Float64}), device_id, chain, Npop, Npar, Ngeneration, b, cov))
+    b, cov
+end
+function convergence_check(chain::Array{Float64,3}, log_obj::Matrix{Float64}, figure_path=nothing; verbose=true, parnames=[], device_id=0)   # utils.jl:34-94
+    Npop, Npar, Ngeneration = size(chain)
+    @assert size(log_obj) == (Npop, Ngeneration) "log_obj must be Npop x Ngeneration"                        # utils.jl:40-46
+    ar = accept_ratio(log_obj; device_id=device_id)
+    Rhat = Rhat_gelman(chain; device_id=device_id)
+    if verbose
+        println("Summary Checks\n\nAcceptance Ratio of each chain:"); println(ar); println("\nRhat Gelman: $Rhat\n")
+    end
+    ar, Rhat                                                                                                 # (the plotting part is commented out in the reference)
+end
+# on-device forms over a live handle's history (no N x d x G download): mean / covariance of generations g_from..g_to
+function mean_cov(h, g_from, g_to, d)
+    b = zeros(d); cov = zeros(d, d)
+    chk(ccall((:demcz_mean_cov, libdemcz), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Float64}), h, g_from, g_to, b, cov), h); b, cov
+end
+
+# ---- checkpoint: what a resumed run needs (the reference resumes in memory only, demcz.jl:18-22) ----------------------------
+struct Checkpoint
+    prevrun::MC                 # last generation only: chain[:, :, end:end], log_obj[:, end:end], Xcurrent, log_objcurrent
+    Z::Matrix{Float64}
+    generations_done::Int       # how far the chains' random streams have advanced (pass to set_rng_offset)
+    seed::UInt64
+end
+checkpoint(mc::MC, Z, generations_done, seed) =
+    Checkpoint(MC(mc.chain[:, :, end:end], mc.log_obj[:, end:end], copy(mc.Xcurrent), copy(mc.log_objcurrent)), Matrix{Float64}(Z), generations_done, UInt64(seed))
+function save_checkpoint(path, ck::Checkpoint)                       # a flat little-endian file: 5 Int64 header words, then the arrays
+    N, d = size(ck.prevrun.Xcurrent); M = size(ck.Z, 1)
+    open(path, "w") do io
+        write(io, Int64[N, d, M, ck.generations_done, reinterpret(Int64, ck.seed)])
+        write(io, ck.prevrun.chain); write(io, ck.prevrun.log_obj); write(io, ck.prevrun.Xcurrent); write(io, ck.prevrun.log_objcurrent); write(io, ck.Z)
+    end
+end
+function load_checkpoint(path)
+    open(path, "r") do io
+        hdr = Vector{Int64}(undef, 5); read!(io, hdr); N, d, M = hdr[1], hdr[2], hdr[3]
+        chain = Array{Float64,3}(undef, N, d, 1); lo = Matrix{Float64}(undef, N, 1); X = Matrix{Float64}(undef, N, d)
+        lp = Vector{Float64}(undef, N); Z = Matrix{Float64}(undef, M, d)
+        read!(io, chain); read!(io, lo); read!(io, X); read!(io, lp); read!(io, Z)
+        Checkpoint(MC(chain, lo, X, lp), Z, hdr[4], reinterpret(UInt64, hdr[5]))
+    end
+end
+# resume: demcz_sample(t, ck.Z, opts; prevrun=ck.prevrun, seed=ck.seed, drawn=ck.generations_done)
+
 # ---- drivers: src/demcz.jl:1-63 and src/demcz_anneal.jl:14-65 with the device below runchain! -------------
-demcz_sample(t::LogObj, Zmat, opts::DEMCopt; prevrun=nothing, seed=0) =
+demcz_sample(t::LogObj, Zmat, opts::DEMCopt; prevrun=nothing, seed=0, drawn=nothing) =
     demcz_sample(t, Zmat, opts.N, opts.K, opts.Ngeneration, opts.Nblocks, opts.blockindex, opts.eps_scale, opts.γ;
                  prevrun=prevrun, verbose=opts.verbose, print_step=opts.print_step, autostop=opts.autostop,
-                 autostop_Rhat=opts.autostop_Rhat, autostop_every=opts.autostop_every, seed=seed)
+                 autostop_Rhat=opts.autostop_Rhat, autostop_every=opts.autostop_every, seed=seed, drawn=drawn)
 
 function demcz_sample(t::LogObj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockindex=[1:size(Zmat, 2)],
                       eps_scale=1e-4 * ones(size(Zmat, 2)), γ=2.38; prevrun=nothing, verbose=true, print_step=100,
-                      autostop=:no, autostop_Rhat=1.01, autostop_every=1000, seed=0)
+                      autostop=:no, autostop_Rhat=1.01, autostop_every=1000, seed=0, drawn=nothing)
     nrowZ, d = size(Zmat)
     Mcap = nrowZ + Int(ceil(N * Ngeneration / K))                                     # demcz.jl:11
-    X, lp, drawn = start_state(t, Zmat, N, prevrun)
+    X, lp, drawn0 = start_state(t, Zmat, N, prevrun)
+    drawn = drawn === nothing ? drawn0 : drawn                                         # (a checkpoint's prevrun keeps one generation: its stream position is given)
     h = create(t, N, d, K, Mcap, Ngeneration, blockindex, eps_scale, seed)
     try
         set_state(h, X, lp, Matrix{Float64}(Zmat))

@@ -17,6 +17,7 @@ JL2C = {
     "Ptr{Int64}": {"int64_t*"}, "Ref{Int64}": {"int64_t*"},
     "Ptr{Int32}": {"int32_t*", "const int32_t*"}, "Ref{Int32}": {"int32_t*"},
     "Ptr{Cvoid}": {"demcz_handle*", "const demcz_handle*", "void*", "const void*"},
+    "Ptr{UInt8}": {"void*", "const void*"},
     "Ref{Ptr{Cvoid}}": {"demcz_handle**"},
     "Ref{DemczConfig}": {"const demcz_config*"},
     "Cstring": {"const char*"},
@@ -48,7 +49,7 @@ def julia_ccalls():
 def test_every_ccall_matches_its_prototype():
     protos = c_prototypes()
     calls = julia_ccalls()
-    assert len(calls) >= 17
+    assert len(calls) >= 27
     for name, ret, types in calls:
         assert name in protos, f"{name}: not declared in include/demcz.h"
         cret, ctypes_ = protos[name]
@@ -100,3 +101,38 @@ def test_closure_methods_exist_and_convert_block_index():
     # demcopt's defaults are the reference's (DEMC.jl:41)
     assert "N=4, K=10, Ngeneration=5000, Nblocks=1, blockindex=[1:Npar], eps_scale=1e-4 * ones(Npar), γ=2.38" in JL
     assert "T0=3, TN=1e-3, autostop=:Rhat, autostop_every=1000, autostop_Rhat=1.05" in JL
+
+
+def test_sharded_surface_diagnostics_and_checkpoint_are_bound():
+    """VERDICT r2 'missing' #3: the multi-GPU entry points (the role of demcz_sample_par, src/demcz.jl:101-165), the reference's
+    diagnostics by their own names (src/utils.jl:2-111) over the device reductions, and a checkpoint."""
+    bound = {c[0] for c in julia_ccalls()}
+    need = {"demcz_comm_unique_id", "demcz_comm_init", "demcz_set_append_lag", "demcz_set_comm_timeout", "demcz_synchronize",
+            "demcz_rhat_array", "demcz_accept_ratio_array", "demcz_mean_cov_array", "demcz_mean_cov"}
+    assert need <= bound, sorted(need - bound)
+    assert re.search(r"function demcz_sample_par\(t::DeviceTarget, Zmat, opts::DEMCopt; sync_every=1000, prevrun=nothing, rank::Integer, nranks::Integer", JL)
+    assert "chain_id0=c0" in JL and "comm_init(h, unique_id, nranks, rank)" in JL
+    assert "Zmat[end-N+1+c0:end-N+c0+nloc, :]" in JL                       # rank r starts at ITS part of the last N rows (demcz.jl:113)
+    for name in ("Rhat_gelman", "flatten_chain", "mean_cov_chain", "convergence_check", "save_checkpoint", "load_checkpoint"):
+        assert re.search(rf"function {name}\(", JL), name
+    # flatten_chain's column order: generation-major, then chain (utils.jl:26-29)
+    assert "permutedims(chain[:, :, 1:Ngeneration], (2, 1, 3))" in JL
+
+
+def test_flatten_chain_index_order_matches_the_reference_loop():
+    """The permutedims/reshape form in the shim against the reference's explicit loop (utils.jl:22-32), in NumPy."""
+    import numpy as np
+    Npop, Npar, G = 3, 2, 4
+    chain = np.arange(Npop * Npar * G, dtype=float).reshape((Npop, Npar, G), order="F")
+    ref = np.zeros((Npar, Npop * G))
+    for i in range(Npar):
+        count = 0
+        for ig in range(G):
+            for ic in range(Npop):
+                ref[i, count] = chain[ic, i, ig]
+                count += 1
+    # Julia: reshape(permutedims(chain, (2, 1, 3)), Npar, Npop*G) with column-major reshape
+    jl = np.reshape(np.transpose(chain, (1, 0, 2)), (Npar, Npop * G), order="F")
+    assert np.array_equal(jl, ref)
+    import demc_jl_amd as demc
+    assert np.array_equal(demc.flatten_chain(chain), ref)
