@@ -8,6 +8,7 @@
 #include "demcz_kernels_pc.h"
 #include "demcz_kernels_lr.h"
 #include "demcz_kernels_ps.h"
+#include "demcz_kernels_ps2.h"
 #include "demcz_kernels_pw.h"
 
 #include <rccl/rccl.h>
@@ -98,6 +99,12 @@ struct demcz_handle {
 #ifdef DEMCZ_STAMPS
     unsigned long long* d_stamps = nullptr;
 #endif
+    // wave-per-chain layout, d <= 5: archive, both record buffers and the launch's temperatures in ONE allocation (dZ), chain
+    // and log_obj histories in one too -- what window_kernel_ps2 needs to address everything with 32-bit offsets
+    bool arena = false, rec_in_arena = false, hist_joint = false;
+    int64_t arena_gens = 0;           // generations each record buffer of the arena holds
+    double* arena_rec[2] = {nullptr, nullptr};
+    double* arena_temp = nullptr;
     int64_t rec_cap = 0;              // generations each buffer holds
     int rec_cur = 0;
     bool host_paced = false;          // inside demcz_run_checked (a blocking call): see launch_window_pc
@@ -163,9 +170,13 @@ struct demcz_handle {
     int64_t batch_base = 0;
     // comm failure path: every host-side wait of a sharded handle has a deadline (demcz_set_comm_timeout); on expiry, or on an
     // asynchronous RCCL error, both communicators are aborted and the handle is dead (DEMCZ_ERR_COMM from every call)
+    // exchanges completed on the side stream, written by a one-thread kernel behind each batch's scatter into pinned host memory:
+    // what a host-paced wait polls (hipEventQuery of an event recorded behind a stream-wait was seen to report "complete" while
+    // the work in front of it had not run -- tests/test_gpu_comm_failure.py, lag 2 -- so the host does not ask the runtime)
+    volatile long long* xdone = nullptr;
     int64_t comm_timeout_ms = 60000;
     bool comm_dead = false;
-    int* stall_flag = nullptr;         // pinned; demcz_debug_stall_exchange: the stall kernel spins until it is set
+    int* stall_flag = nullptr;         // device word; demcz_debug_stall_exchange: the stall kernel spins until it is set
     int32_t stall_next_ms = 0;
 };
 
@@ -208,17 +219,28 @@ static int32_t fail(demcz_handle* h, int32_t code, const std::string& msg)
 // leave, the streams drain), the handle is marked dead and DEMCZ_ERR_COMM is returned from this and every later call.
 // A fresh process is the only retry.  Unsharded handles wait in the runtime as before.
 namespace demcz {
-__global__ void stall_kernel(volatile int* release, unsigned long long max_ticks)
+__global__ void mark_kernel(volatile long long* word, long long value)
+{
+    __hip_atomic_store(const_cast<long long*>(word), value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void stall_kernel(int* release, unsigned long long max_ticks)
 {
     const unsigned long long t0 = wall_clock64();           // 100 MHz
-    while (*release == 0 && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(32);
+    while (__hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(32);
 }
 }  // namespace demcz
 
 static int32_t comm_fail(demcz_handle* h, const std::string& why)
 {
     h->comm_dead = true;
-    if (h->stall_flag) *h->stall_flag = 1;                    // (a test's stall kernel leaves at once)
+    if (h->stall_flag) {                                      // (a test's stall kernel leaves at once: a device word, set from a stream of its own)
+        hipStream_t rs = nullptr;
+        if (hipStreamCreateWithFlags(&rs, hipStreamNonBlocking) == hipSuccess) {
+            (void)hipMemsetAsync(h->stall_flag, 0xff, sizeof(int), rs);
+            (void)hipStreamSynchronize(rs);
+            (void)hipStreamDestroy(rs);
+        }
+    }
     if (h->comm_side) (void)ncclCommAbort(h->comm_side);
     if (h->comm) (void)ncclCommAbort(h->comm);
     h->comm_side = nullptr;                                   // (abort frees them; `comm` stays non-null as the "sharded" mark
@@ -228,7 +250,7 @@ static int32_t comm_fail(demcz_handle* h, const std::string& why)
     for (hipStream_t st : ss) {
         if (!st) continue;
         while (hipStreamQuery(st) == hipErrorNotReady &&
-               std::chrono::steady_clock::now() - t0 < std::chrono::seconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(200));
+               std::chrono::steady_clock::now() - t0 < std::chrono::seconds(1)) std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
     h->err = "communication failure (" + why + "): both RCCL communicators aborted; the handle is dead -- restart the job in fresh processes";
     return DEMCZ_ERR_COMM;
@@ -237,11 +259,16 @@ static int32_t comm_fail(demcz_handle* h, const std::string& why)
 template <class Query>
 static int32_t wait_deadline(demcz_handle* h, Query query, const char* what)
 {
+    static const bool dbg = getenv("DEMCZ_DEBUG_COMM") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     auto last_check = t0;
     for (unsigned long long polls = 0;; ++polls) {
         const hipError_t e = query();
-        if (e == hipSuccess) return DEMCZ_OK;
+        if (e == hipSuccess) {
+            if (dbg) fprintf(stderr, "[demcz] wait %s: done after %llu polls, %.3f ms\n", what, polls,
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+            return DEMCZ_OK;
+        }
         if (e != hipErrorNotReady) { h->err = std::string(what) + ": " + hipGetErrorString(e); return DEMCZ_ERR_HIP; }
         const auto now = std::chrono::steady_clock::now();
         if (now - last_check >= std::chrono::milliseconds(1)) {
@@ -288,13 +315,25 @@ static int32_t sync_event(demcz_handle* h, hipEvent_t ev, const char* what)
         if (rcs_) return rcs_;                                                                   \
     } while (0)
 
+// hipFree / hipMalloc synchronise the whole device: before either, every stream of a sharded handle is waited for HERE, with
+// the deadline -- so that a stalled peer surfaces as DEMCZ_ERR_COMM instead of a runtime call that never returns.
+static int32_t quiesce_all(demcz_handle* h)
+{
+    if (h->comm_dead) return DEMCZ_ERR_COMM;
+    if (!h->comm) return DEMCZ_OK;
+    for (hipStream_t st : {h->stream, h->comm_stream, h->prod_stream, h->diag_stream})
+        if (st) { int32_t rc = sync_stream(h, st, "quiesce"); if (rc) return rc; }
+    return DEMCZ_OK;
+}
+
 // test hook (demcz_debug_stall_exchange): a kernel that holds the stream the next collective goes to
 static int32_t maybe_stall(demcz_handle* h, hipStream_t s)
 {
     if (h->stall_next_ms <= 0) return DEMCZ_OK;
-    if (!h->stall_flag) HIPCHK(h, hipHostMalloc((void**)&h->stall_flag, sizeof(int), hipHostMallocDefault));
-    *h->stall_flag = 0;
-    hipLaunchKernelGGL(stall_kernel, dim3(1), dim3(1), 0, s, (volatile int*)h->stall_flag, (unsigned long long)h->stall_next_ms * 100000ull);
+    if (getenv("DEMCZ_DEBUG_COMM")) fprintf(stderr, "[demcz] stall kernel of %d ms enqueued\n", h->stall_next_ms);
+    if (!h->stall_flag) HIPCHK(h, hipMalloc((void**)&h->stall_flag, sizeof(int)));
+    HIPCHK(h, hipMemsetAsync(h->stall_flag, 0, sizeof(int), s));
+    hipLaunchKernelGGL(stall_kernel, dim3(1), dim3(1), 0, s, h->stall_flag, (unsigned long long)h->stall_next_ms * 100000ull);
     HIPCHK(h, hipGetLastError());
     h->stall_next_ms = 0;
     return DEMCZ_OK;
@@ -307,6 +346,7 @@ static int64_t blockstep_nblk(int b)
 }
 
 constexpr size_t ML_MAX_DYNAMIC_LDS = 160 * 1024;      // LDS per CU on gfx950
+constexpr size_t REC_PAD = 64;       // doubles behind a record buffer: a consumer's fetches may run past its last row's last generation
 constexpr int PC_CONSUMER_CHAINS = 8;       // chains per consumer workgroup of the replicated split layout: 8 lanes per chain
 static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t nobs, int max_blocklen, int nblocks);
 static bool pc_available(int target_kind, int d, bool full_block);
@@ -327,6 +367,7 @@ static int32_t live_verify(demcz_handle* h);
 static void live_release(demcz_handle* h);
 static int64_t live_span(demcz_handle* h);
 static int32_t rec_reserve(demcz_handle* h, int64_t gens);
+static bool ps2_applicable(const demcz_handle* h, const WindowParams& P);
 
 extern "C" int32_t demcz_abi_version(void) { return DEMCZ_ABI_VERSION; }
 
@@ -347,7 +388,7 @@ static hipError_t dev_alloc_copy(T** dst, const T* src, size_t n, hipStream_t s)
 static void free_all(demcz_handle* h)
 {
     if (h->d_acc) (void)hipFree(h->d_acc);
-    void* bufs[] = {h->dZ, h->dX, h->dlp, h->dchain, h->dlogobj, h->dlp_origin, h->dtemp, h->d_block_offsets,
+    void* bufs[] = {h->dZ, h->dX, h->dlp, h->dchain, h->hist_joint ? nullptr : h->dlogobj, h->dlp_origin, h->dtemp, h->d_block_offsets,
                     h->d_slot_of, h->d_slot_role, h->d_eps, h->d_mu, h->d_Wp, h->d_design, h->d_y, h->d_scratch, h->dXprop,
                     h->dlogu, h->d_gather};
     for (void* b : bufs)
@@ -355,7 +396,7 @@ static void free_all(demcz_handle* h)
     for (auto& pe : h->pending) if (pe.ev) (void)hipEventDestroy(pe.ev);
     h->pending.clear();
     for (int b = 0; b < 2; ++b) {
-        if (h->d_rec[b]) (void)hipFree(h->d_rec[b]);
+        if (h->d_rec[b] && !h->rec_in_arena) (void)hipFree(h->d_rec[b]);
         if (b == 0 && h->d_live_err) (void)hipFree(h->d_live_err);
         if (h->d_send[b]) (void)hipFree(h->d_send[b]);
         if (h->d_recv[b]) (void)hipFree(h->d_recv[b]);
@@ -375,7 +416,8 @@ static void free_all(demcz_handle* h)
     if (h->spec_ev) (void)hipEventDestroy(h->spec_ev);
     if (h->diag_ev) (void)hipEventDestroy(h->diag_ev);
     if (h->diag_stream) (void)hipStreamDestroy(h->diag_stream);
-    if (h->stall_flag) (void)hipHostFree(h->stall_flag);
+    if (h->stall_flag) (void)hipFree(h->stall_flag);
+    if (h->xdone) (void)hipHostFree(const_cast<long long*>(h->xdone));
     if (!h->comm_dead) {                 // (a dead handle's communicators were aborted, which frees them)
         if (h->comm_side) (void)ncclCommDestroy(h->comm_side);
         if (h->comm) (void)ncclCommDestroy(h->comm);
@@ -548,8 +590,33 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
     h->cfg.mu = nullptr; h->cfg.W = nullptr; h->cfg.design = nullptr; h->cfg.yobs = nullptr; h->cfg.stream = nullptr;
 
     const int64_t N = cfg->N;
+    const int64_t N_for_arena = cfg->N;
     h->ZS = (d <= 1) ? 2 : (d <= 2) ? 2 : (d <= 4) ? 4 : ((d + 7) / 8) * 8;     // 16-byte aligned rows; d=5 -> one 64-byte line
-    CRCHK(hipMalloc((void**)&h->dZ, (size_t)cfg->Mcap * h->ZS * sizeof(double)));
+    {
+        size_t zbytes = (size_t)cfg->Mcap * h->ZS * sizeof(double);
+        if (h->lanes == DEMCZ_LAYOUT_SPLIT && h->split_kind == 4 && d <= 5 && !getenv("DEMCZ_NO_PS2")) {
+            // (record buffers as demcz_run would size them: a LIVE launch's span, bounded by the history window; a caller that
+            //  outruns the arena gets separate buffers and the general kernel)
+            const int64_t per_gen = (int64_t)(d + 2) * N_for_arena * (int64_t)sizeof(double);
+            int64_t ag = std::max<int64_t>(cfg->K, std::min<int64_t>((int64_t)(64ll << 20) / per_gen, 1 << 20));
+            if (cfg->Gcap > 0) ag = std::min<int64_t>(ag, std::max<int64_t>(cfg->Gcap, 1024));      // (no history kept: launches are as long as a call)
+            ag = std::max<int64_t>(ag, (int64_t)cfg->K * 4);
+            const size_t zb = (zbytes + 255) & ~(size_t)255;
+            const size_t rb = (((size_t)ag * (size_t)(d + 2) * (size_t)N_for_arena + REC_PAD) * sizeof(double) + 255) & ~(size_t)255;
+            const size_t tb = (((size_t)ag + 64) * sizeof(double) + 255) & ~(size_t)255;
+            if (zb + 2 * rb + tb < 0xF0000000ull) {
+                h->arena = true;
+                h->arena_gens = ag;
+                CRCHK(hipMalloc((void**)&h->dZ, zb + 2 * rb + tb));
+                unsigned char* base = reinterpret_cast<unsigned char*>(h->dZ);
+                h->arena_rec[0] = reinterpret_cast<double*>(base + zb);
+                h->arena_rec[1] = reinterpret_cast<double*>(base + zb + rb);
+                h->arena_temp = reinterpret_cast<double*>(base + zb + 2 * rb);
+                CRCHK(hipMemsetAsync(base + zb, 0, 2 * rb + tb, h->stream));       // row 0 / temperature 0: always legal
+            }
+        }
+        if (!h->arena) CRCHK(hipMalloc((void**)&h->dZ, zbytes));
+    }
     // (the reference pads with zeros, demcz.jl:11; rows at or beyond M never leave the device, and here they hold
     //  the sentinel LIVE launches recognise an unpublished row by: fill_unwritten_rows() in demcz_set_state)
     CRCHK(hipMalloc((void**)&h->d_live_err, 4 * sizeof(unsigned int)));
@@ -557,10 +624,11 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
     CRCHK(hipMalloc((void**)&h->dX, (size_t)N * d * sizeof(double)));
     CRCHK(hipMalloc((void**)&h->dlp, (size_t)N * sizeof(double)));
     if (cfg->Gcap > 0) {
-        CRCHK(hipMalloc((void**)&h->dchain, (size_t)N * d * cfg->Gcap * sizeof(double)));
-        CRCHK(hipMalloc((void**)&h->dlogobj, (size_t)N * cfg->Gcap * sizeof(double)));
-        CRCHK(hipMemsetAsync(h->dchain, 0, (size_t)N * d * cfg->Gcap * sizeof(double), h->stream));   // demcz.jl:24
-        CRCHK(hipMemsetAsync(h->dlogobj, 0, (size_t)N * cfg->Gcap * sizeof(double), h->stream));
+        // (one allocation: a window kernel's history store of a pass covers both arrays with one buffer descriptor)
+        CRCHK(hipMalloc((void**)&h->dchain, (size_t)N * (d + 1) * cfg->Gcap * sizeof(double)));
+        h->dlogobj = h->dchain + (size_t)N * d * cfg->Gcap;
+        h->hist_joint = true;
+        CRCHK(hipMemsetAsync(h->dchain, 0, (size_t)N * (d + 1) * cfg->Gcap * sizeof(double), h->stream));   // demcz.jl:24
     }
     CRCHK(hipMalloc((void**)&h->dlp_origin, (size_t)N * sizeof(double)));
     CRCHK(dev_alloc_copy(&h->d_block_offsets, h->block_offsets.data(), h->block_offsets.size(), h->stream));
@@ -646,6 +714,7 @@ static TargetParams target_params(const demcz_handle* h)
 static int32_t ensure_scratch(demcz_handle* h, int64_t n)
 {
     if (n <= h->scratch_cap) return DEMCZ_OK;
+    { int32_t rcq = quiesce_all(h); if (rcq) return rcq; }
     SYNCCHK(h, h->stream);
     if (h->diag_stream) SYNCCHK(h, h->diag_stream);      // a check may still be reading the old buffer
     if (h->prod_stream) SYNCCHK(h, h->prod_stream);      // (the checks of a wave-per-chain handle run there)
@@ -859,12 +928,16 @@ static int64_t rec_roles(const demcz_handle* h) { return (h->split_kind == 3) ? 
 #ifdef DEMCZ_STAMPS
 constexpr int64_t DEMCZ_STAMP_WGS = 1 << 16;
 #endif
-constexpr size_t REC_PAD = 32;       // chains per consumer workgroup: 8 lanes per chain
 
 template <int TARGET, int D>
 static void launch_ps(const demcz_handle* h, const WindowParams& P, int64_t blocks, bool live)
 {
     const dim3 grid((unsigned)blocks), wg(64 * PS_CHAINS), wgl(64 * (PS_CHAINS + 1));     // LIVE: chain waves + publisher wave
+    if (ps2_applicable(h, P)) {               // the regular launch: the steady-state kernel
+        if (live) hipLaunchKernelGGL((window_kernel_ps2<TARGET, D, true, false>), grid, wgl, 0, h->stream, P);
+        else hipLaunchKernelGGL((window_kernel_ps2<TARGET, D, false, false>), grid, wg, 0, h->stream, P);
+        return;
+    }
     if (P.temperature) {
         if (live) hipLaunchKernelGGL((window_kernel_ps<TARGET, D, true, true>), grid, wgl, 0, h->stream, P);
         else hipLaunchKernelGGL((window_kernel_ps<TARGET, D, false, true>), grid, wg, 0, h->stream, P);
@@ -926,7 +999,8 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
             // the buffer it refills (= everything enqueued on the main stream so far).  Alone (records for THIS window,
             // needed at once): on the main stream.
             hipStream_t ps = h->stream;
-            if (P.consumer_blocks > 0) {
+            static const bool serial_env = getenv("DEMCZ_PRODUCE_SERIAL") != nullptr;     // diagnosis: producer in front of its consumer's successor, on the main stream
+            if (P.consumer_blocks > 0 && !serial_env) {
                 if (!h->prod_stream) {
                     HIPCHK(h, hipStreamCreateWithFlags(&h->prod_stream, hipStreamNonBlocking));
                     HIPCHK(h, hipEventCreateWithFlags(&h->prod_gate, hipEventDisableTiming));
@@ -1055,11 +1129,19 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
 static int32_t rec_reserve(demcz_handle* h, int64_t gens)
 {
     if (gens <= h->rec_cap) return DEMCZ_OK;
+    { int32_t rcq = quiesce_all(h); if (rcq) return rcq; }
     SYNCCHK(h, h->stream);
     if (h->prod_stream) SYNCCHK(h, h->prod_stream);
     h->prod_pending[0] = h->prod_pending[1] = false;
+    if (h->arena && gens <= h->arena_gens && h->rec_cap == 0) {
+        // the arena's buffers (zeroed at create): next to the archive, so that window_kernel_ps2 reaches them by 32-bit offsets
+        for (int b = 0; b < 2; ++b) { h->d_rec[b] = h->arena_rec[b]; h->rec_desc[b].valid = false; }
+        h->rec_in_arena = true;
+        h->rec_cap = h->arena_gens;
+        return DEMCZ_OK;
+    }
     for (int b = 0; b < 2; ++b) {
-        if (h->d_rec[b]) HIPCHK(h, hipFree(h->d_rec[b]));
+        if (h->d_rec[b] && !h->rec_in_arena) HIPCHK(h, hipFree(h->d_rec[b]));
         h->d_rec[b] = nullptr;
         // (+ REC_PAD doubles: a consumer's last 16-byte chunk fetch may run past its row's last generation)
         const size_t nd = (size_t)gens * (size_t)rec_fields(h) * h->cfg.N + REC_PAD;
@@ -1067,8 +1149,20 @@ static int32_t rec_reserve(demcz_handle* h, int64_t gens)
         HIPCHK(h, hipMemsetAsync(h->d_rec[b], 0, nd * sizeof(double), h->stream));   // row 0: always a legal index
         h->rec_desc[b].valid = false;
     }
+    h->rec_in_arena = false;
     h->rec_cap = gens;
     return DEMCZ_OK;
+}
+
+// A launch window_kernel_ps2 can take (demcz_kernels_ps2.h): regular passes, everything reachable by 32-bit offsets.
+static bool ps2_applicable(const demcz_handle* h, const WindowParams& P)
+{
+    static const bool off = getenv("DEMCZ_NO_PS2") != nullptr;
+    if (off || h->split_kind != 4 || P.d < 2 || P.d > 5 || !h->arena || !h->rec_in_arena) return false;
+    if (P.temperature) return false;
+    if (P.K % PS2_R != 0 || P.to_boundary % PS2_R != 0 || P.ngen % PS2_R != 0 || P.ngen < PS2_R) return false;
+    if (P.chain && (!h->hist_joint || (double)h->cfg.N * (h->cfg.d + 1) * (double)h->cfg.Gcap * 8.0 >= 4293918720.0)) return false;
+    return true;
 }
 
 static int32_t pc_prepare(demcz_handle* h, WindowParams& P, int64_t cur_rows, int64_t next_g, int64_t next_ngen, int64_t next_M,
@@ -1247,6 +1341,12 @@ static int32_t exchange_batch(demcz_handle* h)
     HIPCHK(h, hipEventRecord(done, h->comm_stream));
     h->pending.back().ev = done;                       // the entry that covers this batch
     h->pending.back().xseq = ++h->xseq;
+    if (!h->xdone) {
+        HIPCHK(h, hipHostMalloc((void**)&h->xdone, sizeof(long long), hipHostMallocDefault));
+        *h->xdone = 0;
+    }
+    hipLaunchKernelGGL(mark_kernel, dim3(1), dim3(1), 0, h->comm_stream, h->xdone, (long long)h->xseq);
+    HIPCHK(h, hipGetLastError());
     h->buf_xseq[buf] = h->xseq;
     HIPCHK(h, hipEventRecord(h->buf_done[buf], h->comm_stream));
     h->batch_cnt = 0;
@@ -1263,7 +1363,12 @@ static int32_t admit_pending(demcz_handle* h, int64_t g)
         if (pe.ev) {
             // (a blocking caller waits on the host: see launch_window_pc -- the exchange of a batch has the whole next batch to
             //  finish, and the batch after that is only enqueued now)
-            if (h->host_paced) { int32_t rcw = sync_event(h, pe.ev, "admit_pending (exchange of a batch)"); if (rcw) return rcw; }
+            if (h->host_paced && h->xdone) {
+                volatile long long* xd = h->xdone;
+                const long long need = (long long)pe.xseq;
+                int32_t rcw = wait_deadline(h, [xd, need]() { return (*xd >= need) ? hipSuccess : hipErrorNotReady; }, "admit_pending (exchange of a batch)");
+                if (rcw) return rcw;
+            }
             else HIPCHK(h, hipStreamWaitEvent(h->stream, pe.ev, 0));
             HIPCHK(h, hipEventDestroy(pe.ev));
             h->xseq_waited = std::max(h->xseq_waited, pe.xseq);      // (the side stream runs its exchanges in order)
@@ -1372,6 +1477,14 @@ static int pc_live_blocks_per_cu()
 }
 
 template <int D>
+static int ps2_live_blocks_per_cu()
+{
+    int a = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&window_kernel_ps2<TARGET_MVNORMAL, D, true, false>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) a = 0;
+    return a;
+}
+
+template <int D>
 static int ps_live_blocks_per_cu()
 {
     int a = 0, b = 0;
@@ -1395,10 +1508,10 @@ static int64_t live_wg_capacity(demcz_handle* h)
     int per_cu = 0;
     if (h->split_kind == 4) {
         switch (h->cfg.d) {
-        case 2: per_cu = ps_live_blocks_per_cu<2>(); break;
-        case 3: per_cu = ps_live_blocks_per_cu<3>(); break;
-        case 4: per_cu = ps_live_blocks_per_cu<4>(); break;
-        case 5: per_cu = ps_live_blocks_per_cu<5>(); break;
+        case 2: per_cu = std::min(ps_live_blocks_per_cu<2>(), ps2_live_blocks_per_cu<2>()); break;
+        case 3: per_cu = std::min(ps_live_blocks_per_cu<3>(), ps2_live_blocks_per_cu<3>()); break;
+        case 4: per_cu = std::min(ps_live_blocks_per_cu<4>(), ps2_live_blocks_per_cu<4>()); break;
+        case 5: per_cu = std::min(ps_live_blocks_per_cu<5>(), ps2_live_blocks_per_cu<5>()); break;
         case 8: per_cu = pw_live_blocks_per_cu<8>(); break;
         case 10: per_cu = pw_live_blocks_per_cu<10>(); break;
         case 20: per_cu = pw_live_blocks_per_cu<20>(); break;
@@ -1520,6 +1633,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     }
     if (temperature) {
         if (G > h->temp_cap) {
+            { int32_t rcq = quiesce_all(h); if (rcq) return rcq; }
             SYNCCHK(h, h->stream);
             if (h->dtemp) HIPCHK(h, hipFree(h->dtemp));
             h->dtemp = nullptr; h->temp_cap = 0;
@@ -2440,6 +2554,7 @@ static int32_t run_checked_body(demcz_handle* h, int64_t g_from, int64_t g_to, d
     const int64_t max_checks = (g_to - g_from + 1) / every + 2;
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     if (max_checks * d > h->pinned_cap) {
+        { int32_t rcq = quiesce_all(h); if (rcq) return rcq; }
         SYNCCHK(h, h->stream);
         if (h->pinned_rhat) (void)hipHostFree(h->pinned_rhat);
         h->pinned_rhat = nullptr; h->pinned_cap = 0;

@@ -1,0 +1,55 @@
+"""Where a pass of the steady-state wave-per-chain kernel (demcz_kernels_ps2.h) spends its time: shader-clock sums per segment
+written by a diagnostic build (-DDEMCZ_STAMPS, build_ab/stamps.so; never the shipped library).  A stamp drains the wave's
+outstanding LDS operations, so the segments are proportions, not absolute costs.
+usage: python scripts/ps2_stamps.py [N] [K] [generations] [M0]   (run on the GPU box; M0: rows of a synthetic initial archive)"""
+import ctypes as C
+import os
+import subprocess
+import sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+so = ROOT / "build_ab" / "stamps.so"
+src = ROOT / "demc.jl_amd" / "csrc"
+if not so.exists() or so.stat().st_mtime < max(p.stat().st_mtime for p in src.glob("*")):
+    so.parent.mkdir(exist_ok=True)
+    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-pass-failed",
+                    "-DDEMCZ_STAMPS", "-o", str(so), str(src / "demcz_capi.hip"), "-lrccl"], check=True)
+os.environ["DEMCZ_LIB"] = str(so)
+sys.path.insert(0, str(ROOT))
+import numpy as np
+import demc_jl_amd as demc
+from demc_jl_amd import _lib
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+G = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
+M0big = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+d = 5
+w = demc.workloads.mvnormal_problem(d, N)
+if M0big:
+    w["Zinit"] = np.asfortranarray(w["mu"] + 0.1 * np.random.default_rng(0).standard_normal((M0big, d)))
+M0 = w["Zinit"].shape[0]
+e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K + 1), Gcap=G, blockindex=[range(d)], eps_scale=w["eps_scale"], seed=1,
+                   target=w["target"])
+assert e.info()["lanes_per_chain"] == 164
+e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+e.run(1, G // 2, 2.38)
+e.set_kernel_timing(True)
+e.run(G // 2 + 1, G, 2.38)
+nl, ms = e.get_kernel_time()
+lib = _lib.load()
+buf = np.zeros((N, 16), dtype=np.uint64)
+lib.demcz_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+rc = lib.demcz_debug_read_stamps(e._h, buf.ctypes.data_as(C.c_void_p), N)
+assert rc == 0, rc
+s = buf.astype(np.float64)
+assert np.all(s[:, 15] == 2), "the last launch was not window_kernel_ps2's"
+n = s[:, 14]
+print(f"N={N} K={K} M0={M0}: last launch = {G - G // 2} generations in {ms * 1e3:.1f} us (stamped build), {n.mean():.0f} passes per chain wave")
+print(f"  whole launch: {s[:, 8].mean():.0f} shader clocks mean, {s[:, 8].max():.0f} max = {(s[:, 8] / n).mean():.0f} per pass")
+names = ["candidate adds + history store", "front end of the next pass (DMA wait, increments, DMA issue, node rows)", "log-density",
+         "table write, bpermute, accept tests, path", "winner, state + history values back from the table", "boundary: row to the publisher",
+         "waits for rows not yet published"]
+for i, nm in enumerate(names):
+    print(f"  {(s[:, i] / n).mean():8.0f} per pass  ({100 * s[:, i].sum() / s[:, 8].sum():5.1f} %)  {nm}")
+print(f"  passes that waited for a row: {100 * (s[:, 11] / n).mean():.2f} %")

@@ -12,9 +12,11 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 d = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 w = demc.workloads.mvnormal_problem(d, N)
 M0 = w["Zinit"].shape[0]
+import os
+NOHIST = bool(os.environ.get("NOHIST"))       # NOHIST=1: no chain / log_obj history kept (what the history stores cost)
 for K in (10, 1000):
     G = S * 1000
-    e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K + 1), Gcap=G, blockindex=[range(d)], eps_scale=w["eps_scale"], seed=1,
+    e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K + 1), Gcap=0 if NOHIST else G, blockindex=[range(d)], eps_scale=w["eps_scale"], seed=1,
                        target=w["target"])
     e.set_state(w["Zinit"][-N:], None, w["Zinit"])
     out = []
