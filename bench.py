@@ -430,7 +430,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "frac_of_measured_copy": achieved / 6290.0,        # MI355X_MICROARCH.md: 6.29 TB/s measured copy rate
                          "traffic": traffic[0], "traffic_fetch_x2": traffic[1], "traffic_source": traffic[2],
-                         "kernel": (f"demcz::window_kernel_ps<MVNORMAL, {d}, LIVE={'true' if live_on else 'false'}> (+ demcz::produce_kernel<{d}> beside it)"
+                         "kernel": (f"demcz::window_kernel_ps2<MVNORMAL, {d}, LIVE={'true' if live_on else 'false'}> (+ demcz::produce_kernel<{d}> beside it)"
                                     if lanes == 164 else
                                     f"demcz::window_kernel_pc8<MVNORMAL, {d}, LIVE={'true' if live_on else 'false'}>" if split
                                     else "demcz::window_kernel"),

@@ -103,6 +103,21 @@ struct WindowParams {
 #endif
 };
 
+// Which block of chains a workgroup runs.  Workgroups go to the chip's eight XCDs round-robin by index, each XCD with an L2 of
+// its own; a 128-byte line of the chain / log_obj history (one generation, one parameter, sixteen consecutive chains) is
+// completed by 8-byte stores of the waves that run those chains.  Handed out in index order, a line's chains sit on several XCDs:
+// each L2 holds a partly written copy and writes its part back on its own.  Giving XCD x the x-th eighth of the chain blocks
+// keeps every line's writers on one XCD, whose L2 merges them (window_kernel_ps2 at C2: 181 -> 153 us per 1000 generations).
+// nblocks = the launch's chain-running workgroups (they are the first of the grid); blocks beyond them keep their index.
+constexpr int DEMCZ_XCDS = 8;
+__device__ __forceinline__ int xcd_block(int nblocks)
+{
+    const int b = (int)blockIdx.x;
+    if (b >= nblocks || nblocks % DEMCZ_XCDS != 0) return b;
+    return (b % DEMCZ_XCDS) * (nblocks / DEMCZ_XCDS) + b / DEMCZ_XCDS;
+}
+__device__ __forceinline__ int xcd_block(const WindowParams& P) { return xcd_block(P.consumer_blocks > 0 ? (int)P.consumer_blocks : (int)gridDim.x); }
+
 // Chains of this wave whose log_obj changed in a generation: a vector compare straight into a lane mask (the wavefront
 // ballot), AND the mask of the lanes that speak for a chain (wave-uniform, computed once), popcount.
 __device__ __forceinline__ unsigned int wave_count_changed(double lp_after, double lp_before, unsigned long long speak64)

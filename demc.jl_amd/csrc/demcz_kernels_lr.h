@@ -488,7 +488,8 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr8s(const Wind
     if (flag_l[0] != 0u) return;
 
     const bool sp = j >= 8;                                // this lane's column: the proposal of generation g (false) / g + 1 (true)
-    const int64_t c_raw = (int64_t)blockIdx.x * LR8_CHAINS + jc;
+    const int bx8 = xcd_block(P);          // (eight chains = 64 bytes of a history line per workgroup: XCD-aware, demcz_kernels.h)
+    const int64_t c_raw = (int64_t)bx8 * LR8_CHAINS + jc;
     const bool active = c_raw < P.N;
     const int64_t c = active ? c_raw : P.N - 1;
 
@@ -519,7 +520,7 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr8s(const Wind
     for (int i = 0; i < 4; ++i) {
         const int pp = i * 64 + l, pc = pp & 15;
         ld_ch[i] = pp >> 5; ld_go[i] = (pp >> 4) & 1;
-        const int64_t cr = (int64_t)blockIdx.x * LR8_CHAINS + ld_ch[i];
+        const int64_t cr = (int64_t)bx8 * LR8_CHAINS + ld_ch[i];
         const int64_t cc = cr < P.N ? cr : P.N - 1;
         ld_rec[i] = pc < F / 2;
         ld_hi[i] = pc >= F / 2 + D / 2;
@@ -554,14 +555,14 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr8s(const Wind
     // generations (chain's next) + 4 + (l & 1) of chain l >> 1
     {
         const int ch = l >> 3, e = l & 7;
-        const int64_t cr = (int64_t)blockIdx.x * LR8_CHAINS + ch;
+        const int64_t cr = (int64_t)bx8 * LR8_CHAINS + ch;
         const int64_t cc = cr < P.N ? cr : P.N - 1;
         ixr_w[ch * LR8_IXRING + e] = P.rec_in[rq_gen * (e < last ? e : last) + cc * F + (D + 1)];
     }
     stage_ask(0);
     stage_put();
     const int ix_ch = (l >> 1) & 7, ix_e = l & 1;
-    const int64_t ix_c = [&] { const int64_t cr = (int64_t)blockIdx.x * LR8_CHAINS + ix_ch; return cr < P.N ? cr : P.N - 1; }();
+    const int64_t ix_c = [&] { const int64_t cr = (int64_t)bx8 * LR8_CHAINS + ix_ch; return cr < P.N ? cr : P.N - 1; }();
 
     int gen = 0;                         // this chain's next generation (of the launch, 0-based)
     int to_b = P.to_boundary;            // countdown to the chain's next K boundary
@@ -829,7 +830,7 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr8s(const Wind
         if (own[m] && writer) P.Xcur[c + P.N * (4 * m + q)] = x[m];
     if (q == 0 && writer) P.lpcur[c] = lp;
     static_assert(NMF < LR16_WAVES, "parameter groups and log_obj each have a wave to write them");
-    wave_store_counts(P, (int64_t)blockIdx.x * LR16_WAVES + w, cnt_total, cnt_first);
+    wave_store_counts(P, (int64_t)bx8 * LR16_WAVES + w, cnt_total, cnt_first);
 #ifdef DEMCZ_STAMPS
     if (P.stamps && (tid & 63) == 0 && blockIdx.x < 16384u) {      // as window_kernel_lr16, per STEP; [15]: steps
         unsigned long long* o = P.stamps + ((size_t)blockIdx.x * LR16_WAVES + w) * 16;

@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
     constexpr int WPW = ML_WAVES;                               // at most; the launch says how many (blockDim.x / 64: 1 or ML_WAVES)
     const int wpw = (int)(blockDim.x >> 6);
     const int wv = (int)(threadIdx.x >> 6);
-    const int64_t vb = (int64_t)blockIdx.x * wpw + wv;          // this wave's index among the chain waves
+    const int64_t vb = (int64_t)xcd_block(P) * wpw + wv;        // this wave's index among the chain waves (XCD-aware: demcz_kernels.h)
     static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "lane-cooperative layout: MvNormal / isotropic targets");
     static_assert(!LIVE || REC, "LIVE launches are a property of the split form");
     if constexpr (REC) {
@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
     constexpr int WPW = REC ? MLB_REC_WAVES : 1;                // at most; the launch says how many (blockDim.x / 64: 1 or MLB_REC_WAVES)
     const int wpw = (int)(blockDim.x >> 6);
     const int wv = (int)(threadIdx.x >> 6);
-    const int64_t vb = (int64_t)blockIdx.x * wpw + wv;          // this wave's index among the consumer waves
+    const int64_t vb = (int64_t)xcd_block(P) * wpw + wv;        // this wave's index among the consumer waves (XCD-aware)
     static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "block layout: MvNormal / isotropic targets");
     static_assert(!LIVE || REC, "LIVE launches are a property of the split form");
     if constexpr (REC) {

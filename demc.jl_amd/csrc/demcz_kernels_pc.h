@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(LIVE ? 64 * PC8_LIVE_WAVES : 64) window_kernel
         __syncthreads();
         if (threadIdx.x >= 64) {
             const int l = (int)threadIdx.x - 64;
-            const int64_t c0 = (int64_t)blockIdx.x * G;
+            const int64_t c0 = (int64_t)xcd_block(P) * G;
             unsigned int done = 0u;
             while (true) {
                 const unsigned int seq = __hip_atomic_load(&pub_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(LIVE ? 64 * PC8_LIVE_WAVES : 64) window_kernel
     };
     const int lane = threadIdx.x, r = lane % L, gq = lane / L;
     // groups beyond the last chain shadow chain N-1 and store nothing
-    const int64_t c_own = (int64_t)blockIdx.x * G + gq;
+    const int64_t c_own = (int64_t)xcd_block(P) * G + gq;      // (XCD-aware: demcz_kernels.h)
     const bool live = c_own < P.N;
     const int64_t c = live ? c_own : P.N - 1;
 

@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             // keep away from the chain waves): a store per chain wave could not keep up with a boundary every two passes.
             const bool pl = lane < PS_CHAINS * D;
             const int cw = pl ? lane / D : 0, pp = pl ? lane % D : 0;
-            const int64_t cl = (int64_t)blockIdx.x * PS_CHAINS + cw;
+            const int64_t cl = (int64_t)xcd_block(P) * PS_CHAINS + cw;
             unsigned int done = 0u;
             while (true) {
                 // The chain waves reach their boundaries at different moments.  Looking for ready rows only once the
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             if (lane == 0) __hip_atomic_store(&pub_exit[w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
-    const int64_t c = (int64_t)blockIdx.x * PS_CHAINS + w;
+    const int64_t c = (int64_t)xcd_block(P) * PS_CHAINS + w;       // (XCD-aware: demcz_kernels.h)
     if (c >= P.N) {
         wave_store_counts(P, c, 0u, 0u);
         leave();

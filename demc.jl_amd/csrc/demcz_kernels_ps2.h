@@ -39,7 +39,6 @@ constexpr int PS2_R = 5;             // generations per pass (the tree's depth):
 #ifndef PS2_XCD_SWIZZLE
 #define PS2_XCD_SWIZZLE 1
 #endif
-constexpr int PS2_XCDS = 8;          // accelerator complex dies of an MI355X: workgroup b runs on XCD b mod 8
 #ifndef PS2_AHEAD_N
 #define PS2_AHEAD_N 2
 #endif
@@ -88,18 +87,11 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             return;
         }
     }
-    // Which chains this workgroup runs.  Workgroups go to the chip's eight XCDs round-robin by index, each XCD with an L2 of its
-    // own; a 128-byte line of the history (one generation, one parameter, sixteen consecutive chains = four workgroups) is
-    // completed by 8-byte stores of sixteen waves.  With chains handed out in index order those four workgroups sit on four
-    // XCDs, four L2s each hold a quarter-written copy of the line and each writes its part back on its own.  Handing XCD x the
-    // x-th eighth of the chains keeps every line's writers on one XCD, whose L2 merges them.
-    const int nwg = P.consumer_blocks;
 #if PS2_XCD_SWIZZLE
-    const int bxs = (nwg % PS2_XCDS == 0) ? (int)(blockIdx.x % PS2_XCDS) * (nwg / PS2_XCDS) + (int)(blockIdx.x / PS2_XCDS) : (int)blockIdx.x;
+    const int bxs = xcd_block(P);          // XCD x runs the x-th eighth of the chains: demcz_kernels.h
 #else
     const int bxs = (int)blockIdx.x;
 #endif
-    (void)nwg;
     __shared__ __attribute__((aligned(16))) unsigned char raw[PS_CHAINS][PS2_SLOTS][1024];
     __shared__ __attribute__((aligned(16))) double sdelta[PS_CHAINS][SDN];
     __shared__ __attribute__((aligned(16))) double ctab[PS_CHAINS][64 * CR];       // row l: lane l's candidate (rows 32..63 shadow 0..31)

@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
                     const int e = lane + 64 * t;
                     const bool pl = e < PS_CHAINS * D;
                     const int cw = pl ? e / D : 0, pp = pl ? e % D : 0;
-                    const int64_t cl = (int64_t)blockIdx.x * PS_CHAINS + cw;
+                    const int64_t cl = (int64_t)xcd_block(P) * PS_CHAINS + cw;
                     const unsigned int seq = __hip_atomic_load(&pub_seq[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     const bool ready = pl && seq != done[t];
                     if (ready) {
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             if (lane == 0) __hip_atomic_store(&pub_exit[w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
-    const int64_t c = (int64_t)blockIdx.x * PS_CHAINS + w;
+    const int64_t c = (int64_t)xcd_block(P) * PS_CHAINS + w;       // (XCD-aware: demcz_kernels.h)
     if (c >= P.N) {
         wave_store_counts(P, c, 0u, 0u);
         leave();

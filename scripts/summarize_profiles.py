@@ -45,7 +45,7 @@ try:
             shape = {"chains": c["chains_total"] // b["n_gpus"], "dim": c["dim"], "K": c["K"], "lanes_per_chain": c["lanes_per_chain"],
                      "generations_per_launch": r["generations_per_launch"],
                      # the kernels one window launch consists of: the wave-per-chain layout runs its producer half as a kernel of its own
-                     "kernel_prefixes": (["void demcz::window_kernel_ps<0, %d, true, false>" % c["dim"], "void demcz::produce_kernel<%d>" % c["dim"]]
+                     "kernel_prefixes": (["void demcz::window_kernel_ps2<0, %d, true, false>" % c["dim"], "void demcz::produce_kernel<%d>" % c["dim"]]
                                          if c["lanes_per_chain"] == 164 else ["void demcz::window_kernel_pc8<0, %d, true, false>" % c["dim"]]),
                      "avg_launch_us_under_profiler": r["avg_launch_us"], "value_under_profiler": b["value"]}
             doc["workload"] = c["workload"]
