@@ -23,11 +23,95 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 using namespace demcz;
 
 static thread_local std::string g_create_error;
+
+// ---- buffer pools ---------------------------------------------------------------------------------------------------------
+// The reference's demcz_sample allocates its result arrays per call (demcz.jl:24); behind this ABI that is a device history, an
+// archive and -- for the streamed history -- pinned host mirrors of half a gigabyte at C2, per call.  hipMalloc / hipFree /
+// hipHostMalloc of that size cost milliseconds each (and hipFree synchronises the device), so buffers a destroyed handle gives
+// back are kept (up to a cap) for the next handle of the process: a second demcz_sample call allocates nothing.
+namespace {
+struct BufPool {
+    struct Entry { void* p; size_t bytes; int device; };
+    std::mutex mu;
+    std::vector<Entry> free_list;
+    size_t cached = 0;
+    const size_t cap;
+    const bool host;
+    BufPool(size_t cap_, bool host_) : cap(cap_), host(host_) {}
+    hipError_t acquire(void** out, size_t bytes, int device)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            int best = -1;
+            for (int i = 0; i < (int)free_list.size(); ++i) {
+                const Entry& e = free_list[i];
+                if (e.device == device && e.bytes >= bytes && e.bytes <= bytes + bytes / 4 + (1u << 20) && (best < 0 || e.bytes < free_list[best].bytes)) best = i;
+            }
+            if (best >= 0) {
+                *out = free_list[best].p;
+                cached -= free_list[best].bytes;
+                sizes[*out] = free_list[best].bytes;
+                free_list.erase(free_list.begin() + best);
+                return hipSuccess;
+            }
+        }
+        const hipError_t e = host ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
+        if (e == hipSuccess) { std::lock_guard<std::mutex> lk(mu); sizes[*out] = bytes; }
+        return e;
+    }
+    void release(void* p, int device)
+    {
+        if (!p) return;
+        size_t bytes = 0;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = sizes.find(p);
+            if (it != sizes.end()) { bytes = it->second; sizes.erase(it); }
+            if (bytes && cached + bytes <= cap && !getenv("DEMCZ_NO_POOL")) {
+                free_list.push_back({p, bytes, device});
+                cached += bytes;
+                return;
+            }
+        }
+        if (host) (void)hipHostFree(p); else (void)hipFree(p);
+    }
+    std::unordered_map<void*, size_t> sizes;
+};
+BufPool g_dev_pool(6ull << 30, false);      // device buffers (history, archive arena): at most 6 GiB kept
+BufPool g_host_pool(3ull << 30, true);      // pinned host mirrors of the history: at most 3 GiB kept
+}  // namespace
+// ... and so are its streams (creating and destroying five streams was 4-5 ms of an end-to-end C2 call)
+static std::mutex g_stream_mu;
+static std::vector<std::pair<int, hipStream_t>> g_stream_pool;
+static hipError_t stream_acquire(int device, hipStream_t* out)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        for (size_t i = 0; i < g_stream_pool.size(); ++i)
+            if (g_stream_pool[i].first == device) { *out = g_stream_pool[i].second; g_stream_pool.erase(g_stream_pool.begin() + (long)i); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+static void stream_release(int device, hipStream_t s, bool drained)
+{
+    if (!s) return;
+    if (drained && !getenv("DEMCZ_NO_POOL")) {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        if (g_stream_pool.size() < 32) { g_stream_pool.emplace_back(device, s); return; }
+    }
+    (void)hipStreamDestroy(s);
+}
+// every device / pinned allocation of a handle goes through the pools (a pointer the pool does not know is simply freed)
+static hipError_t dev_malloc(int device, void** out, size_t bytes) { return g_dev_pool.acquire(out, std::max<size_t>(bytes, 16), device); }
+static hipError_t dev_free(int device, void* p) { g_dev_pool.release(p, device); return hipSuccess; }
+static hipError_t host_malloc(void** out, size_t bytes) { return g_host_pool.acquire(out, std::max<size_t>(bytes, 16), -1); }
+static hipError_t host_free(void* p) { g_host_pool.release(p, -1); return hipSuccess; }
 
 struct demcz_handle {
     demcz_config cfg{};
@@ -168,6 +252,15 @@ struct demcz_handle {
     int64_t xseq = 0, xseq_waited = 0, buf_xseq[2] = {0, 0};
     int batch_buf = 0, batch_cnt = 0;
     int64_t batch_base = 0;
+    // streamed history (demcz_history_stream): pinned host mirrors of chain / log_obj, filled slab by slab on a copy stream while
+    // the next slab computes; hs_upto = history slots whose copy has been enqueued, hs_events = (slot_end, event) per copy
+    bool hs_on = false;
+    double* hs_chain = nullptr;
+    double* hs_logobj = nullptr;
+    hipStream_t hs_stream = nullptr;
+    std::deque<std::pair<int64_t, hipEvent_t>> hs_events;
+    int64_t hs_upto = 0;
+    bool pooled_dev = false;           // dZ / dchain came from (and go back to) the process-wide device pool
     // comm failure path: every host-side wait of a sharded handle has a deadline (demcz_set_comm_timeout); on expiry, or on an
     // asynchronous RCCL error, both communicators are aborted and the handle is dead (DEMCZ_ERR_COMM from every call)
     // exchanges completed on the side stream, written by a one-thread kernel behind each batch's scatter into pinned host memory:
@@ -331,7 +424,7 @@ static int32_t maybe_stall(demcz_handle* h, hipStream_t s)
 {
     if (h->stall_next_ms <= 0) return DEMCZ_OK;
     if (getenv("DEMCZ_DEBUG_COMM")) fprintf(stderr, "[demcz] stall kernel of %d ms enqueued\n", h->stall_next_ms);
-    if (!h->stall_flag) HIPCHK(h, hipMalloc((void**)&h->stall_flag, sizeof(int)));
+    if (!h->stall_flag) HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->stall_flag, sizeof(int)));
     HIPCHK(h, hipMemsetAsync(h->stall_flag, 0, sizeof(int), s));
     hipLaunchKernelGGL(stall_kernel, dim3(1), dim3(1), 0, s, h->stall_flag, (unsigned long long)h->stall_next_ms * 100000ull);
     HIPCHK(h, hipGetLastError());
@@ -367,6 +460,7 @@ static int32_t live_verify(demcz_handle* h);
 static void live_release(demcz_handle* h);
 static int64_t live_span(demcz_handle* h);
 static int32_t rec_reserve(demcz_handle* h, int64_t gens);
+static int32_t check_hist_range(demcz_handle* h, int64_t g_from, int64_t g_to, const char* who);
 static bool ps2_applicable(const demcz_handle* h, const WindowParams& P);
 
 extern "C" int32_t demcz_abi_version(void) { return DEMCZ_ABI_VERSION; }
@@ -377,9 +471,9 @@ extern "C" const char* demcz_last_error(const demcz_handle* h)
 }
 
 template <class T>
-static hipError_t dev_alloc_copy(T** dst, const T* src, size_t n, hipStream_t s)
+static hipError_t dev_alloc_copy(T** dst, const T* src, size_t n, hipStream_t s, int device)
 {
-    hipError_t e = hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T));
+    hipError_t e = dev_malloc(device, (void**)dst, std::max<size_t>(n, 1) * sizeof(T));
     if (e != hipSuccess) return e;
     if (n) e = hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyHostToDevice, s);
     return e;
@@ -387,42 +481,53 @@ static hipError_t dev_alloc_copy(T** dst, const T* src, size_t n, hipStream_t s)
 
 static void free_all(demcz_handle* h)
 {
-    if (h->d_acc) (void)hipFree(h->d_acc);
+    if (h->d_acc) (void)dev_free(h->cfg.device_id, h->d_acc);
+    if (h->pooled_dev) {               // (the two big ones go back to the pool; free_all runs behind a stream synchronisation)
+        g_dev_pool.release(h->dZ, h->cfg.device_id);
+        if (h->hist_joint) g_dev_pool.release(h->dchain, h->cfg.device_id);
+        h->dZ = nullptr;
+        if (h->hist_joint) h->dchain = nullptr;
+    }
+    for (auto& pe : h->hs_events) if (pe.second) (void)hipEventDestroy(pe.second);
+    h->hs_events.clear();
+    stream_release(h->cfg.device_id, h->hs_stream, !h->comm_dead && hipStreamQuery(h->hs_stream) == hipSuccess);
+    g_host_pool.release(h->hs_chain, -1);
+    g_host_pool.release(h->hs_logobj, -1);
     void* bufs[] = {h->dZ, h->dX, h->dlp, h->dchain, h->hist_joint ? nullptr : h->dlogobj, h->dlp_origin, h->dtemp, h->d_block_offsets,
                     h->d_slot_of, h->d_slot_role, h->d_eps, h->d_mu, h->d_Wp, h->d_design, h->d_y, h->d_scratch, h->dXprop,
                     h->dlogu, h->d_gather};
     for (void* b : bufs)
-        if (b) (void)hipFree(b);
+        if (b) (void)dev_free(h->cfg.device_id, b);
     for (auto& pe : h->pending) if (pe.ev) (void)hipEventDestroy(pe.ev);
     h->pending.clear();
     for (int b = 0; b < 2; ++b) {
-        if (h->d_rec[b] && !h->rec_in_arena) (void)hipFree(h->d_rec[b]);
-        if (b == 0 && h->d_live_err) (void)hipFree(h->d_live_err);
-        if (h->d_send[b]) (void)hipFree(h->d_send[b]);
-        if (h->d_recv[b]) (void)hipFree(h->d_recv[b]);
+        if (h->d_rec[b] && !h->rec_in_arena) (void)dev_free(h->cfg.device_id, h->d_rec[b]);
+        if (b == 0 && h->d_live_err) (void)dev_free(h->cfg.device_id, h->d_live_err);
+        if (h->d_send[b]) (void)dev_free(h->cfg.device_id, h->d_send[b]);
+        if (h->d_recv[b]) (void)dev_free(h->cfg.device_id, h->d_recv[b]);
         if (h->buf_done[b]) (void)hipEventDestroy(h->buf_done[b]);
     }
-    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
-    if (h->prod_stream) { if (!h->comm_dead) (void)hipStreamSynchronize(h->prod_stream); (void)hipStreamDestroy(h->prod_stream); }
+    if (h->comm_stream) stream_release(h->cfg.device_id, h->comm_stream, !h->comm_dead && hipStreamQuery(h->comm_stream) == hipSuccess);
+    if (h->prod_stream) { if (!h->comm_dead) (void)hipStreamSynchronize(h->prod_stream); stream_release(h->cfg.device_id, h->prod_stream, !h->comm_dead); }
     for (int b = 0; b < 2; ++b) if (h->prod_done[b]) (void)hipEventDestroy(h->prod_done[b]);
     if (h->prod_gate) (void)hipEventDestroy(h->prod_gate);
-    if (h->d_stage) (void)hipHostFree(h->d_stage);
+    if (h->d_stage) (void)host_free(h->d_stage);
     for (auto& pr : h->timed) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-    if (h->pinned_rhat) (void)hipHostFree(h->pinned_rhat);
-    if (h->d_safe_X) (void)hipFree(h->d_safe_X);
-    if (h->d_safe_lp) (void)hipFree(h->d_safe_lp);
-    if (h->d_spec_X) (void)hipFree(h->d_spec_X);
-    if (h->d_spec_lp) (void)hipFree(h->d_spec_lp);
+    if (h->pinned_rhat) (void)host_free(h->pinned_rhat);
+    if (h->d_safe_X) (void)dev_free(h->cfg.device_id, h->d_safe_X);
+    if (h->d_safe_lp) (void)dev_free(h->cfg.device_id, h->d_safe_lp);
+    if (h->d_spec_X) (void)dev_free(h->cfg.device_id, h->d_spec_X);
+    if (h->d_spec_lp) (void)dev_free(h->cfg.device_id, h->d_spec_lp);
     if (h->spec_ev) (void)hipEventDestroy(h->spec_ev);
     if (h->diag_ev) (void)hipEventDestroy(h->diag_ev);
-    if (h->diag_stream) (void)hipStreamDestroy(h->diag_stream);
-    if (h->stall_flag) (void)hipFree(h->stall_flag);
-    if (h->xdone) (void)hipHostFree(const_cast<long long*>(h->xdone));
+    if (h->diag_stream) stream_release(h->cfg.device_id, h->diag_stream, !h->comm_dead && hipStreamQuery(h->diag_stream) == hipSuccess);
+    if (h->stall_flag) (void)dev_free(h->cfg.device_id, h->stall_flag);
+    if (h->xdone) (void)host_free(const_cast<long long*>(h->xdone));
     if (!h->comm_dead) {                 // (a dead handle's communicators were aborted, which frees them)
         if (h->comm_side) (void)ncclCommDestroy(h->comm_side);
         if (h->comm) (void)ncclCommDestroy(h->comm);
     }
-    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->own_stream && h->stream) stream_release(h->cfg.device_id, h->stream, !h->comm_dead && hipStreamQuery(h->stream) == hipSuccess);
 }
 
 extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
@@ -492,7 +597,7 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
     if (cfg->stream) {
         h->stream = (hipStream_t)cfg->stream;
     } else {
-        CRCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        CRCHK(stream_acquire(cfg->device_id, &h->stream));
         h->own_stream = true;
     }
     h->block_offsets.assign(cfg->block_offsets, cfg->block_offsets + cfg->Nblocks + 1);
@@ -607,7 +712,7 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
             if (zb + 2 * rb + tb < 0xF0000000ull) {
                 h->arena = true;
                 h->arena_gens = ag;
-                CRCHK(hipMalloc((void**)&h->dZ, zb + 2 * rb + tb));
+                CRCHK(g_dev_pool.acquire((void**)&h->dZ, zb + 2 * rb + tb, cfg->device_id));
                 unsigned char* base = reinterpret_cast<unsigned char*>(h->dZ);
                 h->arena_rec[0] = reinterpret_cast<double*>(base + zb);
                 h->arena_rec[1] = reinterpret_cast<double*>(base + zb + rb);
@@ -615,52 +720,53 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
                 CRCHK(hipMemsetAsync(base + zb, 0, 2 * rb + tb, h->stream));       // row 0 / temperature 0: always legal
             }
         }
-        if (!h->arena) CRCHK(hipMalloc((void**)&h->dZ, zbytes));
+        if (!h->arena) CRCHK(g_dev_pool.acquire((void**)&h->dZ, zbytes, cfg->device_id));
+        h->pooled_dev = true;
     }
     // (the reference pads with zeros, demcz.jl:11; rows at or beyond M never leave the device, and here they hold
     //  the sentinel LIVE launches recognise an unpublished row by: fill_unwritten_rows() in demcz_set_state)
-    CRCHK(hipMalloc((void**)&h->d_live_err, 4 * sizeof(unsigned int)));
+    CRCHK(dev_malloc(h->cfg.device_id, (void**)&h->d_live_err, 4 * sizeof(unsigned int)));
     CRCHK(hipMemsetAsync(h->d_live_err, 0, 4 * sizeof(unsigned int), h->stream));
-    CRCHK(hipMalloc((void**)&h->dX, (size_t)N * d * sizeof(double)));
-    CRCHK(hipMalloc((void**)&h->dlp, (size_t)N * sizeof(double)));
+    CRCHK(dev_malloc(h->cfg.device_id, (void**)&h->dX, (size_t)N * d * sizeof(double)));
+    CRCHK(dev_malloc(h->cfg.device_id, (void**)&h->dlp, (size_t)N * sizeof(double)));
     if (cfg->Gcap > 0) {
         // (one allocation: a window kernel's history store of a pass covers both arrays with one buffer descriptor)
-        CRCHK(hipMalloc((void**)&h->dchain, (size_t)N * (d + 1) * cfg->Gcap * sizeof(double)));
+        CRCHK(g_dev_pool.acquire((void**)&h->dchain, (size_t)N * (d + 1) * cfg->Gcap * sizeof(double), cfg->device_id));
         h->dlogobj = h->dchain + (size_t)N * d * cfg->Gcap;
         h->hist_joint = true;
         CRCHK(hipMemsetAsync(h->dchain, 0, (size_t)N * (d + 1) * cfg->Gcap * sizeof(double), h->stream));   // demcz.jl:24
     }
-    CRCHK(hipMalloc((void**)&h->dlp_origin, (size_t)N * sizeof(double)));
-    CRCHK(dev_alloc_copy(&h->d_block_offsets, h->block_offsets.data(), h->block_offsets.size(), h->stream));
-    CRCHK(dev_alloc_copy(&h->d_slot_of, h->slot_of.data(), h->slot_of.size(), h->stream));
-    CRCHK(dev_alloc_copy(&h->d_eps, h->eps.data(), h->eps.size(), h->stream));
+    CRCHK(dev_malloc(h->cfg.device_id, (void**)&h->dlp_origin, (size_t)N * sizeof(double)));
+    CRCHK(dev_alloc_copy(&h->d_block_offsets, h->block_offsets.data(), h->block_offsets.size(), h->stream, cfg->device_id));
+    CRCHK(dev_alloc_copy(&h->d_slot_of, h->slot_of.data(), h->slot_of.size(), h->stream, cfg->device_id));
+    CRCHK(dev_alloc_copy(&h->d_eps, h->eps.data(), h->eps.size(), h->stream, cfg->device_id));
     {   // what every Philox block of a generation is: rows, a normal pair, or the accept uniform (per block, in order)
         std::vector<int32_t> role;
         for (int ib = 0; ib < cfg->Nblocks; ++ib) {
             const int nblk = (int)blockstep_nblk(h->block_offsets[ib + 1] - h->block_offsets[ib]);
             for (int t = 0; t < nblk; ++t) role.push_back(t == 0 ? 0 : (t == nblk - 1 ? 2 : 1));
         }
-        CRCHK(dev_alloc_copy(&h->d_slot_role, role.data(), role.size(), h->stream));
+        CRCHK(dev_alloc_copy(&h->d_slot_role, role.data(), role.size(), h->stream, cfg->device_id));
     }
     std::vector<double> wp, design_rm;
     if (cfg->target_kind == DEMCZ_TARGET_MVNORMAL || cfg->target_kind == DEMCZ_TARGET_ISO_QUAD)
-        CRCHK(dev_alloc_copy(&h->d_mu, cfg->mu, (size_t)d, h->stream));
+        CRCHK(dev_alloc_copy(&h->d_mu, cfg->mu, (size_t)d, h->stream, cfg->device_id));
     if (cfg->target_kind == DEMCZ_TARGET_MVNORMAL) {
         wp.resize((size_t)d * (d + 1) / 2);
         for (int i = 0; i < d; ++i)
             for (int j = 0; j <= i; ++j) wp[(size_t)i * (i + 1) / 2 + j] = cfg->W[i + (size_t)d * j];
-        CRCHK(dev_alloc_copy(&h->d_Wp, wp.data(), wp.size(), h->stream));
+        CRCHK(dev_alloc_copy(&h->d_Wp, wp.data(), wp.size(), h->stream, cfg->device_id));
     }
     if (cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) {
         design_rm.resize((size_t)cfg->nobs * d);
         for (int64_t o = 0; o < cfg->nobs; ++o)
             for (int j = 0; j < d; ++j) design_rm[(size_t)o * d + j] = cfg->design[o + cfg->nobs * j];
-        CRCHK(dev_alloc_copy(&h->d_design, design_rm.data(), design_rm.size(), h->stream));
-        CRCHK(dev_alloc_copy(&h->d_y, cfg->yobs, (size_t)cfg->nobs, h->stream));
+        CRCHK(dev_alloc_copy(&h->d_design, design_rm.data(), design_rm.size(), h->stream, cfg->device_id));
+        CRCHK(dev_alloc_copy(&h->d_y, cfg->yobs, (size_t)cfg->nobs, h->stream, cfg->device_id));
     }
     if (cfg->target_kind == DEMCZ_TARGET_HOST_CALLBACK) {
-        CRCHK(hipMalloc((void**)&h->dXprop, (size_t)N * d * sizeof(double)));
-        CRCHK(hipMalloc((void**)&h->dlogu, (size_t)N * sizeof(double)));
+        CRCHK(dev_malloc(h->cfg.device_id, (void**)&h->dXprop, (size_t)N * d * sizeof(double)));
+        CRCHK(dev_malloc(h->cfg.device_id, (void**)&h->dlogu, (size_t)N * sizeof(double)));
     }
     if (cfg->target_kind != DEMCZ_TARGET_HOST_CALLBACK) {
         // waves that run chains in one window launch (every one writes its two counters)
@@ -678,11 +784,11 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         h->acc_waves = waves;
         h->acc_slots = (int32_t)std::min<int64_t>(4096, std::max<int64_t>(64, (int64_t)(64ll << 20) / (waves * 8)));
         const size_t nb = (size_t)h->acc_slots * (size_t)waves * 2 * sizeof(unsigned int);
-        CRCHK(hipMalloc((void**)&h->d_acc, nb));
+        CRCHK(dev_malloc(h->cfg.device_id, (void**)&h->d_acc, nb));
         CRCHK(hipMemsetAsync(h->d_acc, 0, nb, h->stream));
     }
     h->stage_cap = std::max<int64_t>(4096, (int64_t)d * (d + 1) + 64);
-    CRCHK(hipHostMalloc((void**)&h->d_stage, (size_t)h->stage_cap * sizeof(double), hipHostMallocDefault));
+    CRCHK(host_malloc((void**)&h->d_stage, (size_t)h->stage_cap * sizeof(double)));
     CRCHK(hipStreamSynchronize(h->stream));   // the host vectors above go out of scope
 #undef CRCHK
     *out = h;
@@ -718,9 +824,9 @@ static int32_t ensure_scratch(demcz_handle* h, int64_t n)
     SYNCCHK(h, h->stream);
     if (h->diag_stream) SYNCCHK(h, h->diag_stream);      // a check may still be reading the old buffer
     if (h->prod_stream) SYNCCHK(h, h->prod_stream);      // (the checks of a wave-per-chain handle run there)
-    if (h->d_scratch) HIPCHK(h, hipFree(h->d_scratch));
+    if (h->d_scratch) HIPCHK(h, dev_free(h->cfg.device_id, h->d_scratch));
     h->d_scratch = nullptr; h->scratch_cap = 0;
-    HIPCHK(h, hipMalloc((void**)&h->d_scratch, (size_t)n * sizeof(double)));
+    HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->d_scratch, (size_t)n * sizeof(double)));
     h->scratch_cap = n;
     return DEMCZ_OK;
 }
@@ -828,6 +934,35 @@ extern "C" int32_t demcz_get_state(demcz_handle* h, double* X, double* logp, dou
     }
     SYNCCHK(h, h->stream);
     if (M) *M = h->M_app;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_get_archive_pinned(demcz_handle* h, double** Z, int64_t* M)
+{
+    if (!h || !Z || !M) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (!h->has_state) return fail(h, DEMCZ_ERR_STATE, "demcz_get_archive_pinned: no state set");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    int32_t rc = live_verify(h);
+    if (rc) return rc;
+    const int d = h->cfg.d;
+    const int64_t Mall = h->M_app;
+    rc = flush_exchanges(h);
+    if (rc) return rc;
+    rc = ensure_scratch(h, Mall * d);
+    if (rc) return rc;
+    double* host = nullptr;
+    HIPCHK(h, host_malloc((void**)&host, (size_t)Mall * d * sizeof(double)));
+    const int64_t tot = Mall * d;
+    hipLaunchKernelGGL(export_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->dZ,
+                       h->ZS, (int64_t)0, h->d_scratch, Mall, Mall, d);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(host, h->d_scratch, (size_t)tot * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess) {
+        (void)host_free(host);
+        return fail(h, DEMCZ_ERR_HIP, "demcz_get_archive_pinned: export failed");
+    }
+    rc = sync_stream(h, h->stream, "demcz_get_archive_pinned");
+    if (rc) { (void)host_free(host); return rc; }
+    *Z = host;
+    *M = Mall;
     return DEMCZ_OK;
 }
 
@@ -1002,7 +1137,7 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
             static const bool serial_env = getenv("DEMCZ_PRODUCE_SERIAL") != nullptr;     // diagnosis: producer in front of its consumer's successor, on the main stream
             if (P.consumer_blocks > 0 && !serial_env) {
                 if (!h->prod_stream) {
-                    HIPCHK(h, hipStreamCreateWithFlags(&h->prod_stream, hipStreamNonBlocking));
+                    HIPCHK(h, stream_acquire(h->cfg.device_id, &h->prod_stream));
                     HIPCHK(h, hipEventCreateWithFlags(&h->prod_gate, hipEventDisableTiming));
                     for (int b = 0; b < 2; ++b) HIPCHK(h, hipEventCreateWithFlags(&h->prod_done[b], hipEventDisableTiming));
                 }
@@ -1141,11 +1276,11 @@ static int32_t rec_reserve(demcz_handle* h, int64_t gens)
         return DEMCZ_OK;
     }
     for (int b = 0; b < 2; ++b) {
-        if (h->d_rec[b] && !h->rec_in_arena) HIPCHK(h, hipFree(h->d_rec[b]));
+        if (h->d_rec[b] && !h->rec_in_arena) HIPCHK(h, dev_free(h->cfg.device_id, h->d_rec[b]));
         h->d_rec[b] = nullptr;
         // (+ REC_PAD doubles: a consumer's last 16-byte chunk fetch may run past its row's last generation)
         const size_t nd = (size_t)gens * (size_t)rec_fields(h) * h->cfg.N + REC_PAD;
-        HIPCHK(h, hipMalloc((void**)&h->d_rec[b], nd * sizeof(double)));
+        HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->d_rec[b], nd * sizeof(double)));
         HIPCHK(h, hipMemsetAsync(h->d_rec[b], 0, nd * sizeof(double), h->stream));   // row 0: always a legal index
         h->rec_desc[b].valid = false;
     }
@@ -1342,7 +1477,7 @@ static int32_t exchange_batch(demcz_handle* h)
     h->pending.back().ev = done;                       // the entry that covers this batch
     h->pending.back().xseq = ++h->xseq;
     if (!h->xdone) {
-        HIPCHK(h, hipHostMalloc((void**)&h->xdone, sizeof(long long), hipHostMallocDefault));
+        HIPCHK(h, host_malloc((void**)&h->xdone, sizeof(long long)));
         *h->xdone = 0;
     }
     hipLaunchKernelGGL(mark_kernel, dim3(1), dim3(1), 0, h->comm_stream, h->xdone, (long long)h->xseq);
@@ -1604,6 +1739,77 @@ static int64_t live_span(demcz_handle* h)
     return std::max<int64_t>(h->cfg.K, std::min<int64_t>(span, 1 << 20));
 }
 
+// Streamed history: generations g_from..g_to (already enqueued on the compute stream) are copied to the pinned host mirrors on
+// the copy stream, behind an event -- while the compute stream goes on with the next slab.
+static int32_t stream_history(demcz_handle* h, int64_t g_from, int64_t g_to)
+{
+    if (!h->hs_on || h->cfg.Gcap <= 0 || g_to < g_from) return DEMCZ_OK;
+    const int64_t N = h->cfg.N, s0 = g_from - h->g0 - 1, G = g_to - g_from + 1;
+    const int d = h->cfg.d;
+    if (s0 < 0 || s0 + G > h->cfg.Gcap) return DEMCZ_OK;
+    hipEvent_t ev = h->after_launch_ev;
+    if (!ev) {
+        if (!h->diag_ev) HIPCHK(h, hipEventCreateWithFlags(&h->diag_ev, hipEventDisableTiming));
+        HIPCHK(h, hipEventRecord(h->diag_ev, h->stream));
+        h->after_launch_ev = ev = h->diag_ev;
+    }
+    HIPCHK(h, hipStreamWaitEvent(h->hs_stream, ev, 0));
+    HIPCHK(h, hipMemcpyAsync(h->hs_chain + (size_t)N * d * s0, h->dchain + (size_t)N * d * s0, (size_t)N * d * G * sizeof(double), hipMemcpyDeviceToHost, h->hs_stream));
+    HIPCHK(h, hipMemcpyAsync(h->hs_logobj + (size_t)N * s0, h->dlogobj + (size_t)N * s0, (size_t)N * G * sizeof(double), hipMemcpyDeviceToHost, h->hs_stream));
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_history_stream(demcz_handle* h, int32_t enabled)
+{
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    DEADCHK(h);
+    if (h->cfg.Gcap <= 0) return fail(h, DEMCZ_ERR_STATE, "demcz_history_stream: handle keeps no history (Gcap = 0)");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    if (enabled && !h->hs_on) {
+        const size_t nc = (size_t)h->cfg.N * h->cfg.d * h->cfg.Gcap * sizeof(double), nl = (size_t)h->cfg.N * h->cfg.Gcap * sizeof(double);
+        if (!h->hs_chain) HIPCHK(h, g_host_pool.acquire((void**)&h->hs_chain, nc, -1));
+        if (!h->hs_logobj) HIPCHK(h, g_host_pool.acquire((void**)&h->hs_logobj, nl, -1));
+        if (!h->hs_stream) HIPCHK(h, stream_acquire(h->cfg.device_id, &h->hs_stream));
+    }
+    h->hs_on = enabled != 0;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_get_history_view(demcz_handle* h, int64_t g_from, int64_t g_to, double** chain, double** log_obj)
+{
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    int32_t rc = check_hist_range(h, g_from, g_to, "demcz_get_history_view");
+    if (rc) return rc;
+    if (!h->hs_on || !h->hs_chain) return fail(h, DEMCZ_ERR_STATE, "demcz_get_history_view: call demcz_history_stream(h, 1) before the run");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    rc = live_verify(h);                       // (a voided LIVE slab is redone here, and the redo streams its generations again)
+    if (rc) return rc;
+    rc = sync_stream(h, h->hs_stream, "demcz_get_history_view");
+    if (rc) return rc;
+    const int64_t s0 = g_from - h->g0 - 1;
+    if (chain) *chain = h->hs_chain + (size_t)h->cfg.N * h->cfg.d * s0;
+    if (log_obj) *log_obj = h->hs_logobj + (size_t)h->cfg.N * s0;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_detach_history(demcz_handle* h, void** chain_base, void** logobj_base)
+{
+    if (!h || !chain_base || !logobj_base) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (!h->hs_chain) return fail(h, DEMCZ_ERR_STATE, "demcz_detach_history: no streamed history on this handle");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    if (h->hs_stream) { int32_t rc = sync_stream(h, h->hs_stream, "demcz_detach_history"); if (rc) return rc; }
+    *chain_base = h->hs_chain; *logobj_base = h->hs_logobj;
+    h->hs_chain = h->hs_logobj = nullptr;      // the caller owns them now: demcz_release_host_buffer
+    h->hs_on = false;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_release_host_buffer(void* base)
+{
+    if (base) g_host_pool.release(base, -1);
+    return DEMCZ_OK;
+}
+
 extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, double gamma, const double* temperature)
 {
     if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
@@ -1635,10 +1841,10 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         if (G > h->temp_cap) {
             { int32_t rcq = quiesce_all(h); if (rcq) return rcq; }
             SYNCCHK(h, h->stream);
-            if (h->dtemp) HIPCHK(h, hipFree(h->dtemp));
+            if (h->dtemp) HIPCHK(h, dev_free(h->cfg.device_id, h->dtemp));
             h->dtemp = nullptr; h->temp_cap = 0;
             // (+ 8: the wave-per-chain consumer fetches a pass's temperatures as whole 16-byte pieces, demcz_kernels_ps.h)
-            HIPCHK(h, hipMalloc((void**)&h->dtemp, (size_t)(G + 8) * sizeof(double)));
+            HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->dtemp, (size_t)(G + 8) * sizeof(double)));
             HIPCHK(h, hipMemsetAsync(h->dtemp, 0, (size_t)(G + 8) * sizeof(double), h->stream));
             h->temp_cap = G;
         }
@@ -1662,7 +1868,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     P.rec_fields = (h->lanes == DEMCZ_LAYOUT_SPLIT && h->split_kind == 2) ? h->cfg.d + 2 : 0;    // lane-per-parameter consumers: record-major
 #ifdef DEMCZ_STAMPS
     if (!h->d_stamps) {
-        HIPCHK(h, hipMalloc((void**)&h->d_stamps, (size_t)DEMCZ_STAMP_WGS * 16 * sizeof(unsigned long long)));
+        HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->d_stamps, (size_t)DEMCZ_STAMP_WGS * 16 * sizeof(unsigned long long)));
         HIPCHK(h, hipMemset(h->d_stamps, 0, (size_t)DEMCZ_STAMP_WGS * 16 * sizeof(unsigned long long)));
     }
     P.stamps = h->d_stamps;
@@ -1693,8 +1899,8 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
             if (h->live_log.empty()) {
                 const int64_t N = h->cfg.N;
                 const int d = h->cfg.d;
-                if (!h->d_safe_X) HIPCHK(h, hipMalloc((void**)&h->d_safe_X, (size_t)N * d * sizeof(double)));
-                if (!h->d_safe_lp) HIPCHK(h, hipMalloc((void**)&h->d_safe_lp, (size_t)N * sizeof(double)));
+                if (!h->d_safe_X) HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->d_safe_X, (size_t)N * d * sizeof(double)));
+                if (!h->d_safe_lp) HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->d_safe_lp, (size_t)N * sizeof(double)));
                 HIPCHK(h, hipMemcpyAsync(h->d_safe_X, h->dX, (size_t)N * d * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
                 HIPCHK(h, hipMemcpyAsync(h->d_safe_lp, h->dlp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
                 h->safe_M = h->M; h->safe_M_app = h->M_app; h->safe_g_done = h->g_done;
@@ -1785,6 +1991,9 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
             if ((int64_t)h->acc_log.size() > h->acc_slots) h->acc_log.pop_front();
         }
         ++timed_launches;
+        // streamed history: this launch's generations leave for the host mirrors behind it, while the next launch computes
+        // (one marker per launch on the compute stream: launches that stream are long ones)
+        if (h->hs_on && hist) { int32_t rch = stream_history(h, g, w_end); if (rch) return rch; }
         if (nbound > 0 && !h->external_append) {
             const int64_t rows = h->cfg.N * (sharded ? h->nranks : 1);
             if (E == 0) {
@@ -2035,7 +2244,7 @@ static int32_t rhat_enqueue(demcz_handle* h, int64_t g_from, int64_t g_to, doubl
         }
         qs = h->prod_stream;
     } else if (side && !h->comm) {
-        if (!h->diag_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->diag_stream, hipStreamNonBlocking));
+        if (!h->diag_stream) HIPCHK(h, stream_acquire(h->cfg.device_id, &h->diag_stream));
         if (!h->diag_ev) HIPCHK(h, hipEventCreateWithFlags(&h->diag_ev, hipEventDisableTiming));
         if (h->after_launch_ev) {
             HIPCHK(h, hipStreamWaitEvent(h->diag_stream, h->after_launch_ev, 0));
@@ -2313,7 +2522,7 @@ extern "C" int32_t demcz_comm_init(demcz_handle* h, const void* unique_id_128B, 
     h->nranks = nranks;
     h->rank = rank;
     if (const char* tenv = getenv("DEMCZ_COMM_TIMEOUT_MS")) h->comm_timeout_ms = std::max<long long>(0, atoll(tenv));
-    HIPCHK(h, hipMalloc((void**)&h->d_gather, (size_t)h->cfg.N * h->cfg.d * nranks * sizeof(double)));
+    HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->d_gather, (size_t)h->cfg.N * h->cfg.d * nranks * sizeof(double)));
     return DEMCZ_OK;
 }
 
@@ -2395,7 +2604,7 @@ extern "C" int32_t demcz_set_append_lag(demcz_handle* h, int32_t batches)
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     if (h->comm && batches > 0) {
         // side stream + double-buffered batch slabs: [E][d][n_loc] out, [R][E][d][n_loc] in
-        if (!h->comm_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+        if (!h->comm_stream) HIPCHK(h, stream_acquire(h->cfg.device_id, &h->comm_stream));
         // a communicator of its own for the side stream (collective over the parent: every rank makes this call)
         // (nothing of the parent communicator may still be queued on the compute stream when it is split)
         SYNCCHK(h, h->stream);
@@ -2403,11 +2612,11 @@ extern "C" int32_t demcz_set_append_lag(demcz_handle* h, int32_t batches)
         if (!h->comm_side) NCCLCHK(h, ncclCommSplit(h->comm, 0, h->rank, &h->comm_side, nullptr));
         const size_t one = (size_t)h->cfg.N * h->cfg.d * sizeof(double);
         for (int b = 0; b < 2; ++b) {
-            if (h->d_send[b]) HIPCHK(h, hipFree(h->d_send[b]));
-            if (h->d_recv[b]) HIPCHK(h, hipFree(h->d_recv[b]));
+            if (h->d_send[b]) HIPCHK(h, dev_free(h->cfg.device_id, h->d_send[b]));
+            if (h->d_recv[b]) HIPCHK(h, dev_free(h->cfg.device_id, h->d_recv[b]));
             h->d_send[b] = h->d_recv[b] = nullptr;
-            HIPCHK(h, hipMalloc((void**)&h->d_send[b], one * batches));
-            HIPCHK(h, hipMalloc((void**)&h->d_recv[b], one * batches * h->nranks));
+            HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->d_send[b], one * batches));
+            HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->d_recv[b], one * batches * h->nranks));
             if (!h->buf_done[b]) {
                 HIPCHK(h, hipEventCreateWithFlags(&h->buf_done[b], hipEventDisableTiming));
                 HIPCHK(h, hipEventRecord(h->buf_done[b], h->comm_stream));
@@ -2556,10 +2765,10 @@ static int32_t run_checked_body(demcz_handle* h, int64_t g_from, int64_t g_to, d
     if (max_checks * d > h->pinned_cap) {
         { int32_t rcq = quiesce_all(h); if (rcq) return rcq; }
         SYNCCHK(h, h->stream);
-        if (h->pinned_rhat) (void)hipHostFree(h->pinned_rhat);
+        if (h->pinned_rhat) (void)host_free(h->pinned_rhat);
         h->pinned_rhat = nullptr; h->pinned_cap = 0;
         const int64_t cap = std::max<int64_t>(max_checks, 1024) * d;       // (no reallocation between calls of different length)
-        HIPCHK(h, hipHostMalloc((void**)&h->pinned_rhat, (size_t)cap * sizeof(double), hipHostMallocDefault));
+        HIPCHK(h, host_malloc((void**)&h->pinned_rhat, (size_t)cap * sizeof(double)));
         h->pinned_cap = cap;
     }
     double* pinned = h->pinned_rhat;
@@ -2576,8 +2785,8 @@ static int32_t run_checked_body(demcz_handle* h, int64_t g_from, int64_t g_to, d
     const bool speculate = !monitor && !h->comm && h->lag == 0 && !h->external_append && !temperature;
     const int64_t N = h->cfg.N;
     if (speculate) {
-        if (!h->d_spec_X) HIPCHK(h, hipMalloc((void**)&h->d_spec_X, (size_t)N * d * sizeof(double)));
-        if (!h->d_spec_lp) HIPCHK(h, hipMalloc((void**)&h->d_spec_lp, (size_t)N * sizeof(double)));
+        if (!h->d_spec_X) HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->d_spec_X, (size_t)N * d * sizeof(double)));
+        if (!h->d_spec_lp) HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->d_spec_lp, (size_t)N * sizeof(double)));
         if (!h->spec_ev) HIPCHK(h, hipEventCreateWithFlags(&h->spec_ev, hipEventDisableTiming));
     }
     bool ahead = false;                 // the slab starting at g has already been enqueued
@@ -2634,6 +2843,7 @@ static int32_t run_checked_body(demcz_handle* h, int64_t g_from, int64_t g_to, d
                             rc = fail(h, DEMCZ_ERR_HIP, "demcz_run_checked: restore failed");
                             break;
                         }
+                        if (h->hs_on) { h->after_launch_ev = nullptr; rc = stream_history(h, nxt + 1, h->g_done); if (rc) break; }   // (the mirrors read zeros there too)
                         h->M_app = M_before;
                         h->M = M_before;
                         h->g_done = nxt;

@@ -29,6 +29,21 @@ def blocks_to_csr(blockindex, d):
     return offs, idx
 
 
+class _PinnedOwner:
+    """Pinned host buffers detached from a handle: returned to the library's pool when nothing refers to them any more."""
+
+    def __init__(self, L, bases):
+        self._L, self._bases = L, [b for b in bases if b]
+
+    def __del__(self):
+        try:
+            for b in self._bases:
+                self._L.demcz_release_host_buffer(C.c_void_p(b))
+        except Exception:
+            pass
+        self._bases = []
+
+
 class HipEngine:
     """Device state of one shard: Z replica, current states, history, RNG position."""
 
@@ -99,8 +114,13 @@ class HipEngine:
         self._chk(self._L.demcz_get_state(self._h, _lib.ptr(X), _lib.ptr(lp), None, 0, C.byref(M)))
         Z = None
         if with_Z:
-            Z = np.empty((M.value, self.d), order="F")
-            self._chk(self._L.demcz_get_state(self._h, None, None, _lib.ptr(Z), M.value, None))
+            # the archive comes back in a pinned buffer of the library's pool (no page faults of a fresh 41 MB array under the
+            # copy); the array below is a view of it, and the buffer returns to the pool with the array
+            pz, Mz = C.c_void_p(), C.c_int64()
+            self._chk(self._L.demcz_get_archive_pinned(self._h, C.byref(pz), C.byref(Mz)))
+            buf = (C.c_double * (Mz.value * self.d)).from_address(pz.value)
+            buf._owner = _PinnedOwner(self._L, [pz.value])
+            Z = np.ctypeslib.as_array(buf).reshape((Mz.value, self.d), order="F")
         return X, lp, Z, int(M.value)
 
     @property
@@ -201,6 +221,30 @@ class HipEngine:
         lo = np.empty((self.N, G), order="F") if log_obj else None
         self._chk(self._L.demcz_get_history(self._h, int(g_from), int(g_to), _lib.ptr(ch), _lib.ptr(lo)))
         return ch, lo
+
+    # -- streamed history: pinned host mirrors filled while the GPU runs (demcz_history_stream) -------------------------
+    def history_stream(self, enabled=True):
+        self._chk(self._L.demcz_history_stream(self._h, 1 if enabled else 0))
+        self._streaming = bool(enabled)
+
+    def take_history(self, g_from, g_to):
+        """mc.chain[:, :, g_from:g_to], mc.log_obj[:, g_from:g_to] as NumPy arrays OVER the library's pinned mirrors (no copy):
+        the mirrors are detached from the handle and go back to the library's pool when the last array over them is
+        collected.  One call per run (the handle keeps no mirrors afterwards)."""
+        G = g_to - g_from + 1
+        pc, pl = C.c_void_p(), C.c_void_p()
+        self._chk(self._L.demcz_get_history_view(self._h, int(g_from), int(g_to), C.byref(pc), C.byref(pl)))
+        bc, bl = C.c_void_p(), C.c_void_p()
+        self._chk(self._L.demcz_detach_history(self._h, C.byref(bc), C.byref(bl)))
+        self._streaming = False
+        owner = _PinnedOwner(self._L, [bc.value, bl.value])
+        cbuf = (C.c_double * (self.N * self.d * G)).from_address(pc.value)
+        lbuf = (C.c_double * (self.N * G)).from_address(pl.value)
+        cbuf._owner = owner          # (NumPy keeps the ctypes object alive; the ctypes object keeps the owner alive)
+        lbuf._owner = owner
+        chain = np.ctypeslib.as_array(cbuf).reshape((self.N, self.d, G), order="F")
+        lobj = np.ctypeslib.as_array(lbuf).reshape((self.N, G), order="F")
+        return chain, lobj
 
     def get_changed(self, g_from, g_to):
         out = np.zeros(g_to - g_from + 1, dtype=np.int64)

@@ -264,6 +264,19 @@ class _Runner:
         return s[0] / s[1]
 
     # results ----------------------------------------------------------------------------------
+    def stream_history(self):
+        """Single device engine: have the library stream every slab's history to pinned host mirrors while the next slab runs
+        (demcz_history_stream); `history()` then returns arrays over those mirrors without copying.  Returns whether it is on."""
+        e = self.engines[0]
+        self._streamed = False
+        if len(self.engines) == 1 and hasattr(e, "history_stream") and getattr(e, "Gcap", 0) > 0:
+            try:
+                e.history_stream(True)
+                self._streamed = True
+            except Exception:
+                self._streamed = False
+        return self._streamed
+
     def prepare_result_arrays(self, G, threads=4):
         """The arrays the history will come back into (mc.chain N x d x G, mc.log_obj N x G), made NOW and their pages
         touched by a few threads while the GPU runs: a fresh 0.5 GB array takes the download 20-28 ms of page faults, a
@@ -298,7 +311,11 @@ class _Runner:
             t.join()
         return res[0], res[1]
 
-    def history(self, g_from, g_to):
+    def history(self, g_from, g_to, take=False):
+        """`take`: the run is over and these are its result arrays -- a streamed history is handed over without a copy."""
+        if take and len(self.engines) == 1 and getattr(self, "_streamed", False) and g_from == 1:
+            self._streamed = False          # (the mirrors leave the handle with the arrays)
+            return self.engines[0].take_history(g_from, g_to)
         if len(self.engines) == 1:          # (the engine's arrays are already column-major: no copy of 0.4 GB at C2)
             out = self._take_result_arrays()
             return self.engines[0].get_history(g_from, g_to, out=out) if out is not None else self.engines[0].get_history(g_from, g_to)
@@ -406,8 +423,8 @@ def _run_generations(runner, logobj, g_from, g_to, gamma, Nblocks, temperature=N
 
 
 def _finish(runner, prevrun, G, padded_Z, Mcap, rng_offset=0):
-    chain, lobj = runner.history(1, G)
-    X, lp, Z, M = runner.state()
+    X, lp, Z, M = runner.state()               # (first: it only needs the compute stream; the history copies are still leaving)
+    chain, lobj = runner.history(1, G, take=True)
     if padded_Z:
         Zp = np.zeros((Mcap, Z.shape[1]), order="F")
         Zp[:M] = Z
@@ -470,7 +487,8 @@ def demcz_sample(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
                           sharding=sharding, device_id=device_id, engine_factory=engine_factory,
                           lanes_per_chain=lanes_per_chain, stream=stream, rng_offset=rng_offset, append_lag=append_lag)
     if prevrun is None:
-        runner.prepare_result_arrays(Ngeneration)
+        if not (is_device_target(logobj) and runner.stream_history()):
+            runner.prepare_result_arrays(Ngeneration)
     Mcap = M0 + int(math.ceil(N * Ngeneration / K))
     try:
         if verbose:
@@ -545,7 +563,8 @@ def demcz_anneal(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
                           sharding=sharding, device_id=device_id, engine_factory=engine_factory,
                           lanes_per_chain=lanes_per_chain, stream=stream, rng_offset=rng_offset, append_lag=append_lag)
     if prevrun is None:
-        runner.prepare_result_arrays(Ngeneration)
+        if not (is_device_target(logobj) and runner.stream_history()):
+            runner.prepare_result_arrays(Ngeneration)
     Mcap = M0 + int(math.ceil(N * Ngeneration / K))
 
     def temp(ig):

@@ -121,6 +121,10 @@ int32_t demcz_set_state(demcz_handle* h, const double* X, const double* logp,
  * (demcz.jl:51).  Any pointer may be NULL.  Z is written with leading dimension ldZ >= M. */
 int32_t demcz_get_state(demcz_handle* h, double* X, double* logp, double* Z, int64_t ldZ, int64_t* M);
 
+/* Z[1:M,:] (demcz.jl:51) in a pinned host buffer of the library's pool, M x d column-major with leading dimension M: no page
+ * faults of a fresh array under the copy (41 MB at the end of a C2 run).  The caller gives *Z back with demcz_release_host_buffer. */
+int32_t demcz_get_archive_pinned(demcz_handle* h, double** Z, int64_t* M);
+
 /* Map generation index -> history slot: generation g is stored at slot g - g0 - 1, so the
  * device keeps generations g0+1 .. g0+Gcap.  Default g0 = 0. */
 int32_t demcz_set_history_origin(demcz_handle* h, int64_t g0);
@@ -141,6 +145,20 @@ int32_t demcz_synchronize(demcz_handle* h);
 /* Copy history out: mc.chain[:, :, g_from:g_to] and mc.log_obj[:, g_from:g_to] (DEMC.jl:11-12).
  * Either pointer may be NULL. */
 int32_t demcz_get_history(demcz_handle* h, int64_t g_from, int64_t g_to, double* chain, double* log_obj);
+
+/* Streamed history.  mc.chain / mc.log_obj of a C2 run are half a gigabyte that only exists to be handed back (DEMC.jl:10-12);
+ * copied after the run they cost four times what the run does.  With streaming enabled (before demcz_run) the library keeps
+ * pinned host mirrors of both arrays -- same layout, generation g at slot g - g0 - 1 -- and every demcz_run call's generations
+ * leave on a copy stream while the compute stream goes on with the next call.
+ *   demcz_get_history_view   waits for the copies of g_from..g_to (redoing a voided LIVE slab first) and returns pointers INTO the
+ *                            mirrors: N x d x G and N x G column-major, no further copy.  Valid until the handle is destroyed ...
+ *   demcz_detach_history     ... unless the mirrors are detached: they then belong to the caller (a Julia Array made with
+ *                            unsafe_wrap, a NumPy array over the pointer) until demcz_release_host_buffer gives each back.
+ * The mirrors come from a process-wide pool of pinned buffers: a second run of the same shape allocates nothing. */
+int32_t demcz_history_stream(demcz_handle* h, int32_t enabled);
+int32_t demcz_get_history_view(demcz_handle* h, int64_t g_from, int64_t g_to, double** chain, double** log_obj);
+int32_t demcz_detach_history(demcz_handle* h, void** chain_base, void** logobj_base);
+int32_t demcz_release_host_buffer(void* base);
 
 /* changed[g - g_from] = number of local chains whose log_obj at generation g differs from the
  * one before it -- the event counted by sum(diff(log_obj, dims=2) .!= 0) at demcz.jl:42 and

@@ -677,3 +677,36 @@ def test_host_closure_path_equals_oracle(demc, oracle, tempered):
     ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, blocks, w["eps_scale"], w["gamma"], seed, temperature=T)
     assert np.array_equal(mc.chain, ref["chain"]) and np.array_equal(mc.log_obj, ref["log_obj"])
     assert np.array_equal(mc.Xcurrent, ref["X"]) and np.array_equal(Z, ref["Z"])
+
+
+def test_streamed_history_equals_copied_history(demc, oracle):
+    """demcz_history_stream: the pinned host mirrors filled slab by slab while the GPU runs hold exactly what demcz_get_history
+    copies afterwards -- through LIVE launches, a forced hand-off redo (the redone slabs are streamed again), a discarded
+    speculative slab (zeros), and the drop-in surface (demcz_sample returns arrays over the mirrors)."""
+    d, N, K, G = 5, 512, 10, 600
+    w = demc.workloads.mvnormal_problem(d, N)
+    M0 = w["Zinit"].shape[0]
+    for force_redo in (False, True):
+        e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K + 1), Gcap=G, blockindex=[range(d)], eps_scale=w["eps_scale"], seed=9,
+                           target=w["target"])
+        e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+        e.history_stream(True)
+        if force_redo:
+            e.debug_set_live_fault(1, 301)              # poll limit 1 from generation 301 on: the second call's hand-off fails
+        e.run(1, 300, w["gamma"])
+        e.run(301, G, w["gamma"])
+        ch_copy, lo_copy = e.get_history(1, G)
+        ch, lo = e.take_history(1, G)
+        assert e.live_status()[1] == (1 if force_redo else 0)
+        e.close()
+        ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], 9)
+        assert np.array_equal(ch, ch_copy) and np.array_equal(lo, lo_copy)
+        assert np.array_equal(ch, ref["chain"]) and np.array_equal(lo, ref["log_obj"])
+        assert ch.flags.f_contiguous and lo.flags.f_contiguous
+        del ch, lo                                      # (the mirrors go back to the library's pool)
+    # autostop with a threshold: the slab that ran ahead of the stop decision is discarded -- zeros in the mirrors too
+    opts = demc.demcopt(d, N=N, K=K, Ngeneration=G, eps_scale=w["eps_scale"], verbose=False, autostop="Rhat", autostop_every=100, autostop_Rhat=1.3)
+    mc, Z = demc.demcz_sample(w["target"], w["Zinit"], opts, seed=9)
+    g_stop = mc.chain.shape[2]
+    assert g_stop < G and g_stop % 100 == 0
+    assert np.array_equal(mc.chain, ref["chain"][:, :, :g_stop]) and np.array_equal(mc.log_obj, ref["log_obj"][:, :g_stop])
