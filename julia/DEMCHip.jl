@@ -117,6 +117,26 @@ function history(h, N, d, g_from, g_to)
     chk(ccall((:demcz_get_history, libdemcz), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Float64}), h, g_from, g_to, chain, log_obj), h)
     chain, log_obj
 end
+# Streamed history (demcz_history_stream): the library copies every slab to pinned host mirrors while the next slab computes;
+# take_history wraps the mirrors as Julia arrays WITHOUT copying (unsafe_wrap), detaches them from the handle and hands them back
+# to the library's pool when the arrays are garbage-collected (the finalizer sits on `chain`; `log_obj` keeps `chain` alive).
+history_stream(h, on=true) = chk(ccall((:demcz_history_stream, libdemcz), Int32, (Ptr{Cvoid}, Int32), h, on ? 1 : 0), h)
+function take_history(h, N, d, g_from, g_to)
+    G = g_to - g_from + 1
+    pc = Ref{Ptr{Float64}}(C_NULL); pl = Ref{Ptr{Float64}}(C_NULL)
+    chk(ccall((:demcz_get_history_view, libdemcz), Int32, (Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Float64}}, Ref{Ptr{Float64}}), h, g_from, g_to, pc, pl), h)
+    bc = Ref{Ptr{Cvoid}}(C_NULL); bl = Ref{Ptr{Cvoid}}(C_NULL)
+    chk(ccall((:demcz_detach_history, libdemcz), Int32, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ref{Ptr{Cvoid}}), h, bc, bl), h)
+    chain = unsafe_wrap(Array, pc[], (N, d, G); own=false)
+    log_obj = unsafe_wrap(Array, pl[], (N, G); own=false)
+    bases = (bc[], bl[])
+    finalizer(chain) do _
+        for b in bases
+            ccall((:demcz_release_host_buffer, libdemcz), Int32, (Ptr{Cvoid},), b)
+        end
+    end
+    chain, log_obj            # keep `chain` referenced for as long as `log_obj` is used (MC holds both)
+end
 function state(h, N, d)
     M = Ref{Int64}(0); X = Matrix{Float64}(undef, N, d); lp = Vector{Float64}(undef, N)
     chk(ccall((:demcz_get_state, libdemcz), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ref{Int64}), h, X, lp, C_NULL, 0, M), h)
@@ -306,6 +326,8 @@ function demcz_sample(t::LogObj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, b
     try
         set_state(h, X, lp, Matrix{Float64}(Zmat))
         drawn == 0 || set_rng_offset(h, drawn)                                         # the chains' streams continue
+        streamed = t isa DeviceTarget
+        streamed && history_stream(h)                                                  # slabs leave for the host while the next ones run
         ig = 0
         if autostop == :Rhat && t isa DeviceTarget                                     # demcz.jl:30-53 in one call
             ig = run_checked!(h, 1, Ngeneration, γ, autostop_every, autostop_Rhat)
@@ -321,8 +343,8 @@ function demcz_sample(t::LogObj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, b
         if autostop == :Rhat && ig % autostop_every == 0 && maximum(rhat(h, ig - autostop_every + 1, ig, d)) < autostop_Rhat
             sum(accept_ratio(h, ig - autostop_every + 1, ig, N)) / N < 0.1 && println("Warning: accept ratio below 10% on average")   # demcz.jl:42-46
         end
-        chain, log_obj = history(h, N, d, 1, ig)                                       # demcz.jl:47
         Xc, lpc, Z = state(h, N, d)                                                    # Z[1:M,:], demcz.jl:51
+        chain, log_obj = streamed ? take_history(h, N, d, 1, ig) : history(h, N, d, 1, ig)   # demcz.jl:47 (no copy when streamed)
         mc = prevrun === nothing ? MC(chain, log_obj, Xc, lpc) :
              MC(cat(prevrun.chain, chain, dims=3), cat(prevrun.log_obj, log_obj, dims=2), Xc, lpc)   # demcz.jl:58-59
         return mc, Z

@@ -18,7 +18,8 @@ JL2C = {
     "Ptr{Int32}": {"int32_t*", "const int32_t*"}, "Ref{Int32}": {"int32_t*"},
     "Ptr{Cvoid}": {"demcz_handle*", "const demcz_handle*", "void*", "const void*"},
     "Ptr{UInt8}": {"void*", "const void*"},
-    "Ref{Ptr{Cvoid}}": {"demcz_handle**"},
+    "Ref{Ptr{Cvoid}}": {"demcz_handle**", "void**"},
+    "Ref{Ptr{Float64}}": {"double**"},
     "Ref{DemczConfig}": {"const demcz_config*"},
     "Cstring": {"const char*"},
 }
