@@ -443,6 +443,7 @@ constexpr size_t REC_PAD = 64;       // doubles behind a record buffer: a consum
 constexpr int PC_CONSUMER_CHAINS = 8;       // chains per consumer workgroup of the replicated split layout: 8 lanes per chain
 static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t nobs, int max_blocklen, int nblocks);
 static bool pc_available(int target_kind, int d, bool full_block);
+static bool mlb32_wanted(int64_t N);
 static bool split_ml_available(int target_kind, int d, bool full_block, int64_t nobs);
 static bool ps_available(int target_kind, int d);
 static int64_t live_wg_capacity(demcz_handle* h);
@@ -617,22 +618,24 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         int maxb = 0;
         for (int ib = 0; ib < cfg->Nblocks; ++ib) maxb = std::max(maxb, h->block_offsets[ib + 1] - h->block_offsets[ib]);
         const int L = ml_lanes_available(cfg->target_kind, d, h->full_block, cfg->nobs, maxb, cfg->Nblocks);
+        // d = 20 in blocks, split form chosen by the library: 32 lanes per chain (two chains to a wave, one parameter a lane)
+        const int Lsplit = (L == 16 && d == 20 && !h->full_block && cfg->lanes_per_chain == 0 && cfg->N <= 4096 && mlb32_wanted(cfg->N)) ? 32 : L;
         // 32-bit row indices in the records, 32-bit byte offsets into the archive
         const bool idx32 = cfg->Mcap <= 0xffffffffll && (double)cfg->Mcap * 8.0 * (((d + 7) / 8) * 8) < 4294967296.0;
         const int kind = !idx32 ? 0 : pc_available(cfg->target_kind, d, h->full_block) ? 1
                          : split_ml_available(cfg->target_kind, d, h->full_block, cfg->nobs) ? 2
                          : (!h->full_block && cfg->target_kind == DEMCZ_TARGET_MVNORMAL && L > 1) ? 3 : 0;
-        h->split_lanes = (kind == 2) ? 16 : (kind == 3) ? L : 0;
+        h->split_lanes = (kind == 2) ? 16 : (kind == 3) ? Lsplit : 0;
         {   // four-wave workgroups once there is a chain wave for every SIMD (see demcz_kernels_ml.h, ML_WAVES)
             int cus = 0;
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device_id) != hipSuccess) cus = 0;
-            const int lanes_pc = (kind == 2) ? 16 : (L > 1 ? L : 64);
+            const int lanes_pc = (kind == 2) ? 16 : (kind == 3) ? Lsplit : (L > 1 ? L : 64);
             const int64_t chain_waves = (cfg->N * lanes_pc + 63) / 64;
             h->wpw = (cus > 0 && chain_waves >= 4ll * cus) ? ML_WAVES : 1;
         }
         // chains per consumer workgroup
         h->split_per_wg = (kind == 1) ? PC_CONSUMER_CHAINS : (kind == 2) ? ((cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? LR16_CHAINS : 4 * h->wpw)
-                          : (kind == 3) ? h->wpw * (64 / L) : 1;
+                          : (kind == 3) ? h->wpw * (64 / Lsplit) : 1;
         const bool split_ok = kind != 0;
         // one wave per chain (demcz_kernels_ps.h): where the replicated consumer is built and a pass's draws fit one DMA
         const bool ps_ok = (kind == 1 || kind == 2) && h->full_block && ps_available(cfg->target_kind, d);
@@ -1032,6 +1035,17 @@ static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t n
     return 0;
 }
 
+// Block updates at d = 20 (C3), split form: sixteen lanes per chain put four chains on a wave and ONE wave on a SIMD at C3's 4096
+// chains.  Thirty-two lanes per chain (one parameter a lane, twelve lanes of a chain idle) make it two waves per SIMD that could
+// fill each other's LDS waits -- measured (scripts/ab_c3.sh, DEMCZ_MLB_L32=1; bit-exact): 55.2 us per K-window against 45.4:
+// the block-step is bound by the instructions it issues, not by their latencies, and the idle lanes' share of them is lost.
+// Kept as an experiment switch, off by default.
+static bool mlb32_wanted(int64_t)
+{
+    static const char* env = getenv("DEMCZ_MLB_L32");
+    return env && atoi(env) != 0;
+}
+
 // split layout (demcz_kernels_pc.h)
 static bool pc_available(int target_kind, int d, bool full_block)
 {
@@ -1220,7 +1234,7 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
         case 5: DEMCZ_LAUNCH_MLB_REC(5, 8); break;
         case 6: DEMCZ_LAUNCH_MLB_REC(6, 8); break;
         case 10: DEMCZ_LAUNCH_MLB_REC(10, 8); break;
-        case 20: DEMCZ_LAUNCH_MLB_REC(20, 16); break;
+        case 20: if (h->split_lanes == 32) DEMCZ_LAUNCH_MLB_REC(20, 32); else DEMCZ_LAUNCH_MLB_REC(20, 16); break;
         default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
         }
 #undef DEMCZ_LAUNCH_MLB_REC
@@ -1658,7 +1672,8 @@ static int64_t live_wg_capacity(demcz_handle* h)
         case 5: f = reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 5, 8, true, true>); break;
         case 6: f = reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 6, 8, true, true>); break;
         case 10: f = reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 10, 8, true, true>); break;
-        case 20: f = reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 20, 16, true, true>); break;
+        case 20: f = (h->split_lanes == 32) ? reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 20, 32, true, true>)
+                                             : reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 20, 16, true, true>); break;
         }
         if (!f || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 64 * h->wpw, 0) != hipSuccess) per_cu = 0;
     } else if (h->split_kind == 2 && h->lr_spec) {

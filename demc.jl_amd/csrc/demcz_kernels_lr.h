@@ -27,6 +27,9 @@
 
 namespace demcz {
 
+// the A operand has 4 * ceil(D / 4) columns: a spare one takes the observations (see A_l below)
+template <int D> constexpr bool LR_FOLD_Y = (D % 4) != 0;
+
 constexpr int LR16_WAVES = 4;        // waves per workgroup = residue quarters
 constexpr int LR16_CHAINS = 16;      // chains per workgroup = columns of the instruction
 
@@ -85,7 +88,10 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr16(const Wind
         const int row = ll & 15, kk = ll >> 4;
         const int64_t o = 16 * (int64_t)(4 * T + (row >> 2)) + 4 * ww + (row & 3);
         const int col = 4 * m + kk;
-        A_l[i] = (o < nobs && col < D) ? P.tp.design[o * D + col] : 0.0;
+        // (LR_FOLD_Y: where D leaves a k slot free, the observation itself is column D of the A operand and the B operand there is
+        //  -1: the last fma of the instruction's k chain is fma(y_o, -1, X_o b) = -(y_o - X_o b), rounded once like the
+        //  subtraction it replaces, and its square is the same double -- the residual costs no vector instruction of its own)
+        A_l[i] = (o < nobs && col < D) ? P.tp.design[o * D + col] : ((LR_FOLD_Y<D> && o < nobs && col == D) ? P.tp.yobs[o] : 0.0);
     }
     // y_l[((T 4 + w) 4 + q) 4 + reg] = y[16 (4T + reg) + 4w + q]
     for (int i = tid; i < ngrp * LR16_WAVES * 16; i += 64 * LR16_WAVES) {
@@ -270,7 +276,7 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr16(const Wind
             const double t2 = epsv[m] * zt[m];
             const double delta = t1 + t2;
             xp[m] = x[m] + delta;
-            bop[m] = own[m] ? xp[m] : 0.0;
+            bop[m] = own[m] ? xp[m] : ((LR_FOLD_Y<D> && 4 * m + q == D) ? -1.0 : 0.0);
         }
         const double temp = P.temperature ? P.temperature[gi] : 1.0;
         __builtin_amdgcn_sched_barrier(0);
@@ -293,13 +299,19 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr16(const Wind
             const double* Aw = A_l + (size_t)w * NMF * 64 + l;
             const double* yw = y_l + (size_t)(w * 4 + q) * 4;
             auto finish = [&](const lr_d4& a, int T) {
-                const double2 y01 = reinterpret_cast<const double2*>(yw + (size_t)T * 64)[0];
-                const double2 y23 = reinterpret_cast<const double2*>(yw + (size_t)T * 64)[1];
-                double e;
-                e = y01.x - a[0]; sacc = fma(e, e, sacc);
-                e = y01.y - a[1]; sacc = fma(e, e, sacc);
-                e = y23.x - a[2]; sacc = fma(e, e, sacc);
-                e = y23.y - a[3]; sacc = fma(e, e, sacc);
+                if constexpr (LR_FOLD_Y<D>) {
+                    sacc = fma(a[0], a[0], sacc); sacc = fma(a[1], a[1], sacc);
+                    sacc = fma(a[2], a[2], sacc); sacc = fma(a[3], a[3], sacc);
+                    (void)T; (void)yw;
+                } else {
+                    const double2 y01 = reinterpret_cast<const double2*>(yw + (size_t)T * 64)[0];
+                    const double2 y23 = reinterpret_cast<const double2*>(yw + (size_t)T * 64)[1];
+                    double e;
+                    e = y01.x - a[0]; sacc = fma(e, e, sacc);
+                    e = y01.y - a[1]; sacc = fma(e, e, sacc);
+                    e = y23.x - a[2]; sacc = fma(e, e, sacc);
+                    e = y23.y - a[3]; sacc = fma(e, e, sacc);
+                }
             };
             int T = 0;
             // (tried: software-pipelining the batches so that the vector pipe squares batch b-1 while the matrix pipe runs
@@ -471,7 +483,10 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr8s(const Wind
         const int row = ll & 15, kk = ll >> 4;
         const int64_t o = 16 * (int64_t)(4 * T + (row >> 2)) + 4 * ww + (row & 3);
         const int col = 4 * m + kk;
-        A_l[i] = (o < nobs && col < D) ? P.tp.design[o * D + col] : 0.0;
+        // (LR_FOLD_Y: where D leaves a k slot free, the observation itself is column D of the A operand and the B operand there is
+        //  -1: the last fma of the instruction's k chain is fma(y_o, -1, X_o b) = -(y_o - X_o b), rounded once like the
+        //  subtraction it replaces, and its square is the same double -- the residual costs no vector instruction of its own)
+        A_l[i] = (o < nobs && col < D) ? P.tp.design[o * D + col] : ((LR_FOLD_Y<D> && o < nobs && col == D) ? P.tp.yobs[o] : 0.0);
     }
     for (int i = tid; i < ngrp * LR16_WAVES * 16; i += 64 * LR16_WAVES) {
         const int reg = i & 3, qq = (i >> 2) & 3, ww = (i >> 4) & 3, T = i >> 6;
@@ -638,7 +653,7 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr8s(const Wind
             const double t2 = epsv[m] * zt[m];
             const double delta = t1 + t2;
             xp[m] = x[m] + delta;
-            bop[m] = own[m] ? xp[m] : 0.0;
+            bop[m] = own[m] ? xp[m] : ((LR_FOLD_Y<D> && 4 * m + q == D) ? -1.0 : 0.0);
         }
         __builtin_amdgcn_sched_barrier(0);
         LR_TICK(6);
@@ -672,13 +687,19 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr8s(const Wind
             const double* Aw = A_l + (size_t)w * NMF * 64 + l;
             const double* yw = y_l + (size_t)(w * 4 + q) * 4;
             auto finish = [&](const lr_d4& a, int T) {
-                const double2 y01 = reinterpret_cast<const double2*>(yw + (size_t)T * 64)[0];
-                const double2 y23 = reinterpret_cast<const double2*>(yw + (size_t)T * 64)[1];
-                double e;
-                e = y01.x - a[0]; sacc = fma(e, e, sacc);
-                e = y01.y - a[1]; sacc = fma(e, e, sacc);
-                e = y23.x - a[2]; sacc = fma(e, e, sacc);
-                e = y23.y - a[3]; sacc = fma(e, e, sacc);
+                if constexpr (LR_FOLD_Y<D>) {
+                    sacc = fma(a[0], a[0], sacc); sacc = fma(a[1], a[1], sacc);
+                    sacc = fma(a[2], a[2], sacc); sacc = fma(a[3], a[3], sacc);
+                    (void)T; (void)yw;
+                } else {
+                    const double2 y01 = reinterpret_cast<const double2*>(yw + (size_t)T * 64)[0];
+                    const double2 y23 = reinterpret_cast<const double2*>(yw + (size_t)T * 64)[1];
+                    double e;
+                    e = y01.x - a[0]; sacc = fma(e, e, sacc);
+                    e = y01.y - a[1]; sacc = fma(e, e, sacc);
+                    e = y23.x - a[2]; sacc = fma(e, e, sacc);
+                    e = y23.y - a[3]; sacc = fma(e, e, sacc);
+                }
             };
             int T = 0;
             for (; T + TF <= ngrp; T += TF) {
