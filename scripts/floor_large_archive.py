@@ -1,5 +1,5 @@
 """Floor of a C2 launch's own work at a LARGE archive: K = 1000 (no row hand-off inside a launch) with an initial
-archive of M0 rows, so the gathers miss the L2 as they do late in a K = 10 run.  usage: floor_large_archive.py [M0] [slabs]"""
+archive of M0 rows, so the gathers miss the L2 as they do late in a K = 10 run.  usage: floor_large_archive.py [M0] [slabs] [K]   (K = 10: the LIVE launch itself at that archive size)"""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -8,7 +8,8 @@ import demc_jl_amd as demc
 
 M0 = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-N, d, K = 1024, 5, 1000
+N, d = 1024, 5
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 w = demc.workloads.mvnormal_problem(d, N)
 rng = np.random.default_rng(0)
 Z0 = np.asfortranarray(w["mu"] + 0.1 * rng.standard_normal((M0, d)))

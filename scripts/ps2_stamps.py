@@ -47,9 +47,14 @@ assert np.all(s[:, 15] == 2), "the last launch was not window_kernel_ps2's"
 n = s[:, 14]
 print(f"N={N} K={K} M0={M0}: last launch = {G - G // 2} generations in {ms * 1e3:.1f} us (stamped build), {n.mean():.0f} passes per chain wave")
 print(f"  whole launch: {s[:, 8].mean():.0f} shader clocks mean, {s[:, 8].max():.0f} max = {(s[:, 8] / n).mean():.0f} per pass")
-names = ["candidate adds + history store", "front end of the next pass (DMA wait, increments, DMA issue, node rows)", "log-density",
-         "table write, bpermute, accept tests, path", "winner, state + history values back from the table", "boundary: row to the publisher",
-         "waits for rows not yet published"]
+names = ["history store (+ ps2: DMA wait, raw values asked for), candidate adds", "log-density (+ ps2: the next pass's increments)",
+         "bpermute asked for, table write, next pass's rows asked for (+ ps2: DMA issue)", "accept tests, path (waits for the bpermute)",
+         "winner, state + history values back from the table", "boundary: row to the publisher",
+         "ps3: blocked on the helper wave / ps2: waits for rows not yet published"]
 for i, nm in enumerate(names):
     print(f"  {(s[:, i] / n).mean():8.0f} per pass  ({100 * s[:, i].sum() / s[:, 8].sum():5.1f} %)  {nm}")
-print(f"  passes that waited for a row: {100 * (s[:, 11] / n).mean():.2f} %")
+print(f"  passes that waited (ps2: for a row; ps3: for the helper wave): {100 * (s[:, 11] / n).mean():.2f} %")
+if s[:, 13].max() > 0:      # window_kernel_ps3: the helper wave's own stamps
+    print(f"  helper wave: {(s[:, 13] / n).mean():.0f} clocks per pass, of which waiting for its DMA {(s[:, 7] / n).mean():.0f}, "
+          f"re-reading unpublished rows {(s[:, 9] / n).mean():.0f} ({100 * (s[:, 12] / n).mean():.2f} % of passes), "
+          f"waiting for room in the ring {(s[:, 10] / n).mean():.0f}")
