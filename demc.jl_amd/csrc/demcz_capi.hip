@@ -208,6 +208,7 @@ struct demcz_handle {
     std::vector<RunCall> live_log;
     double* d_safe_X = nullptr;
     double* d_safe_lp = nullptr;
+    bool snap_pending = false;     // the state copy into d_safe_* is still to be made: by the next launch itself, or in front of it
     int64_t safe_M = 0, safe_M_app = 0, safe_g_done = 0;
     bool replaying = false;
     int32_t live_redos = 0;
@@ -896,6 +897,7 @@ extern "C" int32_t demcz_set_state(demcz_handle* h, const double* X, const doubl
     h->M = M0;
     h->M_app = M0;
     h->live_log.clear();
+    h->snap_pending = false;
     h->acc_log.clear();
     rec_invalidate(h);
     for (auto& pe : h->pending) if (pe.ev) (void)hipEventDestroy(pe.ev);
@@ -1436,6 +1438,19 @@ static bool try_launch_ml(const demcz_handle* h, const WindowParams& P)
 
 static int32_t launch_window(demcz_handle* h, const WindowParams& P, bool live = false)
 {
+    if (h->snap_pending) {
+        // the redo snapshot of the state (demcz_run): window_kernel_ps2 writes it as it loads the state -- two 5 us copy launches
+        // less in front of every autostop slab -- any other kernel gets the copies
+        h->snap_pending = false;
+        if (h->lanes == DEMCZ_LAYOUT_SPLIT && !h->lr_spec && ps2_applicable(h, P)) {
+            WindowParams Q = P;
+            Q.safe_X = h->d_safe_X;
+            Q.safe_lp = h->d_safe_lp;
+            return launch_window(h, Q, live);
+        }
+        HIPCHK(h, hipMemcpyAsync(h->d_safe_X, h->dX, (size_t)h->cfg.N * h->cfg.d * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_safe_lp, h->dlp, (size_t)h->cfg.N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
     const dim3 grid((unsigned)((P.N + WINDOW_BS - 1) / WINDOW_BS));
     const int d = P.d;
     if (h->lanes == DEMCZ_LAYOUT_SPLIT) {
@@ -1602,8 +1617,11 @@ static int32_t live_rollback(demcz_handle* h, std::vector<demcz_handle::RunCall>
     SYNCCHK(h, h->stream);
     if (h->diag_stream) SYNCCHK(h, h->diag_stream);
     if (h->prod_stream) SYNCCHK(h, h->prod_stream);
-    HIPCHK(h, hipMemcpyAsync(h->dX, h->d_safe_X, (size_t)N * d * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->dlp, h->d_safe_lp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (!h->snap_pending) {              // (still pending: nothing was launched since, the state is the snapshot)
+        HIPCHK(h, hipMemcpyAsync(h->dX, h->d_safe_X, (size_t)N * d * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->dlp, h->d_safe_lp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
+    h->snap_pending = false;
     if (h->M_app > h->safe_M_app) {
         const size_t rest = (size_t)(h->M_app - h->safe_M_app) * (size_t)h->ZS;
         hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, h->stream,
@@ -1915,6 +1933,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     P.snap = nullptr;
     P.K = K;
     P.acc_out = nullptr; P.live_err = h->d_live_err; P.live_spin_limit = LIVE_SPIN_LIMIT;
+    P.safe_X = nullptr; P.safe_lp = nullptr;
     P.rec_in = nullptr; P.rec_out = nullptr; P.next_g_first = 0; P.next_M = 0; P.next_ngen = 0; P.consumer_blocks = 0;
     P.next_rows = 0; P.next_boff = 0; P.rec_stride = 0;
     P.rec_fields = (h->lanes == DEMCZ_LAYOUT_SPLIT && h->split_kind == 2) ? h->cfg.d + 2 : 0;    // lane-per-parameter consumers: record-major
@@ -1953,8 +1972,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
                 const int d = h->cfg.d;
                 if (!h->d_safe_X) HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->d_safe_X, (size_t)N * d * sizeof(double)));
                 if (!h->d_safe_lp) HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->d_safe_lp, (size_t)N * sizeof(double)));
-                HIPCHK(h, hipMemcpyAsync(h->d_safe_X, h->dX, (size_t)N * d * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-                HIPCHK(h, hipMemcpyAsync(h->d_safe_lp, h->dlp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+                h->snap_pending = true;          // (made by the first launch: launch_window)
                 h->safe_M = h->M; h->safe_M_app = h->M_app; h->safe_g_done = h->g_done;
             }
             demcz_handle::RunCall rcall{g_from, g_to, gamma, temperature != nullptr, {}};

@@ -98,6 +98,10 @@ struct WindowParams {
     // one ballot + s_bcnt1 into a scalar register and writes {sum over the launch, count of its first generation}
     // once, at the end, to acc_out[2 * wave] -- no atomics, no second pass over log_obj (nullptr: not wanted).
     unsigned int* acc_out;
+    // The first LIVE launch after a verified point keeps the state it started from for a possible redo (live_verify): a kernel that
+    // can (window_kernel_ps2) writes it here as it loads it -- N x d (ld N) and N -- instead of two copy launches in front of it.
+    double* safe_X;
+    double* safe_lp;
 #ifdef DEMCZ_STAMPS
     unsigned long long* stamps;   // diagnostic build only (scripts/stamps.py): 16 values per workgroup (8 stamps, 8 sums)
 #endif

@@ -243,6 +243,13 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
 #pragma unroll
     for (int p = 0; p < D; ++p) x[p] = P.Xcur[c + P.N * p];
     xlp = P.lpcur[c];
+    if (P.safe_X) {                        // the state this launch starts from, kept for a redo (WindowParams::safe_X)
+        double xv = x[0];
+#pragma unroll
+        for (int p = 1; p < D; ++p) xv = (lane == p) ? x[p] : xv;
+        if (lane < D) P.safe_X[c + P.N * lane] = xv;
+        if (lane == 0) P.safe_lp[c] = xlp;
+    }
     if (lane < DP + 2) sd_w[R * DP + lane] = (lane < DP) ? -0.0 : 0.0;
 
     // the first two passes' row indices by ordinary loads; then everything that was loaded is in registers before the first DMA

@@ -377,6 +377,13 @@ __global__ void __launch_bounds__(64 * PS3_WAVES, 1) window_kernel_ps3(const Win
 #pragma unroll
     for (int p = 0; p < D; ++p) x[p] = P.Xcur[c + P.N * p];
     xlp = P.lpcur[c];
+    if (P.safe_X) {                        // the state this launch starts from, kept for a redo (WindowParams::safe_X)
+        double xv = x[0];
+#pragma unroll
+        for (int p = 1; p < D; ++p) xv = (lane == p) ? x[p] : xv;
+        if (lane < D) P.safe_X[c + P.N * lane] = xv;
+        if (lane == 0) P.safe_lp[c] = xlp;
+    }
 #pragma unroll
     for (int p = 0; p < D; ++p) asm volatile("" :: "v"(x[p]));
     asm volatile("" :: "v"(xlp));
