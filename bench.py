@@ -99,9 +99,21 @@ def cpu_baseline(w, N, d, K, seed, budget_updates, M_final):
         native = True
     except Exception:
         native = False
-    G = max(K, int(budget_updates // N) // K * K)
     Z0 = w["Zinit"]
     M0 = Z0.shape[0]
+    # the sample is sized by TIME: a 1000-generation calibration run, then as many generations as ~8 s of this host's
+    # single core make (at most budget_updates); the sequential row runs half as many, the OpenMP row twice as many
+    # -- about 20 s of CPU work in all, whatever the host
+    Gc = 1000 // K * K
+    probc = O.Problem(N, d, K, M0 + -(-N * Gc // K), w["eps_scale"], seed, target=w["target"].spec())
+    Xc = np.array(Z0[M0 - N:], order="F")
+    lpc = O.logp(probc, Xc)
+    Zc = np.zeros((M0 + -(-N * Gc // K), d), order="F")
+    Zc[:M0] = Z0
+    t0 = time.perf_counter()
+    O.run(probc, Xc, lpc, Zc, M0, 1, Gc, w["gamma"], history=True, native=native)
+    rate_c = N * Gc / (time.perf_counter() - t0)
+    G = max(K, int(min(budget_updates, 8.0 * rate_c) // N) // K * K)
     Mcap = M0 + -(-N * G // K)
     prob = O.Problem(N, d, K, Mcap, w["eps_scale"], seed, target=w["target"].spec())
     X = np.array(Z0[M0 - N:], order="F")
@@ -454,7 +466,7 @@ def main():
                 out["chain_count_sweep"] = f"failed: {e}"
         if not args.no_cpu_baseline and world == 1:      # (the contract: rank 0 at N = 1 only)
             try:
-                out["cpu_baseline"] = cpu_baseline(demc.workloads.mvnormal_problem(d, n_loc), n_loc, d, K, seed, 1.0e7, w["Zinit"].shape[0] + N * (G // K))
+                out["cpu_baseline"] = cpu_baseline(demc.workloads.mvnormal_problem(d, n_loc), n_loc, d, K, seed, 8.0e7, w["Zinit"].shape[0] + N * (G // K))
             except Exception as e:   # the baseline is reporting only; never fail the bench on it
                 out["cpu_baseline"] = {"value": None, "unit": "chain-updates/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {e}"}
