@@ -43,6 +43,7 @@ SYMBOLS = [
     "demcz_debug_append_slab", "demcz_get_changed_total", "demcz_debug_set_live_fault",
     "demcz_set_comm_timeout", "demcz_debug_stall_exchange", "demcz_get_kernel_time_series",
     "demcz_history_stream", "demcz_get_history_view", "demcz_detach_history", "demcz_release_host_buffer", "demcz_get_archive_pinned",
+    "demcz_debug_kernel_counts",
 ]
 
 
@@ -133,6 +134,7 @@ def load():
                                        C.POINTER(C.c_uint64), _dp, _dp]
     L.demcz_set_live_spin_limit.argtypes = [C.c_void_p, C.c_int32]
     L.demcz_get_live_status.argtypes = [C.c_void_p, _ip, _ip]
+    L.demcz_debug_kernel_counts.argtypes = [C.c_void_p, _lp]
     L.demcz_history_stream.argtypes = [C.c_void_p, C.c_int32]
     L.demcz_get_history_view.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.demcz_detach_history.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]

@@ -155,6 +155,7 @@ struct demcz_handle {
     int64_t rng_offset = 0;   // generations already consumed from every chain's stream (resume)
     bool has_state = false;
     int64_t launches = 0;
+    mutable int64_t kernel_counts[4] = {0, 0, 0, 0};      // demcz_debug_kernel_counts
     bool external_append = false;
     // host-closure mode
     double* dXprop = nullptr;
@@ -1088,9 +1089,11 @@ static void launch_ps(const demcz_handle* h, const WindowParams& P, int64_t bloc
     const dim3 grid((unsigned)blocks), wg(64 * PS_CHAINS), wgl(64 * (PS_CHAINS + 1));     // LIVE: chain waves + publisher wave
     if (ps3_applicable(h, P, blocks, live)) {  // opt-in (DEMCZ_PS3=1): the front end on a wave of its own (demcz_kernels_ps3.h)
         hipLaunchKernelGGL((window_kernel_ps3<TARGET, D, false>), grid, dim3(64 * PS3_WAVES), 0, h->stream, P);
+        ++h->kernel_counts[0];
         return;
     }
     if (ps2_applicable(h, P)) {               // the regular launch: the steady-state kernel
+        ++h->kernel_counts[1];
         if (live) hipLaunchKernelGGL((window_kernel_ps2<TARGET, D, true, false>), grid, wgl, 0, h->stream, P);
         else hipLaunchKernelGGL((window_kernel_ps2<TARGET, D, false, false>), grid, wg, 0, h->stream, P);
         return;
@@ -2982,6 +2985,17 @@ extern "C" int32_t demcz_debug_set_live_fault(demcz_handle* h, int32_t polls, in
     if (!h || polls < 0 || g_from < 0) return DEMCZ_ERR_INVALID_ARGUMENT;
     h->live_fault_polls = polls;
     h->live_fault_g = g_from;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_debug_kernel_counts(const demcz_handle* h, int64_t* counts)
+{
+    if (!h || !counts) return DEMCZ_ERR_INVALID_ARGUMENT;
+    const int64_t known = h->kernel_counts[0] + h->kernel_counts[1];
+    counts[0] = h->kernel_counts[0];
+    counts[1] = h->kernel_counts[1];
+    counts[2] = (h->lanes == DEMCZ_LAYOUT_SPLIT && h->split_kind == 4) ? h->launches - known : 0;
+    counts[3] = (h->lanes == DEMCZ_LAYOUT_SPLIT && h->split_kind == 4) ? 0 : h->launches;
     return DEMCZ_OK;
 }
 

@@ -200,6 +200,12 @@ class HipEngine:
         self._chk(self._L.demcz_get_live_status(self._h, C.byref(on), C.byref(redos)))
         return bool(on.value), int(redos.value)
 
+    def kernel_counts(self):
+        """Diagnostic: window launches so far by kernel -- {"ps3", "ps2", "ps_general", "other"} (demcz_debug_kernel_counts)."""
+        c = (C.c_int64 * 4)()
+        self._chk(self._L.demcz_debug_kernel_counts(self._h, c))
+        return dict(zip(("ps3", "ps2", "ps_general", "other"), (int(v) for v in c)))
+
     def synchronize(self):
         self._chk(self._L.demcz_synchronize(self._h))
 

@@ -252,3 +252,20 @@ def test_run_checked_of_more_than_256_slabs_redoes_from_its_entry(demc, oracle, 
         assert np.array_equal(a[3], ref["chain"]) and np.array_equal(a[7], ref["Z"])
     else:
         assert a[0] < every * 280 or a[0] == G      # (wherever it stopped, both runs agree; see above)
+
+
+@pytest.mark.parametrize("d", [5, 3])
+def test_helper_wave_kernel_equals_oracle(d):
+    """window_kernel_ps3 (opt-in, DEMCZ_PS3=1: the pass's front end on a helper wave per chain, demcz_kernels_ps3.h) on two LIVE
+    launches of a 1024-chain run against the oracle, bit for bit.  The switch is read when the library is loaded: a process of
+    its own (tests/ps3_case.py)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    r = subprocess.run([sys.executable, str(Path(__file__).resolve().parent / "ps3_case.py"), str(d)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["counts"]["ps3"] == 2 and out["counts"]["ps2"] == 0, out        # both launches took the helper-wave kernel
+    assert out["live"] == [True, 0], out
+    assert out["same"], "window_kernel_ps3 differs from the oracle"
