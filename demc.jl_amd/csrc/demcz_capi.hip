@@ -1138,7 +1138,9 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
 {
     const int64_t nbc = (P.N + 63) / 64;
     const bool lr_split = h->split_kind == 2 && h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE;
-    const int64_t units = nbc * rec_roles(h) * P.next_ngen;               // 64-lane producer units
+    // 64-lane producer units (the wave-per-chain and replicated consumers' producer, pc_produce, has two lane mappings)
+    const bool pc_records = !(h->split_kind == 3);
+    const int64_t units = pc_records ? produce_units(P.N, (int)rec_roles(h), P.rec_fields, P.next_ngen) : nbc * rec_roles(h) * P.next_ngen;
     // producer units per workgroup = waves per workgroup of the instantiation that is launched
     const int upw = lr_split ? LR16_WAVES : (h->split_kind == 4) ? PS_CHAINS + (live ? 1 : 0) : (h->split_kind == 3 || h->split_kind == 2) ? h->wpw : (h->split_kind == 1 && live) ? PC8_LIVE_WAVES : 1;
     const int64_t blocks = P.consumer_blocks + (units + upw - 1) / upw;

@@ -42,6 +42,19 @@ __device__ __forceinline__ size_t rec_index(int64_t N, int64_t GS, int g, int f,
 // record-major layout (WindowParams::rec_fields = F > 0): rec[(g * N + c) * F + f]
 __device__ __forceinline__ size_t rec_index_rm(int64_t N, int F, int g, int f, int64_t c) { return ((size_t)g * (size_t)N + (size_t)c) * (size_t)F + (size_t)f; }
 
+// What the 64 lanes of a producer unit are.  Chains: unit = (generation, role, block of 64 chains) -- every lane's store goes to
+// a (field, chain) row of its own, rec_stride * 8 bytes from its neighbour's: 64 cache lines per store instruction, each line
+// completed by 16 different units at 16 different times (the producer's WRITE_SIZE was twice its bytes and the stores, not the
+// arithmetic, were most of its 95 us at C2).  Generations: unit = (chain, role, block of 64 generations) -- a lane per
+// generation, one 512-byte run per store.  The records are the same doubles at the same addresses either way (counter-based
+// draws: block = generation * S + role of chain c's stream), so consumers do not care; launches shorter than 64 generations
+// (one K-window of a sharded run) keep the chain mapping, which fills its lanes.
+__host__ __device__ inline bool produce_by_generation(int32_t rec_fields, int32_t ngen) { return rec_fields == 0 && ngen >= 64; }
+__host__ __device__ inline int64_t produce_units(int64_t N, int roles, int32_t rec_fields, int32_t ngen)
+{
+    return produce_by_generation(rec_fields, ngen) ? N * roles * (int64_t)((ngen + 63) / 64) : ((N + 63) / 64) * roles * (int64_t)ngen;
+}
+
 // (`lane`: position in the 64-wide producer unit -- a workgroup of one wave, or one wave of a larger workgroup)
 template <int D>
 __device__ __forceinline__ void pc_produce(const WindowParams& P, int64_t pb, int lane = -1)
@@ -49,10 +62,22 @@ __device__ __forceinline__ void pc_produce(const WindowParams& P, int64_t pb, in
     if (lane < 0) lane = (int)threadIdx.x;
     constexpr int NPAIRS = (D == 1) ? 1 : (D + 1) / 2;
     constexpr int S = NPAIRS + 2;                          // Philox blocks of a generation = producer roles
-    const int64_t nbc = (P.N + 63) / 64;                   // workgroups per (generation, role) plane
-    const int64_t plane = pb / nbc;                        // wave-uniform
-    const int64_t c = (pb % nbc) * 64 + lane;
-    const int role = (int)(plane % S), gi = (int)(plane / S);
+    int64_t c;
+    int role, gi;
+    if (produce_by_generation(P.rec_fields, P.next_ngen)) {
+        const int64_t gblocks = (P.next_ngen + 63) / 64;
+        const int64_t per_chain = (int64_t)S * gblocks;
+        c = pb / per_chain;                                // wave-uniform, like role
+        const int64_t rem = pb % per_chain;
+        role = (int)(rem / gblocks);
+        gi = (int)(rem % gblocks) * 64 + lane;
+    } else {
+        const int64_t nbc = (P.N + 63) / 64;               // units per (generation, role) plane
+        const int64_t plane = pb / nbc;                    // wave-uniform
+        c = (pb % nbc) * 64 + lane;
+        role = (int)(plane % S);
+        gi = (int)(plane / S);
+    }
     if (gi >= P.next_ngen || c >= P.N) return;
     philox_blocks rng;
     uint64_t r1, r2;
