@@ -576,7 +576,21 @@ __global__ void rhat_moments_kernel(const double* chain, int64_t N, int d, int64
     const double* base = chain + i + stride * (s0 + h * n);
     const double x0 = base[0];
     double a = 0.0, b = 0.0;
-    for (int64_t t = t0; t < t1; ++t) {
+    // (eight loads in flight per thread, added in generation order: a thread's samples are N*d doubles apart, every one a
+    //  trip to HBM -- one at a time the loop is that latency times its length)
+    int64_t t = t0;
+    for (; t + 8 <= t1; t += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = base[stride * (t + u)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double w = v[u] - x0;
+            a += w;
+            b = fma(w, w, b);
+        }
+    }
+    for (; t < t1; ++t) {
         double v = base[stride * t] - x0;
         a += v;
         b = fma(v, v, b);
@@ -615,16 +629,21 @@ __global__ void __launch_bounds__(256) rhat_reduce_kernel(const double* mean_j, 
     const int64_t stride = N * d;
     double a = 0.0, b = 0.0;
     const double gm = stage ? grand[p] / grand_div : 0.0;
+    // k = threadIdx.x, + 256, ...: (h, c) = (k / N, k % N) kept by carrying (a 64-bit division per element was most of the kernel)
+    int64_t h = 0, c = threadIdx.x;
+    while (c >= N) { c -= N; ++h; }
     for (int64_t k = threadIdx.x; k < 2 * N; k += 256) {
-        const int64_t h = k / N, c = k % N;
-        const double mj = mean_j[c + N * p + stride * h];
+        const int64_t at = c + N * p + stride * h;
+        const double mj = mean_j[at];
         if (stage == 0) {
             a += mj;
         } else {
             const double dv = mj - gm;
             a = fma(dv, dv, a);
-            b += s2_j[c + N * p + stride * h];
+            b += s2_j[at];
         }
+        c += 256;
+        while (c >= N) { c -= N; ++h; }
     }
     ra[threadIdx.x] = a;
     rb[threadIdx.x] = b;
@@ -651,9 +670,15 @@ __global__ void __launch_bounds__(256) rhat_tail_kernel(const double* mean_j, co
     const int p = blockIdx.x;
     const int64_t stride = N * d;
     double a = 0.0, b = 0.0;
-    for (int64_t k = threadIdx.x; k < 2 * N; k += 256) {
-        const int64_t h = k / N, c = k % N;
-        a += mean_j[c + N * p + stride * h];
+    int64_t h0 = 0, c0 = threadIdx.x;              // (h, c) = (k / N, k % N) of the thread's first element
+    while (c0 >= N) { c0 -= N; ++h0; }
+    {
+        int64_t h = h0, c = c0;
+        for (int64_t k = threadIdx.x; k < 2 * N; k += 256) {
+            a += mean_j[c + N * p + stride * h];
+            c += 256;
+            while (c >= N) { c -= N; ++h; }
+        }
     }
     ra[threadIdx.x] = a;
     __syncthreads();
@@ -664,11 +689,16 @@ __global__ void __launch_bounds__(256) rhat_tail_kernel(const double* mean_j, co
     const double gm = ra[0] / m;
     __syncthreads();
     a = 0.0;
-    for (int64_t k = threadIdx.x; k < 2 * N; k += 256) {
-        const int64_t h = k / N, c = k % N;
-        const double dv = mean_j[c + N * p + stride * h] - gm;
-        a = fma(dv, dv, a);
-        b += s2_j[c + N * p + stride * h];
+    {
+        int64_t h = h0, c = c0;
+        for (int64_t k = threadIdx.x; k < 2 * N; k += 256) {
+            const int64_t at = c + N * p + stride * h;
+            const double dv = mean_j[at] - gm;
+            a = fma(dv, dv, a);
+            b += s2_j[at];
+            c += 256;
+            while (c >= N) { c -= N; ++h; }
+        }
     }
     ra[threadIdx.x] = a;
     rb[threadIdx.x] = b;

@@ -64,6 +64,7 @@ __device__ __forceinline__ void ps_dma16(const void* gsrc, unsigned lds_dst)
 // (LIVE) only one producer workgroup fits a CU beside a consumer workgroup -- the launch then waits for its producers.
 constexpr int PRODUCE_WAVES = 4;
 constexpr size_t PRODUCE_THROTTLE_LDS = 64 * 1024;     // of a CU's 160 KB, ~27 KB of them a consumer workgroup's: two producer workgroups fit
+                                                       // (32 / 48 KB measure the same since the producer's stores are coalesced: profiles/r03e_producer.txt)
 template <int D>
 __global__ void __launch_bounds__(64 * PRODUCE_WAVES) produce_kernel(const WindowParams P)
 {
