@@ -101,9 +101,9 @@ def cpu_baseline(w, N, d, K, seed, budget_updates, M_final):
         native = False
     Z0 = w["Zinit"]
     M0 = Z0.shape[0]
-    # the sample is sized by TIME: a 1000-generation calibration run, then as many generations as ~8 s of this host's
+    # the sample is sized by TIME: a 1000-generation calibration run, then as many generations as ~5 s of this host's
     # single core make (at most budget_updates); the sequential row runs half as many, the OpenMP row twice as many
-    # -- about 20 s of CPU work in all, whatever the host
+    # -- about 12-20 s of CPU work in all, whatever the host
     Gc = 1000 // K * K
     probc = O.Problem(N, d, K, M0 + -(-N * Gc // K), w["eps_scale"], seed, target=w["target"].spec())
     Xc = np.array(Z0[M0 - N:], order="F")
@@ -113,7 +113,7 @@ def cpu_baseline(w, N, d, K, seed, budget_updates, M_final):
     t0 = time.perf_counter()
     O.run(probc, Xc, lpc, Zc, M0, 1, Gc, w["gamma"], history=True, native=native)
     rate_c = N * Gc / (time.perf_counter() - t0)
-    G = max(K, int(min(budget_updates, 8.0 * rate_c) // N) // K * K)
+    G = max(K, int(min(budget_updates, 5.0 * rate_c) // N) // K * K)
     Mcap = M0 + -(-N * G // K)
     prob = O.Problem(N, d, K, Mcap, w["eps_scale"], seed, target=w["target"].spec())
     X = np.array(Z0[M0 - N:], order="F")
