@@ -9,7 +9,6 @@
 #include "demcz_kernels_lr.h"
 #include "demcz_kernels_ps.h"
 #include "demcz_kernels_ps2.h"
-#include "demcz_kernels_ps3.h"
 #include "demcz_kernels_pw.h"
 
 #include <rccl/rccl.h>
@@ -155,7 +154,7 @@ struct demcz_handle {
     int64_t rng_offset = 0;   // generations already consumed from every chain's stream (resume)
     bool has_state = false;
     int64_t launches = 0;
-    mutable int64_t kernel_counts[4] = {0, 0, 0, 0};      // demcz_debug_kernel_counts
+    mutable int64_t kernel_counts[1] = {0};               // demcz_debug_kernel_counts: launches taken by window_kernel_ps2
     bool external_append = false;
     // host-closure mode
     double* dXprop = nullptr;
@@ -466,7 +465,6 @@ static int64_t live_span(demcz_handle* h);
 static int32_t rec_reserve(demcz_handle* h, int64_t gens);
 static int32_t check_hist_range(demcz_handle* h, int64_t g_from, int64_t g_to, const char* who);
 static bool ps2_applicable(const demcz_handle* h, const WindowParams& P);
-static bool ps3_applicable(const demcz_handle* h, const WindowParams& P, int64_t blocks, bool live);
 
 extern "C" int32_t demcz_abi_version(void) { return DEMCZ_ABI_VERSION; }
 
@@ -1087,13 +1085,8 @@ template <int TARGET, int D>
 static void launch_ps(const demcz_handle* h, const WindowParams& P, int64_t blocks, bool live)
 {
     const dim3 grid((unsigned)blocks), wg(64 * PS_CHAINS), wgl(64 * (PS_CHAINS + 1));     // LIVE: chain waves + publisher wave
-    if (ps3_applicable(h, P, blocks, live)) {  // opt-in (DEMCZ_PS3=1): the front end on a wave of its own (demcz_kernels_ps3.h)
-        hipLaunchKernelGGL((window_kernel_ps3<TARGET, D, false>), grid, dim3(64 * PS3_WAVES), 0, h->stream, P);
-        ++h->kernel_counts[0];
-        return;
-    }
     if (ps2_applicable(h, P)) {               // the regular launch: the steady-state kernel
-        ++h->kernel_counts[1];
+        ++h->kernel_counts[0];
         if (live) hipLaunchKernelGGL((window_kernel_ps2<TARGET, D, true, false>), grid, wgl, 0, h->stream, P);
         else hipLaunchKernelGGL((window_kernel_ps2<TARGET, D, false, false>), grid, wg, 0, h->stream, P);
         return;
@@ -1325,37 +1318,6 @@ static bool ps2_applicable(const demcz_handle* h, const WindowParams& P)
     if (P.K % PS2_R != 0 || P.to_boundary % PS2_R != 0 || P.ngen % PS2_R != 0 || P.ngen < PS2_R) return false;
     if (P.chain && (!h->hist_joint || (double)h->cfg.N * (h->cfg.d + 1) * (double)h->cfg.Gcap * 8.0 >= 4293918720.0)) return false;
     return true;
-}
-
-// ... and window_kernel_ps3 (demcz_kernels_ps3.h), which is OPT-IN (DEMCZ_PS3=1): LIVE launches whose nine-wave workgroups are
-// resident together.  They are the launch's only waves that wait for other workgroups; whatever else is on a CU finishes
-// without them, so the bound is the occupancy query x CUs with no halving (as for window_kernel_lr8s, live_wg_capacity).
-// Not the default: one workgroup fills a CU, so a CU that another kernel (the R-hat monitor's) got to first holds its
-// workgroup -- and through the hand-off every chain -- back: 182 us per slab in the bench against window_kernel_ps2's 164,
-// although the launch alone is 5-9 % faster (profiles/r03d_helper_wave.txt).
-template <int D>
-static int64_t ps3_capacity(int device_id)
-{
-    int a = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&window_kernel_ps3<TARGET_MVNORMAL, D, false>), 64 * PS3_WAVES, 0) != hipSuccess) a = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess) cus = 0;
-    return (int64_t)a * cus;
-}
-static bool ps3_applicable(const demcz_handle* h, const WindowParams& P, int64_t blocks, bool live)
-{
-    static const bool on = getenv("DEMCZ_PS3") != nullptr;
-    if (!on || !live || !ps2_applicable(h, P)) return false;
-    static int64_t cap[6] = {-1, -1, -1, -1, -1, -1};          // (per d; one device model per process)
-    int64_t& cp = cap[P.d];
-    if (cp < 0) {
-        switch (P.d) {
-        case 2: cp = ps3_capacity<2>(h->cfg.device_id); break;
-        case 3: cp = ps3_capacity<3>(h->cfg.device_id); break;
-        case 4: cp = ps3_capacity<4>(h->cfg.device_id); break;
-        default: cp = ps3_capacity<5>(h->cfg.device_id); break;
-        }
-    }
-    return blocks <= cp;
 }
 
 static int32_t pc_prepare(demcz_handle* h, WindowParams& P, int64_t cur_rows, int64_t next_g, int64_t next_ngen, int64_t next_M,
@@ -2993,11 +2955,10 @@ extern "C" int32_t demcz_debug_set_live_fault(demcz_handle* h, int32_t polls, in
 extern "C" int32_t demcz_debug_kernel_counts(const demcz_handle* h, int64_t* counts)
 {
     if (!h || !counts) return DEMCZ_ERR_INVALID_ARGUMENT;
-    const int64_t known = h->kernel_counts[0] + h->kernel_counts[1];
+    const bool wave = h->lanes == DEMCZ_LAYOUT_SPLIT && h->split_kind == 4;
     counts[0] = h->kernel_counts[0];
-    counts[1] = h->kernel_counts[1];
-    counts[2] = (h->lanes == DEMCZ_LAYOUT_SPLIT && h->split_kind == 4) ? h->launches - known : 0;
-    counts[3] = (h->lanes == DEMCZ_LAYOUT_SPLIT && h->split_kind == 4) ? 0 : h->launches;
+    counts[1] = wave ? h->launches - h->kernel_counts[0] : 0;
+    counts[2] = wave ? 0 : h->launches;
     return DEMCZ_OK;
 }
 

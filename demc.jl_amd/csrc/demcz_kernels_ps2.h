@@ -388,6 +388,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     // LDS / scalar-memory operations, so the segments add up to MORE than an unstamped pass: read them as proportions.
     unsigned long long sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sa_nbad = 0;
     const unsigned long long sa_start = __builtin_readcyclecounter();
+    const unsigned long long sa_rt0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz, the same clock on every CU: start skew
 #define PS2_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); sa[i] += t_ - sa_t; sa_t = t_; } while (0)
 #else
 #define PS2_T(i) do { } while (0)
@@ -592,6 +593,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         unsigned long long* o = P.stamps + (size_t)c * 16;
         for (int i = 0; i < 7; ++i) o[i] = sa[i];
         o[8] = __builtin_readcyclecounter() - sa_start; o[11] = sa_nbad; o[14] = (unsigned long long)npass; o[15] = 2;
+        o[9] = sa_rt0; o[10] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
 #undef PS2_T

@@ -201,10 +201,10 @@ class HipEngine:
         return bool(on.value), int(redos.value)
 
     def kernel_counts(self):
-        """Diagnostic: window launches so far by kernel -- {"ps3", "ps2", "ps_general", "other"} (demcz_debug_kernel_counts)."""
-        c = (C.c_int64 * 4)()
+        """Diagnostic: window launches so far by kernel -- {"ps2", "ps_general", "other"} (demcz_debug_kernel_counts)."""
+        c = (C.c_int64 * 3)()
         self._chk(self._L.demcz_debug_kernel_counts(self._h, c))
-        return dict(zip(("ps3", "ps2", "ps_general", "other"), (int(v) for v in c)))
+        return dict(zip(("ps2", "ps_general", "other"), (int(v) for v in c)))
 
     def synchronize(self):
         self._chk(self._L.demcz_synchronize(self._h))

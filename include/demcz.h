@@ -306,9 +306,9 @@ int32_t demcz_selftest_draws(int32_t device_id, uint64_t seed, uint64_t chain, u
  * fall back.  Tests lower the limit to 1 to walk the fall-back path. */
 int32_t demcz_set_live_spin_limit(demcz_handle* h, int32_t polls);
 int32_t demcz_get_live_status(const demcz_handle* h, int32_t* live_enabled, int32_t* redos);
-/* Diagnostic: window launches of the wave-per-chain layout by the kernel that took them (four values): counts[0] window_kernel_ps3
- * (DEMCZ_PS3=1), [1] window_kernel_ps2 (regular launches), [2] the general kernels (window_kernel_ps / _pw), [3] launches of
- * every other layout.  Tests use it to know which kernel a parity case exercised. */
+/* Diagnostic: window launches so far by the kernel that took them (three values): counts[0] window_kernel_ps2 (the regular
+ * launches of the wave-per-chain layout), [1] that layout's general kernels (window_kernel_ps / _pw), [2] launches of every
+ * other layout.  Tests use it to know which kernel a parity case exercised. */
 int32_t demcz_debug_kernel_counts(const demcz_handle* h, int64_t* counts);
 
 /* Fault injection for the LIVE hand-off: LIVE launches whose first generation is >= g_from use the poll limit `polls` instead

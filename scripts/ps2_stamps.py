@@ -54,6 +54,18 @@ names = ["history store (+ ps2: DMA wait, raw values asked for), candidate adds"
 for i, nm in enumerate(names):
     print(f"  {(s[:, i] / n).mean():8.0f} per pass  ({100 * s[:, i].sum() / s[:, 8].sum():5.1f} %)  {nm}")
 print(f"  passes that waited (ps2: for a row; ps3: for the helper wave): {100 * (s[:, 11] / n).mean():.2f} %")
+if buf[:, 9].max() > 0 and s[:, 13].max() == 0:      # window_kernel_ps2: when each chain wave began and ended (100 MHz clock common to all CUs)
+    t0, t1 = buf[:, 9].astype(np.int64), buf[:, 10].astype(np.int64)
+    b = (t0 - t0.min()) / 100.0
+    e = (t1 - t0.min()) / 100.0
+    print(f"  chain waves begin over {b.max():.1f} us (median {np.median(b):.1f}, 90 % by {np.quantile(b, 0.9):.1f}); end between {e.min():.1f} and {e.max():.1f} us")
+    cidx = np.arange(N)
+    print("  mean end by wave of the workgroup (chain mod 4): " + " ".join(f"{e[cidx % 4 == w].mean():.1f}" for w in range(4)))
+    print("  mean end by XCD (chain // (N/8)):               " + " ".join(f"{e[cidx // (N // 8) == x].mean():.1f}" for x in range(8)))
+    wsum = s[:, 6] / 2100.0      # clocks -> us at ~2.1 GHz
+    print(f"  own waits per chain: mean {wsum.mean():.1f} us, min {wsum.min():.1f}, max {wsum.max():.1f}; corr(end, waits) = {np.corrcoef(e, wsum)[0, 1]:.2f}")
+    work = (s[:, 8] - s[:, 6]) / 2100.0
+    print(f"  launch minus own waits per chain: mean {work.mean():.1f} us, min {work.min():.1f}, max {work.max():.1f}; by wave: " + " ".join(f"{work[cidx % 4 == w].mean():.1f}" for w in range(4)))
 if s[:, 13].max() > 0:      # window_kernel_ps3: the helper wave's own stamps
     print(f"  helper wave: {(s[:, 13] / n).mean():.0f} clocks per pass, of which waiting for its DMA {(s[:, 7] / n).mean():.0f}, "
           f"re-reading unpublished rows {(s[:, 9] / n).mean():.0f} ({100 * (s[:, 12] / n).mean():.2f} % of passes), "

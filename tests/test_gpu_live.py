@@ -254,18 +254,20 @@ def test_run_checked_of_more_than_256_slabs_redoes_from_its_entry(demc, oracle, 
         assert a[0] < every * 280 or a[0] == G      # (wherever it stopped, both runs agree; see above)
 
 
-@pytest.mark.parametrize("d", [5, 3])
-def test_helper_wave_kernel_equals_oracle(d):
-    """window_kernel_ps3 (opt-in, DEMCZ_PS3=1: the pass's front end on a helper wave per chain, demcz_kernels_ps3.h) on two LIVE
-    launches of a 1024-chain run against the oracle, bit for bit.  The switch is read when the library is loaded: a process of
-    its own (tests/ps3_case.py)."""
-    import json
-    import subprocess
-    import sys
-    from pathlib import Path
-    r = subprocess.run([sys.executable, str(Path(__file__).resolve().parent / "ps3_case.py"), str(d)], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert out["counts"]["ps3"] == 2 and out["counts"]["ps2"] == 0, out        # both launches took the helper-wave kernel
-    assert out["live"] == [True, 0], out
-    assert out["same"], "window_kernel_ps3 differs from the oracle"
+def test_regular_launches_take_the_steady_state_kernel(demc):
+    """ps2_applicable (demcz_capi.hip): launches that start behind a K boundary with K and their length multiples of five run
+    on window_kernel_ps2, any other launch on the general wave-per-chain kernel -- told apart by demcz_debug_kernel_counts."""
+    N, d, K = 1024, 5, 10
+    w = demc.workloads.mvnormal_problem(d, N)
+    M0 = w["Zinit"].shape[0]
+    e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * 40, Gcap=300, blockindex=[range(d)], eps_scale=w["eps_scale"], seed=5, target=w["target"])
+    e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+    e.run(1, 100, w["gamma"])
+    e.run(101, 200, w["gamma"])
+    c = e.kernel_counts()
+    assert c["ps2"] == 2 and c["ps_general"] == 0 and c["other"] == 0, c
+    e.run(201, 203, w["gamma"])          # three generations: not a multiple of five
+    e.run(204, 300, w["gamma"])          # starts in the middle of a K-window
+    c2 = e.kernel_counts()
+    e.close()
+    assert c2["ps2"] == 2 and c2["ps_general"] >= 2, c2
