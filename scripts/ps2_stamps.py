@@ -47,14 +47,14 @@ assert np.all(s[:, 15] == 2), "the last launch was not window_kernel_ps2's"
 n = s[:, 14]
 print(f"N={N} K={K} M0={M0}: last launch = {G - G // 2} generations in {ms * 1e3:.1f} us (stamped build), {n.mean():.0f} passes per chain wave")
 print(f"  whole launch: {s[:, 8].mean():.0f} shader clocks mean, {s[:, 8].max():.0f} max = {(s[:, 8] / n).mean():.0f} per pass")
-names = ["history store (+ ps2: DMA wait, raw values asked for), candidate adds", "log-density (+ ps2: the next pass's increments)",
-         "bpermute asked for, table write, next pass's rows asked for (+ ps2: DMA issue)", "accept tests, path (waits for the bpermute)",
+names = ["history store, DMA wait, raw values asked for, candidate adds", "log-density, the next pass's increments",
+         "bpermute asked for, table write, DMA issue, next pass's rows asked for", "accept tests, path (waits for the bpermute)",
          "winner, state + history values back from the table", "boundary: row to the publisher",
-         "ps3: blocked on the helper wave / ps2: waits for rows not yet published"]
+         "waits for rows not yet published"]
 for i, nm in enumerate(names):
     print(f"  {(s[:, i] / n).mean():8.0f} per pass  ({100 * s[:, i].sum() / s[:, 8].sum():5.1f} %)  {nm}")
-print(f"  passes that waited (ps2: for a row; ps3: for the helper wave): {100 * (s[:, 11] / n).mean():.2f} %")
-if buf[:, 9].max() > 0 and s[:, 13].max() == 0:      # window_kernel_ps2: when each chain wave began and ended (100 MHz clock common to all CUs)
+print(f"  passes that waited for a row: {100 * (s[:, 11] / n).mean():.2f} %")
+if buf[:, 9].max() > 0:      # window_kernel_ps2: when each chain wave began and ended (100 MHz clock common to all CUs)
     t0, t1 = buf[:, 9].astype(np.int64), buf[:, 10].astype(np.int64)
     b = (t0 - t0.min()) / 100.0
     e = (t1 - t0.min()) / 100.0
@@ -66,7 +66,3 @@ if buf[:, 9].max() > 0 and s[:, 13].max() == 0:      # window_kernel_ps2: when e
     print(f"  own waits per chain: mean {wsum.mean():.1f} us, min {wsum.min():.1f}, max {wsum.max():.1f}; corr(end, waits) = {np.corrcoef(e, wsum)[0, 1]:.2f}")
     work = (s[:, 8] - s[:, 6]) / 2100.0
     print(f"  launch minus own waits per chain: mean {work.mean():.1f} us, min {work.min():.1f}, max {work.max():.1f}; by wave: " + " ".join(f"{work[cidx % 4 == w].mean():.1f}" for w in range(4)))
-if s[:, 13].max() > 0:      # window_kernel_ps3: the helper wave's own stamps
-    print(f"  helper wave: {(s[:, 13] / n).mean():.0f} clocks per pass, of which waiting for its DMA {(s[:, 7] / n).mean():.0f}, "
-          f"re-reading unpublished rows {(s[:, 9] / n).mean():.0f} ({100 * (s[:, 12] / n).mean():.2f} % of passes), "
-          f"waiting for room in the ring {(s[:, 10] / n).mean():.0f}")
