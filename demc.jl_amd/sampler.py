@@ -422,7 +422,25 @@ def _run_generations(runner, logobj, g_from, g_to, gamma, Nblocks, temperature=N
         eng.end_generation(g)
 
 
+def _warn_live_redos(runner):
+    """A LIVE launch whose row hand-off timed out is redone with one launch per K-window (same results, several times slower,
+    and the handle stays in that mode): worth a line in the caller's log -- typically another process shares the GPU."""
+    for e in getattr(runner, "engines", []):
+        st = getattr(e, "live_status", None)
+        if st is None:
+            continue
+        try:
+            _, redos = st()
+        except Exception:
+            continue
+        if redos:
+            warnings.warn(f"DEMCz: {redos} in-launch row hand-off(s) timed out and were redone with one launch per K-window "
+                          "(results unchanged; is another process using this GPU?)", RuntimeWarning, stacklevel=3)
+            return
+
+
 def _finish(runner, prevrun, G, padded_Z, Mcap, rng_offset=0):
+    _warn_live_redos(runner)
     X, lp, Z, M = runner.state()               # (first: it only needs the compute stream; the history copies are still leaving)
     chain, lobj = runner.history(1, G, take=True)
     if padded_Z:

@@ -202,6 +202,13 @@ set_append_lag(h, E) = chk(ccall((:demcz_set_append_lag, libdemcz), Int32, (Ptr{
 # deadline of every wait behind a collective; past it the communicators are aborted and calls throw DemczError(6 = DEMCZ_ERR_COMM)
 set_comm_timeout(h, ms) = chk(ccall((:demcz_set_comm_timeout, libdemcz), Int32, (Ptr{Cvoid}, Int64), h, ms), h)
 synchronize(h) = chk(ccall((:demcz_synchronize, libdemcz), Int32, (Ptr{Cvoid},), h), h)
+# (LIVE launches in use, times an in-launch row hand-off timed out and was redone with one launch per K-window)
+function live_status(h)
+    on = Ref{Int32}(0); redos = Ref{Int32}(0)
+    chk(ccall((:demcz_get_live_status, libdemcz), Int32, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}), h, on, redos), h)
+    on[] != 0, Int(redos[])
+end
+warn_live_redos(h) = (r = live_status(h)[2]; r > 0 && @warn "DEMCz: $r in-launch row hand-off(s) timed out and were redone with one launch per K-window (results unchanged; is another process using this GPU?)"; nothing)
 
 """
     demcz_sample_par(t, Zmat, opts; sync_every=1000, prevrun=nothing, rank, nranks, unique_id, device_id=rank, append_lag=0, seed=0)
@@ -343,6 +350,7 @@ function demcz_sample(t::LogObj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, b
         if autostop == :Rhat && ig % autostop_every == 0 && maximum(rhat(h, ig - autostop_every + 1, ig, d)) < autostop_Rhat
             sum(accept_ratio(h, ig - autostop_every + 1, ig, N)) / N < 0.1 && println("Warning: accept ratio below 10% on average")   # demcz.jl:42-46
         end
+        warn_live_redos(h)
         Xc, lpc, Z = state(h, N, d)                                                    # Z[1:M,:], demcz.jl:51
         chain, log_obj = streamed ? take_history(h, N, d, 1, ig) : history(h, N, d, 1, ig)   # demcz.jl:47 (no copy when streamed)
         mc = prevrun === nothing ? MC(chain, log_obj, Xc, lpc) :
