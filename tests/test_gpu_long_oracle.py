@@ -101,3 +101,30 @@ def test_c3_block_updates_long_run_equals_oracle(demc, oracle):
     assert a["lanes"] == SPLIT
     ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, BLOCKS_D20, w["eps_scale"], w["gamma"], seed, threads=THREADS)
     _same(a, ref)
+
+
+def test_c2_eighty_autostop_slabs_equal_oracle(demc, oracle):
+    """The bench's workload for 80 slabs -- 8.2e7 chain-updates through demcz_run_checked (window_kernel_ps2 LIVE launches of
+    1000 generations, the producer's lane-per-generation records, the R-hat monitor beside them), the archive growing to
+    8.2 M rows -- against the oracle: history, state, archive and the R-hat of every slab.  demcz.jl:30-55."""
+    N, d, K, every, S, seed = 1024, 5, 10, 1000, 80, 31953150
+    G = S * every
+    w = demc.workloads.mvnormal_problem(d, N)
+    M0 = w["Zinit"].shape[0]
+    e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K + 1), Gcap=G, blockindex=[range(d)], eps_scale=w["eps_scale"], seed=seed,
+                       target=w["target"])
+    e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+    g_stop, rmax, _ = e.run_checked(1, G, w["gamma"], every, 0.0)
+    assert g_stop == G and len(rmax) == S
+    counts, live = e.kernel_counts(), e.live_status()
+    ch, lo = e.get_history(1, G)
+    X, lp, Z, M = e.get_state()
+    e.close()
+    assert counts["ps2"] == S and counts["ps_general"] == 0 and live == (True, 0), (counts, live)
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed, threads=THREADS)
+    assert np.array_equal(lo, ref["log_obj"]), "log_obj history differs from the oracle"
+    assert np.array_equal(ch, ref["chain"]), "chain history differs from the oracle"
+    assert np.array_equal(X, ref["X"]) and np.array_equal(lp, ref["logp"]) and M == ref["M"] and np.array_equal(Z, ref["Z"])
+    for s in (0, S // 2, S - 1):                           # the monitor's statistic of three slabs against the oracle's
+        r = oracle.rhat_gelman(ref["chain"][:, :, s * every:(s + 1) * every])
+        assert abs(rmax[s] - np.max(r)) < 1e-9, (s, rmax[s], np.max(r))
