@@ -1087,6 +1087,11 @@ static void launch_ps(const demcz_handle* h, const WindowParams& P, int64_t bloc
     const dim3 grid((unsigned)blocks), wg(64 * PS_CHAINS), wgl(64 * (PS_CHAINS + 1));     // LIVE: chain waves + publisher wave
     if (ps2_applicable(h, P)) {               // the regular launch: the steady-state kernel
         ++h->kernel_counts[0];
+        if (P.temperature) {
+            if (live) hipLaunchKernelGGL((window_kernel_ps2<TARGET, D, true, true>), grid, wgl, 0, h->stream, P);
+            else hipLaunchKernelGGL((window_kernel_ps2<TARGET, D, false, true>), grid, wg, 0, h->stream, P);
+            return;
+        }
         if (live) hipLaunchKernelGGL((window_kernel_ps2<TARGET, D, true, false>), grid, wgl, 0, h->stream, P);
         else hipLaunchKernelGGL((window_kernel_ps2<TARGET, D, false, false>), grid, wg, 0, h->stream, P);
         return;
@@ -1314,7 +1319,7 @@ static bool ps2_applicable(const demcz_handle* h, const WindowParams& P)
 {
     static const bool off = getenv("DEMCZ_NO_PS2") != nullptr;
     if (off || h->split_kind != 4 || P.d < 2 || P.d > 5 || !h->arena || !h->rec_in_arena) return false;
-    if (P.temperature) return false;
+    if (P.temperature && (P.temperature < h->arena_temp || P.temperature >= h->arena_temp + h->arena_gens)) return false;
     if (P.K % PS2_R != 0 || P.to_boundary % PS2_R != 0 || P.ngen % PS2_R != 0 || P.ngen < PS2_R) return false;
     if (P.chain && (!h->hist_joint || (double)h->cfg.N * (h->cfg.d + 1) * (double)h->cfg.Gcap * 8.0 >= 4293918720.0)) return false;
     return true;
@@ -1650,9 +1655,10 @@ static int pc_live_blocks_per_cu()
 template <int D>
 static int ps2_live_blocks_per_cu()
 {
-    int a = 0;
+    int a = 0, b = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&window_kernel_ps2<TARGET_MVNORMAL, D, true, false>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) a = 0;
-    return a;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(&window_kernel_ps2<TARGET_MVNORMAL, D, true, true>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) b = 0;
+    return std::min(a, b);
 }
 
 template <int D>
@@ -1874,7 +1880,14 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         if (h->external_append && nb == 1 && (g_to % K) != 0)
             return fail(h, DEMCZ_ERR_STATE, "demcz_run: with external append the K boundary must be the last generation of the call");
     }
-    if (temperature) {
+    // (a handle with the arena keeps a call's temperatures inside it when they fit: window_kernel_ps2 then reaches them with the
+    //  32-bit offsets it reaches everything else with)
+    const bool temp_in_arena = temperature && h->arena && h->arena_temp && G <= h->arena_gens;
+    if (temperature && temp_in_arena) {
+        SYNCCHK(h, h->stream);              // (earlier windows may still read the region)
+        HIPCHK(h, hipMemcpyAsync(h->arena_temp, temperature, (size_t)G * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        SYNCCHK(h, h->stream);              // the caller may reuse its buffer on return
+    } else if (temperature) {
         if (G > h->temp_cap) {
             { int32_t rcq = quiesce_all(h); if (rcq) return rcq; }
             SYNCCHK(h, h->stream);
@@ -1983,7 +1996,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         P.ngen = (int32_t)(w_end - g + 1);
         P.to_boundary = (int32_t)(next_boundary - g + 1);
         P.slot_first = hist ? (g - h->g0 - 1) : 0;
-        P.temperature = temperature ? h->dtemp + (g - g_from) : nullptr;
+        P.temperature = temperature ? (temp_in_arena ? h->arena_temp : h->dtemp) + (g - g_from) : nullptr;
         P.do_append = (nbound > 0 && kernel_appends) ? 1 : 0;
         P.snap = nullptr;
         if (nbound > 0 && sharded && E > 0) {

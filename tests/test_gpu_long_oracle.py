@@ -128,3 +128,26 @@ def test_c2_eighty_autostop_slabs_equal_oracle(demc, oracle):
     for s in (0, S // 2, S - 1):                           # the monitor's statistic of three slabs against the oracle's
         r = oracle.rhat_gelman(ref["chain"][:, :, s * every:(s + 1) * every])
         assert abs(rmax[s] - np.max(r)) < 1e-9, (s, rmax[s], np.max(r))
+
+
+def test_c2_tempered_live_run_equals_oracle(demc, oracle):
+    """demcz_anneal's accept test log(rand()) < (prop - prev) / T(ig) (demcz_anneal.jl:172-178, T from :1-3) on the steady-state
+    wave-per-chain kernel: window_kernel_ps2<.., LIVE, TEMPER> -- the temperatures ride in the pass's DMA -- for 1500 generations
+    of 1024 chains in three calls, against the oracle."""
+    N, d, K, G, seed = 1024, 5, 10, 1500, 977
+    w = demc.workloads.mvnormal_problem(d, N)
+    M0 = w["Zinit"].shape[0]
+    T = np.array([3.0 * (1e-3 / 3.0) ** (g / G) for g in range(1, G + 1)])
+    e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K + 1), Gcap=G, blockindex=[range(d)], eps_scale=w["eps_scale"], seed=seed,
+                       target=w["target"])
+    e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+    for a, b in ((1, 500), (501, 1000), (1001, 1500)):
+        e.run(a, b, w["gamma"], T[a - 1:b])
+    counts, live = e.kernel_counts(), e.live_status()
+    ch, lo = e.get_history(1, G)
+    X, lp, Z, M = e.get_state()
+    tot = e.changed_total(1, G)
+    e.close()
+    assert counts["ps2"] == 3 and counts["ps_general"] == 0 and live == (True, 0), (counts, live)
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed, temperature=T, threads=THREADS)
+    _same(dict(chain=ch, log_obj=lo, X=X, logp=lp, Z=Z, M=M, changed_total=tot), ref)
