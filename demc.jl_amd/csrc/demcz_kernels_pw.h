@@ -389,8 +389,20 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
 #pragma unroll
         for (int t = 0; t < NF; ++t) { ixA[t] = ixB[t]; ixB[t] = *reinterpret_cast<const uint64_t*>(raw_w + ixo + fu[t] * 8); }
     }
+#ifdef DEMCZ_STAMPS
+    // diagnostic build (scripts/pw_stamps.py): shader-clock sums per segment of a pass (a stamp drains the wave's outstanding LDS /
+    // scalar-memory operations: read the segments as proportions)
+    unsigned long long sa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long sa_start = __builtin_readcyclecounter();
+#define PW_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); sa[i] += t_ - sa_t; sa_t = t_; } while (0)
+#else
+#define PW_T(i) do { } while (0)
+#endif
     int slot = 1;
     for (int ip = 0; ip < npass; ++ip) {
+#ifdef DEMCZ_STAMPS
+        unsigned long long sa_t = __builtin_readcyclecounter();
+#endif
         const int R = qR(0);
         [[maybe_unused]] unsigned int pub_seen = 0u;
         if constexpr (LIVE) {
@@ -418,13 +430,16 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
                 if (2 * q + 1 < D) cand[2 * q + 1] = cand[2 * q + 1] + t.y;
             }
             // (one generation's row at a time, its adds done before the next row is asked for: left alone the compiler
-            //  fetches all five rows first -- 200 registers, spilled -- and adds after the front end)
+            //  fetches all five rows first -- 200 registers, spilled -- and adds after the front end; a rolling window of one
+            //  row's worth of pieces across the rows ends the same way: 233 registers / 115 spilled)
 #pragma unroll
             for (int p = 0; p < D; ++p) asm volatile("" : "+v"(cand[p]));
         }
+        PW_T(0);                 // state row + candidate adds straight from LDS
         wave_lds_handoff();      // (the front end below rewrites the increments)
         store_history();
         const bool bad_n = front(slot, qR(1), qR(3), g3, g5, true);
+        PW_T(1);                 // history stores, DMA wait, next pass's increments, DMA issue
         // the candidates go to rows 1..31 of the table (row 0 keeps the state the pass started from); the log-density follows
         if (nodel) {
 #pragma unroll
@@ -447,6 +462,9 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             // for them.  Measured alternatives at C4's shard, us per K-window: these scalar loads 7.25; W spread over the
             // lanes' registers and read with v_readlane (420 extra vector instructions) 7.7; an LDS copy read with
             // wave-uniform addresses 11.9 (the CU's four chain waves run into the LDS bandwidth); the 16-lane kernel 10.2.
+            // Two rows' fma chains interleaved (independent fmas issue every 4 clocks, dependent ones every 8): 7.0 against
+            // 6.8-6.9 -- it is the waits for the scalar loads, not the fma latency, that the 2800-3000 clocks of this section
+            // are made of (profiles/r03e_pw_stamps.txt), and the second chain cost 40 more SGPR spills.
             typedef const __attribute__((address_space(4))) double* cptr;
             uint64_t wa = (uint64_t)(uintptr_t)P.tp.Wp;
             asm volatile("" : "+s"(wa));
@@ -469,6 +487,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             }
         }
         if (nodel) ct_w[lane * CR + D] = lpp;
+        PW_T(2);                 // table write, log-density (W through scalar loads)
         unsigned long long mask, chg_a, chg_r;
         {
             const unsigned long long lb = (unsigned long long)__double_as_longlong((lane == 0) ? lp : lpp);
@@ -492,6 +511,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             cnt_total += (unsigned int)__builtin_popcount(chm);
             if (g0 == 0) cnt_first = (chm >> 1) & 1u;
         }
+        PW_T(3);                 // bpermute, accept tests, path
         wave_lds_handoff();
         // history rows of the pass (read now, stored during the next pass), then the winner's row becomes row 0
 #pragma unroll
@@ -506,6 +526,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             if (lane < CR / 2) reinterpret_cast<double2*>(ct_w)[lane] = reinterpret_cast<const double2*>(ct_w + win * CR)[lane];
         }
         wave_lds_handoff();
+        PW_T(4);                 // history values, winner's row to row 0
         // a generation divisible by K ended the pass: runchain!'s append, demcz.jl:88-91
         if (segq & 8u) {
             constexpr int NA = (D + 63) / 64;
@@ -533,11 +554,13 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             }
             ++nb;
         }
+        PW_T(5);                 // boundary
         if constexpr (LIVE) {
             if (__builtin_amdgcn_ballot_w64(bad_n) != 0ull) {
                 if (reread(slot, qR(1), g0 + R)) { leave(); return; }
             }
         }
+        PW_T(6);                 // waits for rows not yet published
         wave_lds_handoff();
         g0 += R;
         g3 += qR(3);
@@ -546,7 +569,16 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
 #pragma unroll
         for (int t = 0; t < NF; ++t) { ixA[t] = ixB[t]; ixB[t] = *reinterpret_cast<const uint64_t*>(raw_w + slot * SLOTB + ixo + fu[t] * 8); }
         slot = (slot + 1 == PS_SLOTS) ? 0 : slot + 1;
+        PW_T(7);                 // queue bookkeeping
     }
+#ifdef DEMCZ_STAMPS
+    if (P.stamps && lane == 0 && c < 65536) {
+        unsigned long long* o = P.stamps + (size_t)c * 16;
+        for (int i = 0; i < 8; ++i) o[i] = sa[i];
+        o[8] = __builtin_readcyclecounter() - sa_start; o[14] = (unsigned long long)npass; o[15] = 3;
+    }
+#endif
+#undef PW_T
     store_history();
     {
         constexpr int NA = (D + 63) / 64;
