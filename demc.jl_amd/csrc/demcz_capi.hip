@@ -1778,7 +1778,13 @@ static int64_t live_span(demcz_handle* h)
     if ((h->cfg.N + per_wg - 1) / per_wg > live_wg_capacity(h)) return 0;
     if (!live_claim(h)) return 0;
     const int64_t per_gen = rec_fields(h) * h->cfg.N * (int64_t)sizeof(double);
-    const int64_t span = (int64_t)(64ll << 20) / per_gen;        // 64 MiB of records per buffer (C2: 1170 generations)
+    // 64 MiB of records per buffer inside the arena (C2: 1170 generations, more than an autostop slab), 1 GiB outside it (C4's
+    // shard 5960 generations instead of 372, C5 5450 instead of 340, C3 820 instead of 51; allocated as launches need it): every
+    // launch boundary costs 15-25 us of gap, first-pass latency and tail imbalance -- C4's shard 7.4 -> 6.1 us per K-window,
+    // C5 22.3 -> 21.5 (profiles/r03f_launch_span.txt)
+    static const int64_t env_mib = getenv("DEMCZ_REC_MIB") ? atol(getenv("DEMCZ_REC_MIB")) : 0;
+    const int64_t mib = env_mib > 0 ? env_mib : (h->arena ? 64 : 1024);
+    const int64_t span = (int64_t)(mib << 20) / per_gen;
     return std::max<int64_t>(h->cfg.K, std::min<int64_t>(span, 1 << 20));
 }
 
