@@ -1783,7 +1783,8 @@ static int64_t live_span(demcz_handle* h)
     // launch boundary costs 15-25 us of gap, first-pass latency and tail imbalance -- C4's shard 7.4 -> 6.1 us per K-window,
     // C5 22.3 -> 21.5 (profiles/r03f_launch_span.txt)
     static const int64_t env_mib = getenv("DEMCZ_REC_MIB") ? atol(getenv("DEMCZ_REC_MIB")) : 0;
-    const int64_t mib = env_mib > 0 ? env_mib : (h->arena ? 64 : 1024);
+    // (block updates, split kind 3: flat between 64 and 256 MiB, 4 % slower at 1 GiB -- 128)
+    const int64_t mib = env_mib > 0 ? env_mib : (h->arena ? 64 : (h->split_kind == 3) ? 128 : 1024);
     const int64_t span = (int64_t)(mib << 20) / per_gen;
     return std::max<int64_t>(h->cfg.K, std::min<int64_t>(span, 1 << 20));
 }
@@ -1992,7 +1993,25 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         // Split layout on one GPU: the launch runs on through the boundaries; waves hand the appended rows
         // to each other inside it (LIVE, demcz_kernels_pc.h), so the schedule is still the synchronous one.
         const int64_t live_max = live_span(h);
-        if (live_max > 0) w_end = std::min(g + live_max - 1, g_to);
+        if (live_max > 0) {
+            // How far this launch goes: as far as the records allow -- but no further than the draws that ARE there, where the
+            // launch before prepared fewer than that (a call longer than the last one); and a launch whose draws have to be made
+            // first, with nothing to run beside (the first of a run), stays short: its producer is serial time
+            // (64 MiB of records, the span of every launch until round 3f; profiles/r03f_launch_span.txt).
+            int64_t n = std::min(live_max, g_to - g + 1);
+            const auto& dc = h->rec_desc[h->rec_cur];
+            const int64_t rows_v = h->cfg.N;                  // (live: immediate visibility, one GPU)
+            const int32_t boff = (int32_t)(K - (next_boundary - g + 1));
+            const bool ready = dc.valid && dc.g_first == g + h->rng_offset && dc.M == h->M && dc.rows == rows_v && dc.boff == boff;
+            if (ready && dc.ngen >= K) {
+                if (dc.ngen < n) n = std::max<int64_t>((dc.ngen / K) * K, K);
+            } else {
+                const int64_t per_gen = rec_fields(h) * h->cfg.N * (int64_t)sizeof(double);
+                const int64_t cold = std::max<int64_t>(K, ((int64_t)(64ll << 20) / per_gen / K) * K);
+                n = std::min(n, cold);
+            }
+            w_end = g + n - 1;
+        }
         int32_t rc = admit_pending(h, g);
         if (rc) return rc;
         const int64_t nbound = w_end / K - (g - 1) / K;           // boundaries inside this launch
