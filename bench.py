@@ -183,6 +183,40 @@ def deferred_batch_us(E, n_loc):
     return (7.5 + 1.6 * E) * (n_loc / 1024.0)
 
 
+def sharded_selfcheck(demc, sharding, rank, local_rank, stream_ptr, all_min, sharded_engine_factory=None):
+    """Before any multi-GPU number is quoted: a small run over the communicator (this rank's shard of 128 chains per rank, 120
+    generations, the R-hat of the whole population) against the SAME run made by this GPU alone over all the chains -- results
+    do not depend on the sharding (a chain's random stream is its global id, every rank holds the whole archive), so the shard
+    must equal its rows of the unsharded history bit for bit, the archives must be equal, and so must the statistic.  Both
+    schedules: rows visible from the next generation on, and batches of two boundaries.  `all_min`: reduces an int over the
+    ranks with MIN.  `sharded_engine_factory`: tests on a one-GPU box build the sharded leg's engine with a one-rank communicator.
+    Returns {schedule: bool}."""
+    n_loc, d, K, G, seed = 128, 5, 10, 120, 4242
+    world = sharding.world_size if sharding else 1
+    N = n_loc * world
+    w = demc.workloads.mvnormal_problem(d, N)
+    X, logp = demc.initial_state(w["target"], w["Zinit"], N, G, K, None, "last_rows")
+    out = {}
+    for name, lag in (("every_K", 0), ("batches_of_2", 2)):
+        res = []
+        for sh in (sharding, None):
+            r = demc.make_runner(w["target"], w["Zinit"], N, K, G, [range(d)], w["eps_scale"], X, logp, seed=seed, sharding=sh,
+                                 device_id=local_rank, engine_factory=sharded_engine_factory if sh is not None else None,
+                                 lanes_per_chain=0, stream=stream_ptr, append_lag=lag)
+            r.run(1, G, w["gamma"])
+            rh = r.rhat(1, G)
+            ch, lo = r.history(1, G)
+            _, _, Z, M = r.state()
+            r.close()
+            res.append((np.array(ch), np.array(lo), np.array(Z), int(M), np.array(rh)))
+        (cs, ls, Zs, Ms, rs), (c1, l1, Z1, M1, r1) = res
+        lo_, hi_ = rank * n_loc, (rank + 1) * n_loc
+        ok = (np.array_equal(cs, c1[lo_:hi_]) and np.array_equal(ls, l1[lo_:hi_]) and Ms == M1 and np.array_equal(Zs, Z1)
+              and bool(np.all(np.abs(rs - r1) <= 1e-9 * np.maximum(1.0, np.abs(r1)))))
+        out[name] = bool(all_min(1 if ok else 0) == 1)
+    return out
+
+
 def tune_append_lag(dist, torch, n_loc, d, K, every, device):
     """Sharded runs: boundaries per all-gather (demcz_set_append_lag).  A batch's rows travel while the next batch computes;
     if the all-gather takes longer than that the run is bound by the links' latency, not by the kernels.  The latency of an
@@ -323,6 +357,29 @@ def main():
             print(json.dumps({"dry_run": True, "ranks": [plan]}))
         return
     stream = torch.cuda.Stream()
+    selfcheck = None
+    if world > 1:
+        def all_min(v):
+            t = torch.tensor([v], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item())
+        try:
+            selfcheck = sharded_selfcheck(demc, sharding, rank, local_rank, stream.cuda_stream, all_min)
+        except demc.DemczError as e:
+            if e.code == 6:            # DEMCZ_ERR_COMM: same exit as below
+                sys.stderr.write(json.dumps({"error": "DEMCZ_ERR_COMM in the sharded self-check", "message": str(e), "rank": rank}) + "\n")
+                sys.stderr.flush()
+                os._exit(3)
+            raise
+        if not all(selfcheck.values()):
+            # a sharded run that does not reproduce the unsharded one is not a measurement of anything: say so and stop
+            if rank == 0:
+                print(json.dumps({"metric": "chain-updates/sec (N x gens/s) + gens-to-Rhat<1.05, MvNormal d=5 N=1024", "value": None,
+                                  "unit": "chain-updates/s", "n_gpus": world, "error": "sharded self-check failed: the sharded run "
+                                  "differs from the same run on one GPU", "sharded_selfcheck": selfcheck}))
+            dist.barrier()
+            dist.destroy_process_group()
+            sys.exit(4)
     X, logp = demc.initial_state(w["target"], w["Zinit"], N, G, K, None, "last_rows")
 
     def measure(lag_m):
@@ -435,7 +492,7 @@ def main():
                                       if lag_value == 0 else f"`value`: deferred visibility, append_lag {lag_value}"),
                        "chains_total": N, "dim": d, "K": K, "generations_per_step": every, "generations_timed": gens,
                        "lanes_per_chain": lanes, "append_lag": lag_value, "append_lag_probe_us": lag_probe,
-                       "live_launches": live_on, "live_redos": live_redos,
+                       "live_launches": live_on, "live_redos": live_redos, "sharded_selfcheck": selfcheck,
                        "parallelism": f"chains sharded x{world}, Z replicated" if world > 1 else "single GPU"},
             "gens_to_rhat_1p05": gens_to_rhat, "rhat_trace": rhat_trace[-12:], "accept_ratio_mean": acc,
             "value_window_kernels_only": N * gens / (ev_ms / 1e3) if ev_ms > 0 else None,

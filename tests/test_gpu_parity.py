@@ -710,3 +710,29 @@ def test_streamed_history_equals_copied_history(demc, oracle):
     g_stop = mc.chain.shape[2]
     assert g_stop < G and g_stop % 100 == 0
     assert np.array_equal(mc.chain, ref["chain"][:, :, :g_stop]) and np.array_equal(mc.log_obj, ref["log_obj"][:, :g_stop])
+
+
+def test_bench_sharded_selfcheck_with_a_one_rank_communicator(demc):
+    """bench.py's gate in front of every multi-GPU number (sharded_selfcheck): a small sharded run against the same run on one
+    GPU, both schedules.  The box has one GPU, so the communicator has one rank -- the RCCL calls, the batching and the
+    comparison are the ones an 8-rank run makes."""
+    import importlib.util
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("bench_mod", root / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from demc_jl_amd.sampler import Sharding
+    made = []
+
+    def factory(**kw):
+        e = demc.HipEngine(**kw)
+        e.comm_init(e.comm_unique_id(), 1, 0)          # the library's sharded path: all-gather, scatter, all-reduced R-hat
+        made.append(e)
+        return e
+    sh = Sharding(rank=0, world_size=1, mode="rccl", local_shards=1, all_gather=lambda a: [a], all_reduce_sum=lambda a: a,
+                  broadcast_bytes=lambda b: b)
+    out = bench.sharded_selfcheck(demc, sh, 0, 0, None, lambda v: v, sharded_engine_factory=factory)
+    assert len(made) == 2                              # one sharded engine per schedule
+    assert out == {"every_K": True, "batches_of_2": True}, out
