@@ -66,3 +66,7 @@ if buf[:, 9].max() > 0:      # window_kernel_ps2: when each chain wave began and
     print(f"  own waits per chain: mean {wsum.mean():.1f} us, min {wsum.min():.1f}, max {wsum.max():.1f}; corr(end, waits) = {np.corrcoef(e, wsum)[0, 1]:.2f}")
     work = (s[:, 8] - s[:, 6]) / 2100.0
     print(f"  launch minus own waits per chain: mean {work.mean():.1f} us, min {work.min():.1f}, max {work.max():.1f}; by wave: " + " ".join(f"{work[cidx % 4 == w].mean():.1f}" for w in range(4)))
+    wg = work.reshape(-1, 4)              # chains of a workgroup (one CU) are consecutive
+    print(f"  work: std over all chains {work.std():.2f} us; std of workgroup means {wg.mean(axis=1).std():.2f}; mean std inside a workgroup {wg.std(axis=1).mean():.2f}")
+    order = np.argsort(wg.mean(axis=1))
+    print("  slowest workgroups (index: mean work us): " + ", ".join(f"{i}: {wg[i].mean():.1f}" for i in order[-6:]) + "; fastest: " + ", ".join(f"{i}: {wg[i].mean():.1f}" for i in order[:4]))
