@@ -90,6 +90,107 @@ def throughput_point(demc, N, d, K, seed, gens, device_id):
     return {"chains": N, "lanes_per_chain": lanes, "value": N * gens / dt, "achieved_GBps": gbs, "frac_of_8TBps": gbs / 8000.0}
 
 
+FP64_MFMA_PEAK_TFLOPS = 78.6    # v_mfma_f64_16x16x4_f64: 2048 flop / 65 clocks x 1024 SIMDs x 2.4 GHz (measured instruction rate,
+                                # scripts/probes/mfma_f64_rate.hip, profiles/r03c_mfma_f64_rate.txt)
+
+
+def config_row(demc, name, w, N, d, K, blocks, seed, device_id, gens=2000, anneal=False, flops_per_update=None):
+    """One of the other BASELINE configs that fit one GPU (C3, C4's per-GPU shard, C5): `gens` generations after a warm slab of
+    the same length, history and appends included, window kernels timed by HIP events on their own stream inside the library
+    (demcz_set_kernel_timing).  Priced like the headline: algorithmic bytes per launch / average launch
+    duration against HBM -- or, for the regression target, algorithmic flops against the FP64 matrix rate."""
+    M0 = w["Zinit"].shape[0]
+    e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (2 * gens // K + 1), Gcap=2 * gens, blockindex=blocks, eps_scale=w["eps_scale"],
+                       seed=seed, target=w["target"], device_id=device_id)
+    try:
+        e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+        temps = np.array([demc.tempbaseline(g, 2 * gens, 3.0, 1e-3) for g in range(1, 2 * gens + 1)]) if anneal else None
+        e.run(1, gens, w["gamma"], None if temps is None else temps[:gens])
+        e.synchronize()
+        e.set_kernel_timing(True)
+        t0 = time.perf_counter()
+        e.run(gens + 1, 2 * gens, w["gamma"], None if temps is None else temps[gens:])
+        e.synchronize()
+        dt = time.perf_counter() - t0
+        launches, ev_ms = e.get_kernel_time()
+        e.set_kernel_timing(False)
+        rh = e.rhat(gens + 1, 2 * gens)
+        live_on, redos = e.live_status()
+        B = algorithmic_bytes_per_update(d, K)
+        gpl = gens / max(launches, 1)
+        avg_s = ev_ms / 1e3 / max(launches, 1)
+        row = {"workload": name, "chains": N, "dim": d, "K": K, "generations_timed": gens, "value": N * gens / dt,
+               "unit": "chain-updates/s", "us_per_K_window": dt / (gens / K) * 1e6,
+               "us_per_K_window_kernels": (ev_ms / 1e3) / (gens / K) * 1e6,
+               "kernel": e.kernel_name(), "lanes_per_chain": e.info()["lanes_per_chain"], "live_launches": live_on, "live_redos": redos,
+               "launches": launches, "generations_per_launch": gpl, "avg_launch_us": avg_s * 1e6, "max_rhat": float(np.max(rh))}
+        if flops_per_update is None:
+            ach = B * N * gpl / avg_s / 1e9
+            row["roofline"] = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                               "bytes_per_chain_update": B, "algorithmic_bytes_per_launch": B * N * gpl}
+        else:
+            ach = flops_per_update * N * gpl / avg_s / 1e12
+            row["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / FP64_MFMA_PEAK_TFLOPS, "flops_per_chain_update": flops_per_update,
+                               "peak_source": "v_mfma_f64_16x16x4_f64 measured: 2048 flop / 65 clocks x 1024 SIMDs x 2.4 GHz "
+                                              "(profiles/r03c_mfma_f64_rate.txt); dtype f64"}
+        return row
+    finally:
+        e.close()
+
+
+def config_rows(demc, seed, device_id):
+    """BASELINE configs C3, C4 (one GPU's shard of it) and C5 -- and C1 on the HIP path (its CPU row is in cpu_baseline)."""
+    out = {}
+    K = 10
+    try:
+        w = demc.workloads.mvnormal_problem(20, 4096)
+        out["C3"] = config_row(demc, "C3: MvNormal d=20, Nblocks=4 (4 x 5), N=4096", w, 4096, 20, K,
+                               [range(0, 5), range(5, 10), range(10, 15), range(15, 20)], seed, device_id)
+        w = demc.workloads.mvnormal_problem(20, 1024)
+        out["C4_shard"] = config_row(demc, "C4: one GPU's shard of MvNormal d=20 N=8192 over 8 GPUs: N=1024, Z all local", w, 1024, 20, K,
+                                     [range(20)], seed, device_id)
+        w = demc.workloads.linreg_problem(10, 2048)
+        nobs = w["design"].shape[0]
+        out["C5"] = config_row(demc, "C5: demcz_anneal on linear-regression SSE, d=10, nobs=1000, N=2048, T0=3 -> TN=1e-3", w, 2048, 10, K,
+                               [range(10)], seed, device_id, anneal=True, flops_per_update=2.0 * nobs * 10 + 3.0 * nobs)
+        w = demc.workloads.mvnormal_problem(5, 4)
+        out["C1_hip"] = config_row(demc, "C1 on the HIP path: MvNormal d=5, N=4, 10 000 generations (BASELINE runs C1 on the CPU: cpu_baseline.c1)",
+                                   w, 4, 5, K, [range(5)], seed, device_id, gens=10000)
+    except Exception as e:          # reporting only
+        out["error"] = f"{type(e).__name__}: {e}"[:300]
+    return out
+
+
+def cpu_c1(K=10, seed=31953150):
+    """BASELINE config C1 as the reference runs it (test/example_normpdf.jl:20-30 plumbing): MvNormal d=5, N=4 chains, 10 000
+    generations, ONE core, chains updated in the reference's order (chain ic+1 sees chain ic's fresh archive row inside a
+    generation divisible by K, src/demcz.jl:30-33, 88-91), chains started at the zero vector (src/demcz.jl:11, 15: the slice of
+    the zero-padded matrix).  The oracle -- this repo's C restatement -- not the Julia package."""
+    import demc_jl_amd as demc
+    import oracle_py as O
+    try:
+        O.build(native=True)
+        native = True
+    except Exception:
+        native = False
+    N, d, G = 4, 5, 10000
+    w = demc.workloads.mvnormal_problem(d, N)
+    Z0 = w["Zinit"]
+    M0 = Z0.shape[0]
+    Mcap = M0 + -(-N * G // K)
+    prob = O.Problem(N, d, K, Mcap, w["eps_scale"], seed, target=w["target"].spec())
+    X = np.zeros((N, d), order="F")                       # init="reference_zeros"
+    lp = O.logp(prob, X)
+    Z = np.zeros((Mcap, d), order="F")
+    Z[:M0] = Z0
+    t0 = time.perf_counter()
+    O.run(prob, X, lp, Z, M0, 1, G, w["gamma"], history=True, native=native, schedule=O.SCHED_SEQUENTIAL)
+    dt = time.perf_counter() - t0
+    return {"value": N * G / dt, "unit": "chain-updates/s", "cores": 1, "seconds": dt,
+            "sample": "C1 whole: N=4, d=5, K=10, 10 000 generations, reference order, chains start at zero (demcz.jl:11,15), O(1) index draw"}
+
+
 def cpu_baseline(w, N, d, K, seed, budget_updates, M_final):
     """Time the oracle (test infrastructure, used here only as the reported CPU baseline)."""
     sys.path.insert(0, str(ROOT / "oracle"))
@@ -101,9 +202,9 @@ def cpu_baseline(w, N, d, K, seed, budget_updates, M_final):
         native = False
     Z0 = w["Zinit"]
     M0 = Z0.shape[0]
-    # the sample is sized by TIME: a 1000-generation calibration run, then as many generations as ~5 s of this host's
+    # the sample is sized by TIME: a 1000-generation calibration run, then as many generations as ~3 s of this host's
     # single core make (at most budget_updates); the sequential row runs half as many, the OpenMP row twice as many
-    # -- about 12-20 s of CPU work in all, whatever the host
+    # -- about 10 s of wall time in all, whatever the host
     Gc = 1000 // K * K
     probc = O.Problem(N, d, K, M0 + -(-N * Gc // K), w["eps_scale"], seed, target=w["target"].spec())
     Xc = np.array(Z0[M0 - N:], order="F")
@@ -113,7 +214,7 @@ def cpu_baseline(w, N, d, K, seed, budget_updates, M_final):
     t0 = time.perf_counter()
     O.run(probc, Xc, lpc, Zc, M0, 1, Gc, w["gamma"], history=True, native=native)
     rate_c = N * Gc / (time.perf_counter() - t0)
-    G = max(K, int(min(budget_updates, 5.0 * rate_c) // N) // K * K)
+    G = max(K, int(min(budget_updates, 3.0 * rate_c) // N) // K * K)
     Mcap = M0 + -(-N * G // K)
     prob = O.Problem(N, d, K, Mcap, w["eps_scale"], seed, target=w["target"].spec())
     X = np.array(Z0[M0 - N:], order="F")
@@ -173,6 +274,10 @@ def cpu_baseline(w, N, d, K, seed, budget_updates, M_final):
         out["omp"] = {"value": N * Gm / dt2, "cores": thr, "sample": f"{Gm} generations, {dt2:.1f} s"}
     except Exception as e:  # the OpenMP row is optional; the scalar port above is the contract
         out["omp"] = {"value": None, "error": str(e)[:200]}
+    try:
+        out["c1"] = cpu_c1(K)
+    except Exception as e:
+        out["c1"] = {"value": None, "error": str(e)[:200]}
     return out
 
 
@@ -265,6 +370,7 @@ def main():
     ap.add_argument("--dim", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the chain-count sweep object")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (C3, C4's shard, C5, C1 on the HIP path)")
     ap.add_argument("--lanes-per-chain", type=int, default=0)
     ap.add_argument("--append-lag", type=int, default=-1,
                     help="demcz_set_append_lag batches for `value`.  Default: 0 (rows visible from the next generation on -- the "
@@ -395,21 +501,16 @@ def main():
             """Generations g_from..g_to with the R-hat check every `every` generations: one library call
             (demcz_run_checked = the driver loop demcz.jl:30-55 without its stop), the window kernels timed by
             HIP events on their own stream inside the library.  Returns (ms spent in window kernels, launches)."""
-            if timed:
-                eng.set_kernel_timing(True)
-            _, trace, _ = runner.run_checked(g_from, g_to, w["gamma"], every, 0.0)
+            _, trace, _ = runner.run_checked(g_from, g_to, w["gamma"], every, 0.0)      # (returns with the streams drained)
+            return trace
+
+        def note(trace, g_from):
             first = ((g_from - 1) // every + 1) * every
             for i, mx in enumerate(trace):
                 gchk = first + i * every
                 res["rhat_trace"].append((gchk, float(mx)))
                 if res["gens_to_rhat"] is None and mx < thr:
                     res["gens_to_rhat"] = gchk
-            runner.synchronize()
-            if not timed:
-                return 0.0, 0
-            n, ms = eng.get_kernel_time()
-            eng.set_kernel_timing(False)
-            return ms, n
 
         def fence():
             runner.synchronize()
@@ -418,12 +519,18 @@ def main():
                 dist.barrier()
                 torch.cuda.synchronize()
 
-        advance(1, W * every, False)
+        note(advance(1, W * every, False), 1)
+        eng.set_kernel_timing(True)
         fence()
+        # the timed region holds the S steps and nothing else: one library call that returns when its last slab's statistic is on
+        # the host, and the fence.  Reading the events out, bookkeeping in Python: after it.
         t0 = time.perf_counter()
-        ev_ms, launches = advance(W * every + 1, G, True)
+        trace = advance(W * every + 1, G, True)
         fence()
         dt = time.perf_counter() - t0
+        note(trace, W * every + 1)
+        launches, ev_ms = eng.get_kernel_time()
+        eng.set_kernel_timing(False)
         if dist is not None:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -439,6 +546,8 @@ def main():
                    acc=runner.accept_ratio_mean(G - every + 1, G))          # (a cheap end-of-run sanity check, not timed)
         res["live_on"], res["live_redos"] = eng.live_status()
         res["lanes"] = eng.info()["lanes_per_chain"]
+        res["kernel"] = eng.kernel_name()
+        res["kernel_counts"] = eng.kernel_counts()
         runner.close()        # (frees the device's LIVE slot for the next measurement / the sweep's handles)
         return res
 
@@ -472,12 +581,12 @@ def main():
         # launches had this shape.  `traffic` = FETCH_SIZE + WRITE_SIZE as counted; `traffic_fetch_x2` = the upper
         # bound with every fetched byte doubled (MI355X_MICROARCH.md, HBM: gfx950 halves coalesced streaming reads)
         traffic = measured_traffic(n_loc, d, K, lanes, gens_per_launch) or (None, None, None)
-        split = lanes == 100
         out = {
             "metric": "chain-updates/sec (N x gens/s) + gens-to-Rhat<1.05, MvNormal d=5 N=1024",
             "value": N * gens / dt, "unit": "chain-updates/s", "n_gpus": world, "steps": S, "warmup": W,
             "ms_per_step": dt / S * 1e3,
             "ms_per_step_median": float(np.median(m["steps_ms"])) if m["steps_ms"] else None,
+            "value_median": (N * every / (float(np.median(m["steps_ms"])) / 1e3)) if m["steps_ms"] else None,
             "ms_per_step_device": {"n": len(m["steps_ms"]), "min": float(np.min(m["steps_ms"])) if m["steps_ms"] else None,
                                    "median": float(np.median(m["steps_ms"])) if m["steps_ms"] else None,
                                    "max": float(np.max(m["steps_ms"])) if m["steps_ms"] else None,
@@ -499,10 +608,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "frac_of_measured_copy": achieved / 6290.0,        # MI355X_MICROARCH.md: 6.29 TB/s measured copy rate
                          "traffic": traffic[0], "traffic_fetch_x2": traffic[1], "traffic_source": traffic[2],
-                         "kernel": (f"demcz::window_kernel_ps2<MVNORMAL, {d}, LIVE={'true' if live_on else 'false'}> (+ demcz::produce_kernel<{d}> beside it)"
-                                    if lanes == 164 else
-                                    f"demcz::window_kernel_pc8<MVNORMAL, {d}, LIVE={'true' if live_on else 'false'}>" if split
-                                    else "demcz::window_kernel"),
+                         "kernel": m["kernel"] + (f" (+ demcz::produce_kernel<{d}> beside it)" if lanes == 164 else ""),
+                         "kernel_counts": m["kernel_counts"],
                          "launches": launches, "generations_per_launch": gens_per_launch,
                          "avg_launch_us": avg_launch_s * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_chain_update": B},
@@ -521,6 +628,8 @@ def main():
                                             for n, g in ((4096, 1000), (16384, 400), (131072, 200), (1048576, 100))]
             except Exception as e:
                 out["chain_count_sweep"] = f"failed: {e}"
+        if world == 1 and not args.no_configs:
+            out["configs"] = config_rows(demc, seed, local_rank)
         if not args.no_cpu_baseline and world == 1:      # (the contract: rank 0 at N = 1 only)
             try:
                 out["cpu_baseline"] = cpu_baseline(demc.workloads.mvnormal_problem(d, n_loc), n_loc, d, K, seed, 8.0e7, w["Zinit"].shape[0] + N * (G // K))

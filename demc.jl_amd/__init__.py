@@ -10,7 +10,7 @@ All computation below the generation loop runs in ``libdemcz_hip.so`` (HIP, gfx9
 C ABI of ``include/demcz.h``; there is no CPU fallback.
 """
 from ._lib import DemczError, build, LIB_PATH, SYMBOLS, LAYOUT_SPLIT, LAYOUT_SPLIT_WAVE          # noqa: F401
-from .engine import HipEngine, selftest_draws                   # noqa: F401
+from .engine import HipEngine, selftest_draws, pool_trim                   # noqa: F401
 from .targets import MvNormalTarget, IsoQuadTarget, LinRegSSETarget, is_device_target   # noqa: F401
 from .sampler import (MC, DEMCopt, demcopt, demcz_sample, demcz_anneal, tempbaseline,   # noqa: F401
                       make_runner, initial_state,

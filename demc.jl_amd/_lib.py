@@ -43,7 +43,7 @@ SYMBOLS = [
     "demcz_debug_append_slab", "demcz_get_changed_total", "demcz_debug_set_live_fault",
     "demcz_set_comm_timeout", "demcz_debug_stall_exchange", "demcz_get_kernel_time_series",
     "demcz_history_stream", "demcz_get_history_view", "demcz_detach_history", "demcz_release_host_buffer", "demcz_get_archive_pinned",
-    "demcz_debug_kernel_counts",
+    "demcz_debug_kernel_counts", "demcz_pool_trim", "demcz_debug_kernel_name",
 ]
 
 
@@ -68,7 +68,7 @@ class Config(C.Structure):
 
 def build_command(out: Path = LIB_PATH) -> list:
     src = PKG_DIR / "csrc" / "demcz_capi.hip"
-    return ["hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-pass-failed",
+    return ["hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-Werror", "-Wno-pass-failed",
             "-o", str(out), str(src), "-lrccl"]
 
 
@@ -139,6 +139,8 @@ def load():
     L.demcz_get_history_view.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.demcz_detach_history.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.demcz_release_host_buffer.argtypes = [C.c_void_p]
+    L.demcz_pool_trim.argtypes = [_lp, _lp]
+    L.demcz_debug_kernel_name.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
     L.demcz_get_archive_pinned.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), _lp]
     L.demcz_get_kernel_time_series.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _ip]
     L.demcz_set_comm_timeout.argtypes = [C.c_void_p, C.c_int64]

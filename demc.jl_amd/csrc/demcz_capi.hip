@@ -61,9 +61,37 @@ struct BufPool {
                 return hipSuccess;
             }
         }
-        const hipError_t e = host ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
+        hipError_t e = host ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
+        if (e != hipSuccess) {
+            // what this pool keeps for later may be exactly what is missing now (a handle of another shape, another library of
+            // the process): give everything cached back to the runtime and ask once more
+            (void)hipGetLastError();
+            if (trim() > 0) e = host ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
+        }
         if (e == hipSuccess) { std::lock_guard<std::mutex> lk(mu); sizes[*out] = bytes; }
         return e;
+    }
+    // frees every cached buffer; returns the bytes given back
+    size_t trim()
+    {
+        std::vector<Entry> drop;
+        size_t n = 0;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            drop.swap(free_list);
+            n = cached;
+            cached = 0;
+        }
+        for (const Entry& e : drop) { if (host) (void)hipHostFree(e.p); else (void)hipFree(e.p); }
+        return n;
+    }
+    // a buffer something may still be writing (an undrained stream, an aborted communicator's kernels): never cached -- hipFree /
+    // hipHostFree wait for the device
+    void discard(void* p)
+    {
+        if (!p) return;
+        { std::lock_guard<std::mutex> lk(mu); sizes.erase(p); }
+        if (host) (void)hipHostFree(p); else (void)hipFree(p);
     }
     void release(void* p, int device)
     {
@@ -155,6 +183,7 @@ struct demcz_handle {
     bool has_state = false;
     int64_t launches = 0;
     mutable int64_t kernel_counts[1] = {0};               // demcz_debug_kernel_counts: launches taken by window_kernel_ps2
+    int last_live = 0, last_ps2 = 0, last_temper = 0;     // demcz_debug_kernel_name: what the most recent window launch was
     bool external_append = false;
     // host-closure mode
     double* dXprop = nullptr;
@@ -255,13 +284,11 @@ struct demcz_handle {
     int batch_buf = 0, batch_cnt = 0;
     int64_t batch_base = 0;
     // streamed history (demcz_history_stream): pinned host mirrors of chain / log_obj, filled slab by slab on a copy stream while
-    // the next slab computes; hs_upto = history slots whose copy has been enqueued, hs_events = (slot_end, event) per copy
+    // the next slab computes
     bool hs_on = false;
     double* hs_chain = nullptr;
     double* hs_logobj = nullptr;
     hipStream_t hs_stream = nullptr;
-    std::deque<std::pair<int64_t, hipEvent_t>> hs_events;
-    int64_t hs_upto = 0;
     bool pooled_dev = false;           // dZ / dchain came from (and go back to) the process-wide device pool
     // comm failure path: every host-side wait of a sharded handle has a deadline (demcz_set_comm_timeout); on expiry, or on an
     // asynchronous RCCL error, both communicators are aborted and the handle is dead (DEMCZ_ERR_COMM from every call)
@@ -341,7 +368,7 @@ static int32_t comm_fail(demcz_handle* h, const std::string& why)
     h->comm_side = nullptr;                                   // (abort frees them; `comm` stays non-null as the "sharded" mark
     // bounded drain: with the collectives gone the streams should run dry; do not wait for ever for that either
     const auto t0 = std::chrono::steady_clock::now();
-    hipStream_t ss[4] = {h->stream, h->comm_stream, h->prod_stream, h->diag_stream};
+    hipStream_t ss[5] = {h->stream, h->comm_stream, h->prod_stream, h->diag_stream, h->hs_stream};
     for (hipStream_t st : ss) {
         if (!st) continue;
         while (hipStreamQuery(st) == hipErrorNotReady &&
@@ -416,7 +443,7 @@ static int32_t quiesce_all(demcz_handle* h)
 {
     if (h->comm_dead) return DEMCZ_ERR_COMM;
     if (!h->comm) return DEMCZ_OK;
-    for (hipStream_t st : {h->stream, h->comm_stream, h->prod_stream, h->diag_stream})
+    for (hipStream_t st : {h->stream, h->comm_stream, h->prod_stream, h->diag_stream, h->hs_stream})
         if (st) { int32_t rc = sync_stream(h, st, "quiesce"); if (rc) return rc; }
     return DEMCZ_OK;
 }
@@ -484,18 +511,27 @@ static hipError_t dev_alloc_copy(T** dst, const T* src, size_t n, hipStream_t s,
 
 static void free_all(demcz_handle* h)
 {
+    // Buffers only go back to the pools when nothing can still be touching them: every stream of the handle has run dry
+    // (demcz_destroy waits for them) and no communicator was aborted under it.  Otherwise they are freed -- hipFree / hipHostFree
+    // wait for the device, which is what the pools exist to avoid but is the only safe thing then.
+    bool drained = !h->comm_dead;
+    for (hipStream_t st : {h->stream, h->prod_stream, h->diag_stream, h->comm_stream, h->hs_stream})
+        if (st && hipStreamQuery(st) != hipSuccess) drained = false;
     if (h->d_acc) (void)dev_free(h->cfg.device_id, h->d_acc);
-    if (h->pooled_dev) {               // (the two big ones go back to the pool; free_all runs behind a stream synchronisation)
-        g_dev_pool.release(h->dZ, h->cfg.device_id);
-        if (h->hist_joint) g_dev_pool.release(h->dchain, h->cfg.device_id);
+    if (h->pooled_dev) {               // (the two big ones)
+        if (drained) {
+            g_dev_pool.release(h->dZ, h->cfg.device_id);
+            if (h->hist_joint) g_dev_pool.release(h->dchain, h->cfg.device_id);
+        } else {
+            g_dev_pool.discard(h->dZ);
+            if (h->hist_joint) g_dev_pool.discard(h->dchain);
+        }
         h->dZ = nullptr;
         if (h->hist_joint) h->dchain = nullptr;
     }
-    for (auto& pe : h->hs_events) if (pe.second) (void)hipEventDestroy(pe.second);
-    h->hs_events.clear();
-    stream_release(h->cfg.device_id, h->hs_stream, !h->comm_dead && hipStreamQuery(h->hs_stream) == hipSuccess);
-    g_host_pool.release(h->hs_chain, -1);
-    g_host_pool.release(h->hs_logobj, -1);
+    if (h->hs_stream) stream_release(h->cfg.device_id, h->hs_stream, drained);
+    if (drained) { g_host_pool.release(h->hs_chain, -1); g_host_pool.release(h->hs_logobj, -1); }
+    else { g_host_pool.discard(h->hs_chain); g_host_pool.discard(h->hs_logobj); }
     void* bufs[] = {h->dZ, h->dX, h->dlp, h->dchain, h->hist_joint ? nullptr : h->dlogobj, h->dlp_origin, h->dtemp, h->d_block_offsets,
                     h->d_slot_of, h->d_slot_role, h->d_eps, h->d_mu, h->d_Wp, h->d_design, h->d_y, h->d_scratch, h->dXprop,
                     h->dlogu, h->d_gather};
@@ -806,7 +842,9 @@ extern "C" int32_t demcz_destroy(demcz_handle* h)
     (void)hipSetDevice(h->cfg.device_id);
     // (side streams: a producer kernel for a launch that never came, monitoring checks, a batched exchange.  A sharded handle
     //  waits with its deadline here too -- a peer may have died -- and a dead one has already been given its time to drain)
-    for (hipStream_t st : {h->stream, h->prod_stream, h->diag_stream, h->comm_stream})
+    // (the copy stream too: a handle destroyed on an error path, or without demcz_get_history_view, may still have D2H copies
+    //  of its history in flight into mirrors that are about to go back to the pool)
+    for (hipStream_t st : {h->stream, h->prod_stream, h->diag_stream, h->comm_stream, h->hs_stream})
         if (st && !h->comm_dead) (void)sync_stream(h, st, "demcz_destroy");
     live_release(h);
     free_all(h);
@@ -1410,6 +1448,11 @@ static bool try_launch_ml(const demcz_handle* h, const WindowParams& P)
 
 static int32_t launch_window(demcz_handle* h, const WindowParams& P, bool live = false)
 {
+    if (P.consumer_blocks > 0 || h->lanes != DEMCZ_LAYOUT_SPLIT) {      // (not the producer-only launches)
+        h->last_live = live ? 1 : 0;
+        h->last_temper = P.temperature ? 1 : 0;
+        h->last_ps2 = (h->lanes == DEMCZ_LAYOUT_SPLIT && h->split_kind == 4 && !h->lr_spec && ps2_applicable(h, P)) ? 1 : 0;
+    }
     if (h->snap_pending) {
         // the redo snapshot of the state (demcz_run): window_kernel_ps2 writes it as it loads the state -- two 5 us copy launches
         // less in front of every autostop slab -- any other kernel gets the copies
@@ -1860,6 +1903,14 @@ extern "C" int32_t demcz_release_host_buffer(void* base)
     return DEMCZ_OK;
 }
 
+extern "C" int32_t demcz_pool_trim(int64_t* device_bytes, int64_t* pinned_bytes)
+{
+    const size_t a = g_dev_pool.trim(), b = g_host_pool.trim();
+    if (device_bytes) *device_bytes = (int64_t)a;
+    if (pinned_bytes) *pinned_bytes = (int64_t)b;
+    return DEMCZ_OK;
+}
+
 extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, double gamma, const double* temperature)
 {
     if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
@@ -1959,6 +2010,10 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
                 const int d = h->cfg.d;
                 if (!h->d_safe_X) HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->d_safe_X, (size_t)N * d * sizeof(double)));
                 if (!h->d_safe_lp) HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->d_safe_lp, (size_t)N * sizeof(double)));
+                if (h->live_fault_polls < 0) {   // fault injection: whatever the snapshot buffers held must never reach the state
+                    HIPCHK(h, hipMemsetAsync(h->d_safe_X, 0xff, (size_t)N * d * sizeof(double), h->stream));
+                    HIPCHK(h, hipMemsetAsync(h->d_safe_lp, 0xff, (size_t)N * sizeof(double), h->stream));
+                }
                 h->snap_pending = true;          // (made by the first launch: launch_window)
                 h->safe_M = h->M; h->safe_M_app = h->M_app; h->safe_g_done = h->g_done;
             }
@@ -2056,6 +2111,8 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         P.live_err = h->d_live_err;
         P.live_spin_limit = h->live_spin_limit ? (int32_t)h->live_spin_limit : LIVE_SPIN_LIMIT;
         if (h->live_fault_polls > 0 && g >= h->live_fault_g) P.live_spin_limit = h->live_fault_polls;
+        if (h->live_fault_polls < 0 && live && g >= h->live_fault_g)      // "a wave of this launch has already given up": every wave leaves at once
+            HIPCHK(h, hipMemsetAsync(h->d_live_err, 0x01, sizeof(unsigned int), h->stream));
         P.acc_out = h->d_acc ? h->d_acc + (size_t)h->acc_next * (size_t)h->acc_waves * 2 : nullptr;
         rc = launch_window(h, P, live);
         h->after_launch_ev = nullptr;         // (whatever was recorded before this launch says nothing about it)
@@ -2984,7 +3041,7 @@ extern "C" int32_t demcz_set_live_spin_limit(demcz_handle* h, int32_t polls)
 
 extern "C" int32_t demcz_debug_set_live_fault(demcz_handle* h, int32_t polls, int64_t g_from)
 {
-    if (!h || polls < 0 || g_from < 0) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (!h || polls < -1 || g_from < 0) return DEMCZ_ERR_INVALID_ARGUMENT;
     h->live_fault_polls = polls;
     h->live_fault_g = g_from;
     return DEMCZ_OK;
@@ -2997,6 +3054,35 @@ extern "C" int32_t demcz_debug_kernel_counts(const demcz_handle* h, int64_t* cou
     counts[0] = h->kernel_counts[0];
     counts[1] = wave ? h->launches - h->kernel_counts[0] : 0;
     counts[2] = wave ? 0 : h->launches;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_debug_kernel_name(const demcz_handle* h, char* buf, int32_t cap)
+{
+    if (!h || !buf || cap < 1) return DEMCZ_ERR_INVALID_ARGUMENT;
+    const int d = h->cfg.d;
+    const char* tg = h->cfg.target_kind == DEMCZ_TARGET_MVNORMAL ? "MVNORMAL" : h->cfg.target_kind == DEMCZ_TARGET_ISO_QUAD ? "ISO_QUAD"
+                     : h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE ? "LINREG_SSE" : "HOST";
+    const char* lv = h->last_live ? "true" : "false";
+    const char* tm = h->last_temper ? "true" : "false";
+    char tmp[160];
+    const bool lr = h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE;
+    if (h->lanes == DEMCZ_LAYOUT_SPLIT) {
+        if (h->lr_spec) snprintf(tmp, sizeof tmp, "window_kernel_lr8s<%d, %s>", d, lv);
+        else if (h->split_kind == 4 && d <= 5) snprintf(tmp, sizeof tmp, "%s<%s, %d, %s, %s>", h->last_ps2 ? "window_kernel_ps2" : "window_kernel_ps", tg, d, lv, tm);
+        else if (h->split_kind == 4) snprintf(tmp, sizeof tmp, "window_kernel_pw<%s, %d, %s, %s>", tg, d, lv, tm);
+        else if (h->split_kind == 3) snprintf(tmp, sizeof tmp, "window_kernel_mlb<%s, %d, %d, true, %s>", tg, d, h->split_lanes, lv);
+        else if (h->split_kind == 2 && lr) snprintf(tmp, sizeof tmp, "window_kernel_lr16<%d, true, %s>", d, lv);
+        else if (h->split_kind == 2) snprintf(tmp, sizeof tmp, "window_kernel_ml<%s, %d, 16, true, %s>", tg, d, lv);
+        else snprintf(tmp, sizeof tmp, "window_kernel_pc8<%s, %d, %s, %s>", tg, d, lv, tm);
+    } else if (h->lanes > 1) {
+        if (!h->full_block) snprintf(tmp, sizeof tmp, "window_kernel_mlb<%s, %d, %d>", tg, d, h->lanes);
+        else if (lr) snprintf(tmp, sizeof tmp, "window_kernel_lr16<%d, false, false>", d);
+        else snprintf(tmp, sizeof tmp, "window_kernel_ml<%s, %d, %d>", tg, d, h->lanes);
+    } else {
+        snprintf(tmp, sizeof tmp, "window_kernel<%s, %d, %s>", tg, d, h->full_block ? "true" : "false");
+    }
+    snprintf(buf, (size_t)cap, "demcz::%s", tmp);
     return DEMCZ_OK;
 }
 

@@ -47,14 +47,21 @@ constexpr int PS2_SLOTS = PS2_AHEAD + 1;     // raw slots: the one being consume
 static_assert(PS2_AHEAD >= 2 && PS2_AHEAD <= 4, "the pass loop is unrolled by the slots");
 // record rows are read up to R * (2 AHEAD + 1) + 1 generations past the launch's last one (never consumed): REC_PAD covers it
 
-// one 16-byte piece per lane from (scalar base + per-lane 32-bit offset) into LDS at m0 + 16 * lane
+// one 16-byte piece per lane from (scalar base + per-lane 32-bit offset) into LDS at lds_dst + 16 * lane (lds_dst: wave-uniform).
+// M0 -- the LDS base of the transfer -- is an INPUT of the asm, bound to the physical register ("{m0}"): the compiler itself
+// moves lds_dst there and knows what M0 holds.  (Until round 4 the asm wrote M0 in its own text and listed it as a clobber,
+// which the compiler does not promise to honour for a reserved register: 112 warnings, and a latent miscompile.  The compiler's
+// builtin, __builtin_amdgcn_global_load_lds, selects the same instruction but models the transfer as a write to ALL of LDS: it
+// puts s_waitcnt vmcnt(0) in front of every later LDS access that might alias -- the publisher hand-off words of each boundary
+// pass -- which drains the very DMA queue the pass structure keeps two passes deep.)  s_nop: one wait state between an SALU
+// write of M0 and an LDS-DMA instruction that reads it (the hazard recogniser does not look inside asm text).
 __device__ __forceinline__ void ps2_dma16(const void* sbase, unsigned voff, unsigned lds_dst)
 {
 #ifndef PS2_DMA_POLICY
 #define PS2_DMA_POLICY ""
 #endif
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" PS2_DMA_POLICY
-                 :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+    asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" PS2_DMA_POLICY
+                 :: "v"(voff), "s"(sbase), "{m0}"(lds_dst) : "memory");
 }
 
 template <int TARGET, int D, bool LIVE, bool TEMPER>
@@ -141,7 +148,17 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         return;
     }
     if constexpr (LIVE) {
-        if (__hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { leave(); return; }
+        if (__hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            // Another wave has already given up.  This chain's row of the redo snapshot is still owed (the host made no copy
+            // in front of this launch: launch_window): Xcur / lpcur of chain c are only ever written by this wave, at the
+            // launch's end, so they still hold the state the launch started from.
+            if (P.safe_X) {
+                if (lane < D) P.safe_X[c + P.N * lane] = P.Xcur[c + P.N * lane];
+                if (lane == 0) P.safe_lp[c] = P.lpcur[c];
+            }
+            leave();
+            return;
+        }
     }
     __builtin_amdgcn_s_setprio(3);
     unsigned char* const raw_w = &raw[w][0][0];

@@ -206,6 +206,12 @@ class HipEngine:
         self._chk(self._L.demcz_debug_kernel_counts(self._h, c))
         return dict(zip(("ps2", "ps_general", "other"), (int(v) for v in c)))
 
+    def kernel_name(self):
+        """Diagnostic: the window kernel the most recent window launch ran, as a profiler names it."""
+        buf = C.create_string_buffer(192)
+        self._chk(self._L.demcz_debug_kernel_name(self._h, buf, 192))
+        return buf.value.decode()
+
     def synchronize(self):
         self._chk(self._L.demcz_synchronize(self._h))
 
@@ -342,6 +348,14 @@ class HipEngine:
 
     def append_rows_device(self, device_ptr: int, nrows: int, ldrows: int):
         self._chk(self._L.demcz_append_rows_device(self._h, C.c_void_p(device_ptr), int(nrows), int(ldrows)))
+
+
+def pool_trim():
+    """Give the buffers the library keeps for the next handle back to the runtime: (device bytes, pinned bytes) freed."""
+    L = _lib.load()
+    a, b = C.c_int64(0), C.c_int64(0)
+    L.demcz_pool_trim(C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
 
 
 def selftest_draws(seed, chain, blk0, n, device_id=0):

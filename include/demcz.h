@@ -160,6 +160,11 @@ int32_t demcz_get_history_view(demcz_handle* h, int64_t g_from, int64_t g_to, do
 int32_t demcz_detach_history(demcz_handle* h, void** chain_base, void** logobj_base);
 int32_t demcz_release_host_buffer(void* base);
 
+/* The library keeps the big buffers of destroyed handles (device: history + archive, at most 6 GiB; pinned host: history mirrors,
+ * at most 3 GiB) for the next handle of the process.  demcz_pool_trim gives everything cached back to the runtime (it is also
+ * what the library does by itself when one of its own allocations fails); either pointer may be NULL. */
+int32_t demcz_pool_trim(int64_t* device_bytes_freed, int64_t* pinned_bytes_freed);
+
 /* changed[g - g_from] = number of local chains whose log_obj at generation g differs from the
  * one before it -- the event counted by sum(diff(log_obj, dims=2) .!= 0) at demcz.jl:42 and
  * demcz_anneal.jl:50. */
@@ -310,10 +315,15 @@ int32_t demcz_get_live_status(const demcz_handle* h, int32_t* live_enabled, int3
  * launches of the wave-per-chain layout), [1] that layout's general kernels (window_kernel_ps / _pw), [2] launches of every
  * other layout.  Tests use it to know which kernel a parity case exercised. */
 int32_t demcz_debug_kernel_counts(const demcz_handle* h, int64_t* counts);
+/* Diagnostic: the name (template arguments included, as a profiler prints it) of the window kernel the handle's most recent
+ * window launch ran, NUL-terminated into buf[cap].  bench.py labels its roofline objects with it. */
+int32_t demcz_debug_kernel_name(const demcz_handle* h, char* buf, int32_t cap);
 
 /* Fault injection for the LIVE hand-off: LIVE launches whose first generation is >= g_from use the poll limit `polls` instead
  * of the handle's (demcz_set_live_spin_limit), so that a test can make a hand-off fail LATE in a long call (e.g. in slab 280 of
- * a 300-slab demcz_run_checked).  polls = 0 switches it off. */
+ * a 300-slab demcz_run_checked).  polls = 0 switches it off.  polls = -1: such a launch finds the error word already set -- as if
+ * a wave had timed out before the others became resident (another process on the GPU) -- so every wave leaves at once; the redo
+ * snapshot buffers are filled with NaN patterns beforehand, so a wave that left without writing its row of the snapshot shows. */
 int32_t demcz_debug_set_live_fault(demcz_handle* h, int32_t polls, int64_t g_from);
 
 /* Fault injection for the exchange: the next collective of this (sharded) handle is held back on its stream for `milliseconds`

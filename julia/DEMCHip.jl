@@ -119,7 +119,8 @@ function history(h, N, d, g_from, g_to)
 end
 # Streamed history (demcz_history_stream): the library copies every slab to pinned host mirrors while the next slab computes;
 # take_history wraps the mirrors as Julia arrays WITHOUT copying (unsafe_wrap), detaches them from the handle and hands them back
-# to the library's pool when the arrays are garbage-collected (the finalizer sits on `chain`; `log_obj` keeps `chain` alive).
+# to the library's pool when the arrays are garbage-collected: each array has a finalizer of its own that releases ITS mirror only,
+# so a caller may keep `mc.log_obj` and drop `mc.chain` (or the other way round) without either reading freed memory.
 history_stream(h, on=true) = chk(ccall((:demcz_history_stream, libdemcz), Int32, (Ptr{Cvoid}, Int32), h, on ? 1 : 0), h)
 function take_history(h, N, d, g_from, g_to)
     G = g_to - g_from + 1
@@ -129,13 +130,19 @@ function take_history(h, N, d, g_from, g_to)
     chk(ccall((:demcz_detach_history, libdemcz), Int32, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ref{Ptr{Cvoid}}), h, bc, bl), h)
     chain = unsafe_wrap(Array, pc[], (N, d, G); own=false)
     log_obj = unsafe_wrap(Array, pl[], (N, G); own=false)
-    bases = (bc[], bl[])
-    finalizer(chain) do _
-        for b in bases
-            ccall((:demcz_release_host_buffer, libdemcz), Int32, (Ptr{Cvoid},), b)
-        end
+    let b = bc[]
+        finalizer(_ -> ccall((:demcz_release_host_buffer, libdemcz), Int32, (Ptr{Cvoid},), b), chain)
     end
-    chain, log_obj            # keep `chain` referenced for as long as `log_obj` is used (MC holds both)
+    let b = bl[]
+        finalizer(_ -> ccall((:demcz_release_host_buffer, libdemcz), Int32, (Ptr{Cvoid},), b), log_obj)
+    end
+    chain, log_obj
+end
+# gives the buffers the library keeps for the next handle back to the runtime (device bytes, pinned bytes)
+function pool_trim()
+    a = Ref{Int64}(0); b = Ref{Int64}(0)
+    ccall((:demcz_pool_trim, libdemcz), Int32, (Ref{Int64}, Ref{Int64}), a, b)
+    a[], b[]
 end
 function state(h, N, d)
     M = Ref{Int64}(0); X = Matrix{Float64}(undef, N, d); lp = Vector{Float64}(undef, N)

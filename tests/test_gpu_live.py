@@ -271,3 +271,31 @@ def test_regular_launches_take_the_steady_state_kernel(demc):
     c2 = e.kernel_counts()
     e.close()
     assert c2["ps2"] == 2 and c2["ps_general"] >= 2, c2
+
+
+@pytest.mark.parametrize("K,first", [(5, 1), (10, 201)])
+def test_wave_that_finds_the_launch_already_failed_still_writes_its_snapshot_row(demc, oracle, K, first):
+    """window_kernel_ps2 writes the redo snapshot of the state itself (no copy launches in front of a slab).  A chain wave that
+    becomes resident after another wave has already timed out leaves at once -- and must have written its chain's row of the
+    snapshot before it does, or the rollback restores garbage.  Fault injection (demcz_debug_set_live_fault, polls = -1): the
+    snapshot buffers are filled with NaN patterns, and the LIVE launch that starts at generation `first` finds the error word
+    set, so EVERY wave takes the early exit.  The redo must then start from the exact state."""
+    N, d, G, seed = 512, 5, 400, 47
+    w = demc.workloads.mvnormal_problem(d, N)
+    e = _engine(demc, w, N, d, K, G, seed, SPLIT_WAVE)
+    if first > 1:
+        e.run(1, first - 1, w["gamma"])
+        e.synchronize()                            # verified: the snapshot of the next call is taken at generation `first`
+    e.debug_set_live_fault(-1, first)
+    e.run(first, G, w["gamma"])
+    assert e.kernel_counts()["ps2"] >= 1, "the faulted launch must be the steady-state kernel's"
+    e.synchronize()
+    on, redos = e.live_status()
+    assert redos == 1 and not on
+    chain, lobj = e.get_history(1, G)
+    X, lp, Z, M = e.get_state()
+    e.close()
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed)
+    assert np.isfinite(X).all() and np.isfinite(lp).all()
+    assert np.array_equal(chain, ref["chain"]) and np.array_equal(lobj, ref["log_obj"])
+    assert np.array_equal(X, ref["X"]) and np.array_equal(lp, ref["logp"]) and M == ref["M"] and np.array_equal(Z, ref["Z"])

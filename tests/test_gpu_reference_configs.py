@@ -136,3 +136,21 @@ def test_test_anneal_script(compat_serial_temp):
     assert bestval > -1e-1, bestval                                            # (as meant)
     assert np.isclose(-np.sum((bestpar - w["mu"]) ** 2), bestval, rtol=1e-12, atol=1e-300)
     assert mc.chain.shape == (N, ndim, Ngen) and Zo.shape[0] == Z.shape[0] + N * (Ngen // K)
+
+
+def test_c1_shape_on_the_hip_path_equals_oracle(demc, oracle):
+    """BASELINE config C1 (test/example_normpdf.jl:20-30 plumbing: MvNormal d = 5, N = 4 chains, 10 000 generations; BASELINE.md
+    runs it on the CPU -- bench.py's cpu_baseline.c1 row) at the same shape on the HIP path, chains started at the zero vector
+    like the reference's serial driver does (demcz.jl:11, 15), against the oracle bit for bit -- all 40 000 updates,
+    the 4000 appended rows, and the acceptance band the reference's own test asserts (example_normpdf.jl:50-51)."""
+    from helpers import oracle_sample
+    d, N, K, G, seed = 5, 4, 10, 10000, 31953150
+    w = demc.workloads.mvnormal_problem(d, N)
+    mc, Z = demc.demcz_sample(w["target"], w["Zinit"], N, K, G, 1, [range(d)], w["eps_scale"], w["gamma"], verbose=False,
+                              seed=seed, init="reference_zeros")
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed, init="reference_zeros")
+    assert np.array_equal(mc.chain, ref["chain"]) and np.array_equal(mc.log_obj, ref["log_obj"])
+    assert np.array_equal(mc.Xcurrent, ref["X"]) and np.array_equal(mc.log_objcurrent, ref["logp"])
+    assert Z.shape[0] == ref["M"] == w["Zinit"].shape[0] + N * (G // K) and np.array_equal(Z, ref["Z"])
+    acc = demc.accept_ratio(mc.log_obj[:, -2500:])
+    assert np.all(acc > 0.1) and np.all(acc < 0.45), acc
