@@ -464,6 +464,7 @@ def main():
         return
     stream = torch.cuda.Stream()
     selfcheck = None
+    exchange_note = None
     if world > 1:
         def all_min(v):
             t = torch.tensor([v], dtype=torch.int64, device="cuda")
@@ -477,6 +478,15 @@ def main():
                 sys.stderr.flush()
                 os._exit(3)
             raise
+        exchange_note = None
+        if not all(selfcheck.values()) and not os.environ.get("DEMCZ_NO_PEER"):
+            # The in-launch hand-off between the GPUs (every rank's publisher waves store boundary rows into every replica over
+            # IPC-opened pointers, demcz_comm_init) has never met real peers before this line runs: if the sharded run does not
+            # reproduce the unsharded one WITH it, it is switched off -- the rows then travel through ncclAllGather per K-window,
+            # the schedule of rounds 1-3 -- and the check is made again.  (The verdict is the MIN over ranks: every rank is here.)
+            exchange_note = f"peer hand-off failed the sharded self-check ({selfcheck}); fell back to the ncclAllGather exchange"
+            os.environ["DEMCZ_NO_PEER"] = "1"
+            selfcheck = sharded_selfcheck(demc, sharding, rank, local_rank, stream.cuda_stream, all_min)
         if not all(selfcheck.values()):
             # a sharded run that does not reproduce the unsharded one is not a measurement of anything: say so and stop
             if rank == 0:
@@ -512,9 +522,10 @@ def main():
                 if res["gens_to_rhat"] is None and mx < thr:
                     res["gens_to_rhat"] = gchk
 
-        def fence():
-            runner.synchronize()
-            torch.cuda.synchronize()
+        def fence(drain_library=True):
+            if drain_library:
+                runner.synchronize()
+            torch.cuda.synchronize()          # (the whole device: the library's streams included)
             if dist is not None:
                 dist.barrier()
                 torch.cuda.synchronize()
@@ -526,7 +537,7 @@ def main():
         # the host, and the fence.  Reading the events out, bookkeeping in Python: after it.
         t0 = time.perf_counter()
         trace = advance(W * every + 1, G, True)
-        fence()
+        fence(drain_library=False)            # (demcz_run_checked returned with the last slab's statistic on the host)
         dt = time.perf_counter() - t0
         note(trace, W * every + 1)
         launches, ev_ms = eng.get_kernel_time()
@@ -546,6 +557,7 @@ def main():
                    acc=runner.accept_ratio_mean(G - every + 1, G))          # (a cheap end-of-run sanity check, not timed)
         res["live_on"], res["live_redos"] = eng.live_status()
         res["lanes"] = eng.info()["lanes_per_chain"]
+        res["peer"] = eng.peer_status()
         res["kernel"] = eng.kernel_name()
         res["kernel_counts"] = eng.kernel_counts()
         runner.close()        # (frees the device's LIVE slot for the next measurement / the sweep's handles)
@@ -602,6 +614,11 @@ def main():
                        "chains_total": N, "dim": d, "K": K, "generations_per_step": every, "generations_timed": gens,
                        "lanes_per_chain": lanes, "append_lag": lag_value, "append_lag_probe_us": lag_probe,
                        "live_launches": live_on, "live_redos": live_redos, "sharded_selfcheck": selfcheck,
+                       "exchange": (None if world == 1 else
+                                    "in-launch hand-off: every rank's publisher waves store a boundary's rows into every replica over IPC-opened "
+                                    f"pointers ({m['peer'][1]} peers); no collective per K-window" if m["peer"][0] == 2 and live_on else
+                                    "ncclAllGather + scatter per K-window" + (" (the in-launch hand-off timed out and the run was redone)" if m["peer"][0] == 2 else "")),
+                       "exchange_note": exchange_note,
                        "parallelism": f"chains sharded x{world}, Z replicated" if world > 1 else "single GPU"},
             "gens_to_rhat_1p05": gens_to_rhat, "rhat_trace": rhat_trace[-12:], "accept_ratio_mean": acc,
             "value_window_kernels_only": N * gens / (ev_ms / 1e3) if ev_ms > 0 else None,

@@ -141,6 +141,16 @@ static hipError_t dev_free(int device, void* p) { g_dev_pool.release(p, device);
 static hipError_t host_malloc(void** out, size_t bytes) { return g_host_pool.acquire(out, std::max<size_t>(bytes, 16), -1); }
 static hipError_t host_free(void* p) { g_host_pool.release(p, -1); return hipSuccess; }
 
+struct demcz_handle;
+// A replica group of one process (demcz_peer_group): R handles on one device, each with its own archive replica and shard of
+// the chains, publishing boundary rows into each other's replicas from inside their launches.  One host thread drives them all.
+struct PeerGroup {
+    std::vector<demcz_handle*> members;
+    bool failed = false;       // a hand-off timed out once: calls are logged and executed in lockstep at the next verification
+    bool busy = false;         // inside group_verify / group_execute
+    bool dead = false;         // a member was destroyed: the others only accept demcz_destroy
+};
+
 struct demcz_handle {
     demcz_config cfg{};
     int lanes = 1;
@@ -153,6 +163,9 @@ struct demcz_handle {
     int64_t S = 0;            // Philox blocks per generation
     int64_t ZS = 0;           // archive row stride in doubles (row-major on the device)
     bool full_block = false;
+    int ngrp = 1;             // MvNormal: groups the sums of the quadratic form are cut into (TargetParams::ngrp; 1 = not grouped)
+    uint64_t gstart = 1ull;   // bit j: parameter j starts a group
+    int mlb_qb = 0;           // > 0: the groups are equal blocks of this many parameters and the block kernel's incremental form is built for them
     // device buffers
     double* dZ = nullptr;
     double* dX = nullptr;
@@ -296,6 +309,21 @@ struct demcz_handle {
     // what a host-paced wait polls (hipEventQuery of an event recorded behind a stream-wait was seen to report "complete" while
     // the work in front of it had not run -- tests/test_gpu_comm_failure.py, lag 2 -- so the host does not ask the runtime)
     volatile long long* xdone = nullptr;
+    // Replicated archives with the rows handed over inside the launches (demcz_kernels_rec.h, live_publish): 0 = off; 1 = a
+    // replica group of handles of THIS process on one device (demcz_peer_group: rehearsal of the schedule on a one-GPU box);
+    // 2 = the ranks of the RCCL communicator, every rank's archive opened over IPC by all others (demcz_comm_init)
+    int peer_mode = 0;
+    int n_peers = 0;
+    double* peer_Z[DEMCZ_MAX_PEERS] = {nullptr};
+    void* ipc_mapped[DEMCZ_MAX_PEERS] = {nullptr};   // mode 2: what hipIpcOpenMemHandle returned (closed at destroy)
+    struct PeerGroup* group = nullptr;               // mode 1
+    bool err_clean = false;            // the LIVE error word was read as zero and no LIVE launch has been enqueued since
+    bool peer_fence = false;           // mode 2: the ranks must meet before the next launch that publishes into peers (this
+                                       // replica's unwritten rows were just re-filled with the sentinel: set_state, rollback)
+    unsigned int* d_err_all = nullptr; // mode 2: [0] max over ranks of the LIVE error word, [1] barrier scratch
+    bool archive_fine = false;         // dZ is a fine-grained allocation of its own (hipExtMallocWithFlags), not the pool's
+    size_t dZ_bytes = 0;
+    int64_t live_share = 0;            // per-mille of the device's LIVE capacity this handle holds (live_claim)
     int64_t comm_timeout_ms = 60000;
     bool comm_dead = false;
     int* stall_flag = nullptr;         // device word; demcz_debug_stall_exchange: the stall kernel spins until it is set
@@ -344,6 +372,14 @@ namespace demcz {
 __global__ void mark_kernel(volatile long long* word, long long value)
 {
     __hip_atomic_store(const_cast<long long*>(word), value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Are the kernels of R streams able to run at the same time?  Each adds one to a counter and waits (bounded) until all R have.
+__global__ void rendezvous_kernel(unsigned int* ctr, unsigned int R, unsigned int* met, unsigned long long max_ticks)
+{
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = wall_clock64();           // 100 MHz
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < R && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(16);
+    if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= R) __hip_atomic_fetch_add(met, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __global__ void stall_kernel(int* release, unsigned long long max_ticks)
 {
@@ -485,8 +521,13 @@ static void rec_invalidate(demcz_handle* h)
     h->rec_desc[0].valid = h->rec_desc[1].valid = false;
 }
 static int32_t flush_exchanges(demcz_handle* h);
+static void peer_detach(demcz_handle* h);
+static int32_t peer_setup_ipc(demcz_handle* h);
+static bool peer_capable(const demcz_handle* h);
 static int32_t check_live_err(demcz_handle* h);
 static int32_t live_verify(demcz_handle* h);
+static int32_t group_verify(demcz_handle* h);
+static int32_t live_failed(demcz_handle* h, bool& failed);
 static void live_release(demcz_handle* h);
 static int64_t live_span(demcz_handle* h);
 static int32_t rec_reserve(demcz_handle* h, int64_t gens);
@@ -518,14 +559,16 @@ static void free_all(demcz_handle* h)
     for (hipStream_t st : {h->stream, h->prod_stream, h->diag_stream, h->comm_stream, h->hs_stream})
         if (st && hipStreamQuery(st) != hipSuccess) drained = false;
     if (h->d_acc) (void)dev_free(h->cfg.device_id, h->d_acc);
+    if (h->d_err_all) (void)dev_free(h->cfg.device_id, h->d_err_all);
+    if (h->archive_fine) { if (h->dZ) (void)hipFree(h->dZ); h->dZ = nullptr; }     // (an allocation of its own: demcz_comm_init)
     if (h->pooled_dev) {               // (the two big ones)
-        if (drained) {
+        if (h->archive_fine) {
+        } else if (drained) {
             g_dev_pool.release(h->dZ, h->cfg.device_id);
-            if (h->hist_joint) g_dev_pool.release(h->dchain, h->cfg.device_id);
         } else {
             g_dev_pool.discard(h->dZ);
-            if (h->hist_joint) g_dev_pool.discard(h->dchain);
         }
+        if (h->hist_joint) { if (drained) g_dev_pool.release(h->dchain, h->cfg.device_id); else g_dev_pool.discard(h->dchain); }
         h->dZ = nullptr;
         if (h->hist_joint) h->dchain = nullptr;
     }
@@ -652,6 +695,29 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
     h->full_block = (cfg->Nblocks == 1 && h->block_offsets[1] == d);
     if (h->full_block)
         for (int p = 0; p < d; ++p) h->full_block = h->full_block && (h->block_indices[p] == p);
+    if (cfg->target_kind == DEMCZ_TARGET_MVNORMAL && cfg->Nblocks >= 2 && h->block_offsets.back() == d) {
+        // the blocks, in order, are consecutive index ranges covering 0..d-1 (any order of the indices inside a block): the sums
+        // of the quadratic form are cut at their boundaries (the grouped order)
+        bool ok = true;
+        uint64_t starts = 0;
+        for (int ib = 0; ib < cfg->Nblocks && ok; ++ib) {
+            const int lo = h->block_offsets[ib], hi = h->block_offsets[ib + 1];
+            uint64_t seen = 0;
+            for (int t = lo; t < hi; ++t) {
+                const int j = h->block_indices[t];
+                if (j < lo || j >= hi || ((seen >> (j - lo)) & 1ull)) { ok = false; break; }
+                seen |= 1ull << (j - lo);
+            }
+            starts |= 1ull << lo;
+        }
+        if (ok) {
+            h->ngrp = cfg->Nblocks;
+            h->gstart = starts;
+            bool equal = true;
+            for (int ib = 0; ib < cfg->Nblocks; ++ib) equal = equal && (h->block_offsets[ib + 1] - h->block_offsets[ib] == h->block_offsets[1]);
+            if (equal && d == 20 && h->block_offsets[1] == 5 && !getenv("DEMCZ_NO_MLB_INCREMENTAL")) h->mlb_qb = 5;      // C3: 4 x 5
+        }
+    }
     {   // layout: L lanes per chain when the chip would otherwise sit idle (small N), else one lane
         int maxb = 0;
         for (int ib = 0; ib < cfg->Nblocks; ++ib) maxb = std::max(maxb, h->block_offsets[ib + 1] - h->block_offsets[ib]);
@@ -754,6 +820,7 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
                 h->arena = true;
                 h->arena_gens = ag;
                 CRCHK(g_dev_pool.acquire((void**)&h->dZ, zb + 2 * rb + tb, cfg->device_id));
+                h->dZ_bytes = zb + 2 * rb + tb;
                 unsigned char* base = reinterpret_cast<unsigned char*>(h->dZ);
                 h->arena_rec[0] = reinterpret_cast<double*>(base + zb);
                 h->arena_rec[1] = reinterpret_cast<double*>(base + zb + rb);
@@ -761,7 +828,7 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
                 CRCHK(hipMemsetAsync(base + zb, 0, 2 * rb + tb, h->stream));       // row 0 / temperature 0: always legal
             }
         }
-        if (!h->arena) CRCHK(g_dev_pool.acquire((void**)&h->dZ, zbytes, cfg->device_id));
+        if (!h->arena) { CRCHK(g_dev_pool.acquire((void**)&h->dZ, zbytes, cfg->device_id)); h->dZ_bytes = zbytes; }
         h->pooled_dev = true;
     }
     // (the reference pads with zeros, demcz.jl:11; rows at or beyond M never leave the device, and here they hold
@@ -836,6 +903,39 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
     return DEMCZ_OK;
 }
 
+// Other replicas publish into this handle's archive from inside their launches: it may only be freed once none of them can
+// still be running.  Replica group of this process: every member's streams are drained here and the group is marked dead (its
+// other members then only accept demcz_destroy).  Ranks of a communicator: they meet in a reduction behind their launches
+// (unless the communicator is dead -- then the archive is NOT freed: a surviving peer's publisher may still be writing it, the
+// process is to be restarted anyway), and the IPC mappings of the peers' archives are closed.
+static void peer_detach(demcz_handle* h)
+{
+    if (h->peer_mode == 1 && h->group) {
+        PeerGroup* G = h->group;
+        if (!G->dead) (void)group_verify(h);          // (what the members have enqueued is completed -- redone if need be -- first)
+        for (demcz_handle* m : G->members) {
+            if (m->stream) (void)hipStreamSynchronize(m->stream);
+            if (m->prod_stream) (void)hipStreamSynchronize(m->prod_stream);
+        }
+        G->dead = true;
+        G->members.erase(std::remove(G->members.begin(), G->members.end(), h), G->members.end());
+        for (demcz_handle* m : G->members) { m->n_peers = 0; }
+        if (G->members.empty()) delete G;
+        h->group = nullptr;
+    } else if (h->peer_mode == 2) {
+        bool met = false;
+        if (!h->comm_dead && h->comm && h->d_err_all) {
+            if (ncclAllReduce(h->d_err_all + 1, h->d_err_all + 1, 1, ncclUint32, ncclMax, h->comm, h->stream) == ncclSuccess)
+                met = sync_stream(h, h->stream, "demcz_destroy (peers)") == DEMCZ_OK;
+        }
+        for (int r = 0; r < DEMCZ_MAX_PEERS; ++r)
+            if (h->ipc_mapped[r]) { (void)hipIpcCloseMemHandle(h->ipc_mapped[r]); h->ipc_mapped[r] = nullptr; }
+        if (!met && h->archive_fine) h->dZ = nullptr;       // leaked on purpose (see above)
+    }
+    h->n_peers = 0;
+    h->peer_mode = 0;
+}
+
 extern "C" int32_t demcz_destroy(demcz_handle* h)
 {
     if (!h) return DEMCZ_OK;
@@ -846,6 +946,7 @@ extern "C" int32_t demcz_destroy(demcz_handle* h)
     //  of its history in flight into mirrors that are about to go back to the pool)
     for (hipStream_t st : {h->stream, h->prod_stream, h->diag_stream, h->comm_stream, h->hs_stream})
         if (st && !h->comm_dead) (void)sync_stream(h, st, "demcz_destroy");
+    peer_detach(h);
     live_release(h);
     free_all(h);
     delete h;
@@ -857,6 +958,7 @@ static TargetParams target_params(const demcz_handle* h)
     TargetParams tp;
     tp.mu = h->d_mu; tp.Wp = h->d_Wp; tp.c0 = h->cfg.c0;
     tp.design = h->d_design; tp.yobs = h->d_y; tp.nobs = h->cfg.nobs;
+    tp.ngrp = h->ngrp; tp.goff = h->d_block_offsets; tp.gstart = h->gstart;
     return tp;
 }
 
@@ -933,6 +1035,7 @@ extern "C" int32_t demcz_set_state(demcz_handle* h, const double* X, const doubl
     SYNCCHK(h, h->stream);
     h->M = M0;
     h->M_app = M0;
+    h->peer_fence = true;
     h->live_log.clear();
     h->snap_pending = false;
     h->acc_log.clear();
@@ -1198,7 +1301,12 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
             // needed at once): on the main stream.
             hipStream_t ps = h->stream;
             static const bool serial_env = getenv("DEMCZ_PRODUCE_SERIAL") != nullptr;     // diagnosis: producer in front of its consumer's successor, on the main stream
-            if (P.consumer_blocks > 0 && !serial_env) {
+            // (members of a replica group of one process keep to ONE stream each: HIP multiplexes streams over a few hardware
+            //  queues, demcz_peer_group has made sure the members' main streams can run at the same time, and a side stream of
+            //  one member that shares a hardware queue with another member's main stream was seen to stall the group until the
+            //  poll limit -- tests/test_gpu_peer.py after a session that had pooled 30 streams.  Ranks on GPUs of their own
+            //  have no such neighbours.)
+            if (P.consumer_blocks > 0 && !serial_env && h->peer_mode != 1) {
                 if (!h->prod_stream) {
                     HIPCHK(h, stream_acquire(h->cfg.device_id, &h->prod_stream));
                     HIPCHK(h, hipEventCreateWithFlags(&h->prod_gate, hipEventDisableTiming));
@@ -1276,14 +1384,25 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
         const dim3 grid((unsigned)blocks), wg(64 * h->wpw);
 #define DEMCZ_LAUNCH_MLB_REC(DD, LL)                                                                                         \
         do {                                                                                                                 \
-            if (live) hipLaunchKernelGGL((window_kernel_mlb<TARGET_MVNORMAL, DD, LL, true, true>), grid, wg, 0, h->stream, P);   \
+            if (h->ngrp > 1) {      /* sums cut at the block boundaries (full evaluation: the group-start mask) */              \
+                if (live) hipLaunchKernelGGL((window_kernel_mlb<TARGET_MVNORMAL, DD, LL, true, true, 0, true>), grid, wg, 0, h->stream, P);   \
+                else hipLaunchKernelGGL((window_kernel_mlb<TARGET_MVNORMAL, DD, LL, true, false, 0, true>), grid, wg, 0, h->stream, P);       \
+            }                                                                                                                \
+            else if (live) hipLaunchKernelGGL((window_kernel_mlb<TARGET_MVNORMAL, DD, LL, true, true>), grid, wg, 0, h->stream, P);   \
             else hipLaunchKernelGGL((window_kernel_mlb<TARGET_MVNORMAL, DD, LL, true, false>), grid, wg, 0, h->stream, P);       \
         } while (0)
         switch (P.d) {
         case 5: DEMCZ_LAUNCH_MLB_REC(5, 8); break;
         case 6: DEMCZ_LAUNCH_MLB_REC(6, 8); break;
         case 10: DEMCZ_LAUNCH_MLB_REC(10, 8); break;
-        case 20: if (h->split_lanes == 32) DEMCZ_LAUNCH_MLB_REC(20, 32); else DEMCZ_LAUNCH_MLB_REC(20, 16); break;
+        case 20:
+            if (h->split_lanes == 32) DEMCZ_LAUNCH_MLB_REC(20, 32);
+            else if (h->mlb_qb == 5) {      // four blocks of five: the incremental form
+                if (live) hipLaunchKernelGGL((window_kernel_mlb<TARGET_MVNORMAL, 20, 16, true, true, 5>), grid, wg, 0, h->stream, P);
+                else hipLaunchKernelGGL((window_kernel_mlb<TARGET_MVNORMAL, 20, 16, true, false, 5>), grid, wg, 0, h->stream, P);
+            }
+            else DEMCZ_LAUNCH_MLB_REC(20, 16);
+            break;
         default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
         }
 #undef DEMCZ_LAUNCH_MLB_REC
@@ -1401,7 +1520,8 @@ template <int TARGET, int D, int L>
 static void launch_window_mlb(const demcz_handle* h, const WindowParams& P)
 {
     constexpr int G = 64 / L;
-    hipLaunchKernelGGL((window_kernel_mlb<TARGET, D, L>), dim3((unsigned)((P.N + G - 1) / G)), dim3(64), 0, h->stream, P);
+    if (h->ngrp > 1) hipLaunchKernelGGL((window_kernel_mlb<TARGET, D, L, false, false, 0, true>), dim3((unsigned)((P.N + G - 1) / G)), dim3(64), 0, h->stream, P);
+    else hipLaunchKernelGGL((window_kernel_mlb<TARGET, D, L>), dim3((unsigned)((P.N + G - 1) / G)), dim3(64), 0, h->stream, P);
 }
 
 static bool try_launch_ml(const demcz_handle* h, const WindowParams& P)
@@ -1414,7 +1534,10 @@ static bool try_launch_ml(const demcz_handle* h, const WindowParams& P)
         case 5: launch_window_mlb<TARGET_MVNORMAL, 5, 8>(h, P); return true;
         case 6: launch_window_mlb<TARGET_MVNORMAL, 6, 8>(h, P); return true;
         case 10: launch_window_mlb<TARGET_MVNORMAL, 10, 8>(h, P); return true;
-        case 20: launch_window_mlb<TARGET_MVNORMAL, 20, 16>(h, P); return true;
+        case 20:
+            if (h->mlb_qb == 5) hipLaunchKernelGGL((window_kernel_mlb<TARGET_MVNORMAL, 20, 16, false, false, 5>), dim3((unsigned)((P.N + 3) / 4)), dim3(64), 0, h->stream, P);
+            else launch_window_mlb<TARGET_MVNORMAL, 20, 16>(h, P);
+            return true;
         }
         return false;
     }
@@ -1612,7 +1735,9 @@ static int32_t check_live_err(demcz_handle* h)
 {
     unsigned int e[4] = {0, 0, 0, 0};
     if (!h->d_live_err) return DEMCZ_OK;         // (the scratch handles of the *_array diagnostics run no chains)
+    if (h->err_clean) return DEMCZ_OK;           // (read as zero since the last LIVE launch: a blocking 16-byte copy less per call)
     HIPCHK(h, hipMemcpy(e, h->d_live_err, sizeof(e), hipMemcpyDeviceToHost));
+    if (!e[0]) h->err_clean = true;
     if (e[0])
         return fail(h, DEMCZ_ERR_HIP, "demcz_run: an archive row appended inside the launch never became visible (LIVE hand-off): "
                                       "generation " + std::to_string(e[1]) + " of the launch, row " + std::to_string(e[2]) +
@@ -1645,6 +1770,7 @@ static int32_t live_rollback(demcz_handle* h, std::vector<demcz_handle::RunCall>
     }
     HIPCHK(h, hipMemsetAsync(h->d_live_err, 0, 4 * sizeof(unsigned int), h->stream));
     SYNCCHK(h, h->stream);
+    h->peer_fence = true;
     h->M = h->safe_M;
     h->M_app = h->safe_M_app;
     h->g_done = h->safe_g_done;
@@ -1656,19 +1782,41 @@ static int32_t live_rollback(demcz_handle* h, std::vector<demcz_handle::RunCall>
     return DEMCZ_OK;
 }
 
+// Did a LIVE launch since the last verified point give up waiting for a row?  The stream is drained first.  With the ranks of a
+// communicator publishing into each other's replicas (peer_mode 2) the answer must be the SAME on every rank -- a rank whose own
+// waits all succeeded still has to join the others' redo, which exchanges rows through RCCL -- so the error words are
+// max-reduced over the communicator (every rank makes the same calls in the same order, so every rank is here together).
+static int32_t live_failed(demcz_handle* h, bool& failed)
+{
+    failed = false;
+    SYNCCHK(h, h->stream);
+    unsigned int e[4] = {0, 0, 0, 0};
+    if (h->peer_mode == 2 && !h->no_live && h->comm) {
+        NCCLCHK(h, ncclAllReduce(h->d_live_err, h->d_err_all, 1, ncclUint32, ncclMax, h->comm, h->stream));
+        SYNCCHK(h, h->stream);
+        HIPCHK(h, hipMemcpy(e, h->d_err_all, sizeof(unsigned int), hipMemcpyDeviceToHost));
+    } else {
+        HIPCHK(h, hipMemcpy(e, h->d_live_err, sizeof(e), hipMemcpyDeviceToHost));
+    }
+    failed = e[0] != 0u;
+    if (!failed && h->peer_mode != 2) h->err_clean = true;
+    return DEMCZ_OK;
+}
+
 // Every entry point that hands results to the caller goes through here: the stream is drained, and if a LIVE
 // launch since the last verification gave up waiting for a row, everything since then is redone with one launch
 // per K-window (bit-identical results; the handle stays in that mode).  DEMCZ_OK afterwards means the results are valid.
 static int32_t live_verify(demcz_handle* h)
 {
     DEADCHK(h);
+    if (h->peer_mode == 1) return group_verify(h);
     if (h->live_log.empty() || h->replaying) return check_live_err(h);
-    SYNCCHK(h, h->stream);
-    unsigned int e[4] = {0, 0, 0, 0};
-    HIPCHK(h, hipMemcpy(e, h->d_live_err, sizeof(e), hipMemcpyDeviceToHost));
-    if (!e[0]) { h->live_log.clear(); return DEMCZ_OK; }
+    bool failed = false;
+    int32_t rc = live_failed(h, failed);
+    if (rc) return rc;
+    if (!failed) { h->live_log.clear(); return DEMCZ_OK; }
     std::vector<demcz_handle::RunCall> calls;
-    int32_t rc = live_rollback(h, calls);
+    rc = live_rollback(h, calls);
     if (rc) return rc;
     h->replaying = true;
     for (const auto& c : calls) {
@@ -1678,6 +1826,109 @@ static int32_t live_verify(demcz_handle* h)
     h->replaying = false;
     if (rc) return rc;
     SYNCCHK(h, h->stream);
+    return check_live_err(h);
+}
+
+// ---- replica groups of one process (demcz_peer_group) --------------------------------------------------------------------------
+// The calls of `calls[m]` (the same list for every member) executed for all members in lockstep, one launch per K-window, the
+// boundary rows of all members appended to every replica in rank order from the members' own state buffers: what the
+// in-launch hand-off does, without it.  The host waits for every phase -- this is the fall-back, not the product path.
+static int32_t group_execute(PeerGroup* G, const std::vector<std::vector<demcz_handle::RunCall>>& calls)
+{
+    const size_t ncall = calls.empty() ? 0 : calls[0].size();
+    for (const auto& cm : calls)
+        if (cm.size() != ncall) return DEMCZ_ERR_STATE;
+    auto sync_all = [&]() -> int32_t {
+        for (demcz_handle* m : G->members) {
+            if (hipStreamSynchronize(m->stream) != hipSuccess) return fail(m, DEMCZ_ERR_HIP, "replica group: stream synchronisation failed");
+            if (m->prod_stream && hipStreamSynchronize(m->prod_stream) != hipSuccess) return fail(m, DEMCZ_ERR_HIP, "replica group: stream synchronisation failed");
+        }
+        return DEMCZ_OK;
+    };
+    int32_t rc = DEMCZ_OK;
+    for (demcz_handle* m : G->members) { m->replaying = true; m->external_append = true; }
+    for (size_t ic = 0; ic < ncall && rc == DEMCZ_OK; ++ic) {
+        const auto& c0 = calls[0][ic];
+        for (size_t mi = 0; mi < G->members.size(); ++mi)
+            if (calls[mi][ic].g_from != c0.g_from || calls[mi][ic].g_to != c0.g_to) rc = DEMCZ_ERR_STATE;
+        if (rc) break;
+        const int K = G->members[0]->cfg.K;
+        for (int64_t g = c0.g_from; g <= c0.g_to && rc == DEMCZ_OK;) {
+            const int64_t w_end = std::min<int64_t>(((g - 1) / K + 1) * (int64_t)K, c0.g_to);
+            for (size_t mi = 0; mi < G->members.size() && rc == DEMCZ_OK; ++mi) {
+                const auto& c = calls[mi][ic];
+                rc = demcz_run(G->members[mi], g, w_end, c.gamma, c.tempered ? c.temperature.data() + (g - c.g_from) : nullptr);
+            }
+            if (rc == DEMCZ_OK) rc = sync_all();
+            if (rc == DEMCZ_OK && w_end % K == 0) {
+                for (demcz_handle* m : G->members)
+                    for (demcz_handle* src : G->members) {
+                        if (rc == DEMCZ_OK) rc = demcz_append_rows_device(m, src->dX, src->cfg.N, src->cfg.N);
+                        if (rc != DEMCZ_OK && m != src && m->err.empty()) m->err = src->err;
+                    }
+                if (rc == DEMCZ_OK) rc = sync_all();
+            }
+            g = w_end + 1;
+        }
+    }
+    for (demcz_handle* m : G->members) { m->replaying = false; m->external_append = false; m->rec_desc[0].valid = m->rec_desc[1].valid = false; }
+    return rc;
+}
+
+// Verification for a member of a replica group = for the whole group (one host thread drives all members, and a member's
+// results depend on every other member's launches having run): all streams are drained, all error words looked at.
+static int32_t group_verify(demcz_handle* h)
+{
+    PeerGroup* G = h->group;
+    if (!G || G->busy || h->replaying) return check_live_err(h);
+    if (G->dead) {      // (a member is gone; it verified the whole group on its way out, so what is there is valid)
+        if (h->live_log.empty()) return check_live_err(h);
+        return fail(h, DEMCZ_ERR_STATE, "a member of this handle's replica group has been destroyed");
+    }
+    bool any_log = false;
+    for (demcz_handle* m : G->members) any_log = any_log || !m->live_log.empty();
+    if (!any_log) return check_live_err(h);
+    for (demcz_handle* m : G->members)
+        if (m->live_log.size() != h->live_log.size())
+            return fail(h, DEMCZ_ERR_STATE, "replica group: every member must be given the same demcz_run calls before any member's results are asked for");
+    G->busy = true;
+    struct Unbusy { PeerGroup* g; ~Unbusy() { g->busy = false; } } unbusy{G};
+    bool failed = false;
+    for (demcz_handle* m : G->members) {
+        HIPCHK(m, hipStreamSynchronize(m->stream));
+        if (m->prod_stream) HIPCHK(m, hipStreamSynchronize(m->prod_stream));
+    }
+    for (demcz_handle* m : G->members) {
+        unsigned int e[4] = {0, 0, 0, 0};
+        HIPCHK(m, hipMemcpy(e, m->d_live_err, sizeof(e), hipMemcpyDeviceToHost));
+        failed = failed || e[0] != 0u;
+        if (e[0] && getenv("DEMCZ_DEBUG_LIVE"))
+            fprintf(stderr, "[demcz] replica %d of %d: hand-off timed out at generation %u of its launch, row %u, workgroup %u (M_app %lld, M %lld, launches %lld, live_claimed %d)\n",
+                    m->rank, m->nranks, e[1], e[2], e[3], (long long)m->M_app, (long long)m->M, (long long)m->launches, (int)m->live_claimed);
+    }
+    if (!G->failed && !failed) {
+        for (demcz_handle* m : G->members) m->live_log.clear();
+        return DEMCZ_OK;
+    }
+    std::vector<std::vector<demcz_handle::RunCall>> calls(G->members.size());
+    if (!G->failed) {
+        // first failure: every member goes back to the state before its first unverified call
+        for (size_t mi = 0; mi < G->members.size(); ++mi) {
+            int32_t rc = live_rollback(G->members[mi], calls[mi]);
+            if (rc) { if (G->members[mi] != h) h->err = G->members[mi]->err; return rc; }
+        }
+        G->failed = true;
+    } else {
+        // the group already runs deferred: the logged calls have not been executed at all
+        for (size_t mi = 0; mi < G->members.size(); ++mi) { calls[mi].swap(G->members[mi]->live_log); G->members[mi]->live_log.clear(); }
+    }
+    int32_t rc = group_execute(G, calls);
+    if (rc) {
+        if (h->err.empty()) for (demcz_handle* m : G->members) if (!m->err.empty()) { h->err = m->err; break; }
+        if (rc == DEMCZ_ERR_STATE && h->err.empty()) h->err = "replica group: the members were not given the same calls";
+        return rc;
+    }
+    for (demcz_handle* m : G->members) m->g_done = calls[0].empty() ? m->g_done : calls[0].back().g_to;
     return check_live_err(h);
 }
 
@@ -1740,11 +1991,15 @@ static int64_t live_wg_capacity(demcz_handle* h)
     } else if (h->split_kind == 3) {
         const void* f = nullptr;
         switch (h->cfg.d) {
-        case 5: f = reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 5, 8, true, true>); break;
-        case 6: f = reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 6, 8, true, true>); break;
-        case 10: f = reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 10, 8, true, true>); break;
-        case 20: f = (h->split_lanes == 32) ? reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 20, 32, true, true>)
-                                             : reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 20, 16, true, true>); break;
+#define DEMCZ_MLB_FN(DD, LL) ((h->ngrp > 1) ? reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, DD, LL, true, true, 0, true>) \
+                                            : reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, DD, LL, true, true>))
+        case 5: f = DEMCZ_MLB_FN(5, 8); break;
+        case 6: f = DEMCZ_MLB_FN(6, 8); break;
+        case 10: f = DEMCZ_MLB_FN(10, 8); break;
+        case 20: f = (h->split_lanes == 32) ? DEMCZ_MLB_FN(20, 32)
+                     : (h->mlb_qb == 5) ? reinterpret_cast<const void*>(&window_kernel_mlb<TARGET_MVNORMAL, 20, 16, true, true, 5>)
+                                        : DEMCZ_MLB_FN(20, 16); break;
+#undef DEMCZ_MLB_FN
         }
         if (!f || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 64 * h->wpw, 0) != hipSuccess) per_cu = 0;
     } else if (h->split_kind == 2 && h->lr_spec) {
@@ -1789,16 +2044,25 @@ static int64_t live_wg_capacity(demcz_handle* h)
 // (Another PROCESS on the GPU is outside this rule; the bounded poll + the automatic redo in demcz_run_checked /
 //  check_live_err cover it.)
 static std::mutex g_live_mutex;
-static demcz_handle* g_live_owner[64] = {nullptr};
+static int64_t g_live_used[64] = {0};      // per-mille of each device's LIVE capacity held by handles of this process
 
+// Round 4: a budget instead of one owner per device.  A handle claims the share of ITS kernel's capacity that its consumer
+// workgroups are (capacities differ by kernel: registers, LDS); claims of a device add up to at most the whole.  That is what
+// lets the R replicas of a sharded run share one GPU (demcz_peer_group), each with 1/R of the chains, and lets two small
+// independent samplers both keep their LIVE launches.
 static bool live_claim(demcz_handle* h)
 {
     if (h->live_claimed) return true;
     const int dev = h->cfg.device_id;
     if (dev < 0 || dev >= 64) return false;
+    const int64_t cap = live_wg_capacity(h);
+    const int64_t wgs = (h->cfg.N + h->split_per_wg - 1) / h->split_per_wg;
+    if (cap <= 0 || wgs > cap) return false;
+    const int64_t share = std::max<int64_t>(1, (wgs * 1000 + cap - 1) / cap);
     std::lock_guard<std::mutex> lk(g_live_mutex);
-    if (g_live_owner[dev] != nullptr && g_live_owner[dev] != h) return false;
-    g_live_owner[dev] = h;
+    if (g_live_used[dev] + share > 1000) return false;
+    g_live_used[dev] += share;
+    h->live_share = share;
     h->live_claimed = true;
     return true;
 }
@@ -1808,13 +2072,23 @@ static void live_release(demcz_handle* h)
     if (!h->live_claimed) return;
     std::lock_guard<std::mutex> lk(g_live_mutex);
     const int dev = h->cfg.device_id;
-    if (dev >= 0 && dev < 64 && g_live_owner[dev] == h) g_live_owner[dev] = nullptr;
+    if (dev >= 0 && dev < 64) g_live_used[dev] = std::max<int64_t>(0, g_live_used[dev] - h->live_share);
+    h->live_share = 0;
     h->live_claimed = false;
+}
+
+// layouts whose LIVE consumers re-read a missing row through live_reload (system scope when there are peers)
+static bool peer_capable(const demcz_handle* h)
+{
+    return h->lanes == DEMCZ_LAYOUT_SPLIT && h->split_kind != 1 && h->split_kind != 0;
 }
 
 static int64_t live_span(demcz_handle* h)
 {
-    if (h->lanes != DEMCZ_LAYOUT_SPLIT || h->comm || h->lag > 0 || h->external_append || h->no_live) return 0;
+    // (sharded: only with the rows handed over inside the launches -- peer_mode 2; otherwise a launch ends at the exchange)
+    if (h->lanes != DEMCZ_LAYOUT_SPLIT || (h->comm && h->peer_mode != 2) || h->lag > 0 || h->external_append || h->no_live) return 0;
+    if (h->peer_mode != 0 && !peer_capable(h)) return 0;
+    if (h->peer_mode == 1 && (!h->group || h->group->failed || h->group->dead)) return 0;
     static const bool disabled = (getenv("DEMCZ_NO_LIVE") != nullptr);     // safety valve: one launch per K-window
     if (disabled) return 0;
     const int per_wg = h->split_per_wg;
@@ -1926,17 +2200,33 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     const int64_t G = g_to - g_from + 1;
     const int K = h->cfg.K;
     const bool sharded = (h->comm != nullptr);
-    const bool kernel_appends = !sharded && !h->external_append;
+    if (h->peer_mode == 1 && (!h->group || h->group->dead))
+        return fail(h, DEMCZ_ERR_STATE, "demcz_run: a member of this handle's replica group has been destroyed");
+    // `peer`: the boundary rows of ALL shards reach this replica from inside the launches (live_publish) -- no exchange step
+    const bool peer = h->peer_mode != 0 && live_span(h) > 0;
+    const bool rccl_exchange = sharded && !peer;
+    const bool kernel_appends = !rccl_exchange && !h->external_append;
+    const int64_t shards = (sharded || h->peer_mode != 0) ? h->nranks : 1;
     // capacity check for all appends of this call
     {
         const int64_t nb = g_to / K - (g_from - 1) / K;
-        const int64_t rows = h->cfg.N * (sharded ? h->nranks : 1);
+        const int64_t rows = h->cfg.N * shards;
         if (!h->external_append && h->M_app + nb * rows > h->cfg.Mcap)
             return fail(h, DEMCZ_ERR_CAPACITY, "demcz_run: Z row capacity (Mcap) would be exceeded");
         if (h->external_append && nb > 1)
             return fail(h, DEMCZ_ERR_STATE, "demcz_run: with external append a call may cross at most one K boundary, at its end");
         if (h->external_append && nb == 1 && (g_to % K) != 0)
             return fail(h, DEMCZ_ERR_STATE, "demcz_run: with external append the K boundary must be the last generation of the call");
+    }
+    if (h->peer_mode == 1 && !peer && !h->replaying) {
+        // A replica group that lost (or never had) its in-launch hand-off: its members cannot exchange rows by themselves, so
+        // the call is only logged here and executed for ALL members in lockstep, one launch per K-window, at the next
+        // verification (group_verify) -- by which time every member has been given the same call.
+        if (h->lag != 0 || h->external_append) return fail(h, DEMCZ_ERR_STATE, "demcz_run: replica groups run with append lag 0 and library-owned appends");
+        demcz_handle::RunCall rcall{g_from, g_to, gamma, temperature != nullptr, {}};
+        if (temperature) rcall.temperature.assign(temperature, temperature + G);
+        h->live_log.push_back(std::move(rcall));
+        return DEMCZ_OK;
     }
     // (a handle with the arena keeps a call's temperatures inside it when they fit: window_kernel_ps2 then reaches them with the
     //  32-bit offsets it reaches everything else with)
@@ -1975,6 +2265,16 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     P.rec_in = nullptr; P.rec_out = nullptr; P.next_g_first = 0; P.next_M = 0; P.next_ngen = 0; P.consumer_blocks = 0;
     P.next_rows = 0; P.next_boff = 0; P.rec_stride = 0;
     P.rec_fields = (h->lanes == DEMCZ_LAYOUT_SPLIT && h->split_kind == 2) ? h->cfg.d + 2 : 0;    // lane-per-parameter consumers: record-major
+    P.brows = h->cfg.N * (peer ? shards : 1);
+    P.row_off = peer ? (int64_t)h->rank * h->cfg.N : 0;
+    P.n_peers = peer ? h->n_peers : 0;
+    for (int r = 0; r < DEMCZ_MAX_PEERS; ++r) P.peer_Z[r] = (peer && r < h->n_peers) ? h->peer_Z[r] : nullptr;
+    if (peer && h->peer_mode == 2 && h->peer_fence) {
+        // this replica's unwritten rows were re-filled with the sentinel (set_state / a rollback) on this stream: no peer may
+        // publish into it before that is done, so the ranks meet here, stream-ordered, before the first launch that publishes
+        NCCLCHK(h, ncclAllReduce(h->d_err_all + 1, h->d_err_all + 1, 1, ncclUint32, ncclMax, h->comm, h->stream));
+        h->peer_fence = false;
+    }
 #ifdef DEMCZ_STAMPS
     if (!h->d_stamps) {
         HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->d_stamps, (size_t)DEMCZ_STAMP_WGS * 16 * sizeof(unsigned long long)));
@@ -2000,7 +2300,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         // bound the redo: verify now (a synchronisation every 256 calls).  Not inside demcz_run_checked: that call rolls back
         // to ITS entry and redoes itself from there (statistics and stop decisions included), so the snapshot must not move
         // into the middle of it.
-        if (h->live_log.size() >= 256 && !h->in_checked) {
+        if (h->live_log.size() >= 256 && !h->in_checked && h->peer_mode != 1) {      // (a replica group verifies as a whole: group_verify)
             int32_t rcv = live_verify(h);
             if (rcv) return rcv;
         }
@@ -2055,7 +2355,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
             // (64 MiB of records, the span of every launch until round 3f; profiles/r03f_launch_span.txt).
             int64_t n = std::min(live_max, g_to - g + 1);
             const auto& dc = h->rec_desc[h->rec_cur];
-            const int64_t rows_v = h->cfg.N;                  // (live: immediate visibility, one GPU)
+            const int64_t rows_v = h->cfg.N * (peer ? shards : 1);      // (live: immediate visibility; all shards' rows with peers)
             const int32_t boff = (int32_t)(K - (next_boundary - g + 1));
             const bool ready = dc.valid && dc.g_first == g + h->rng_offset && dc.M == h->M && dc.rows == rows_v && dc.boff == boff;
             if (ready && dc.ngen >= K) {
@@ -2079,7 +2379,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         P.temperature = temperature ? (temp_in_arena ? h->arena_temp : h->dtemp) + (g - g_from) : nullptr;
         P.do_append = (nbound > 0 && kernel_appends) ? 1 : 0;
         P.snap = nullptr;
-        if (nbound > 0 && sharded && E > 0) {
+        if (nbound > 0 && rccl_exchange && E > 0) {
             if (h->batch_cnt == 0) {
                 // the buffer was last read by the exchange two batches ago
                 // (every wait is a barrier packet between two window kernels: not asked for twice)
@@ -2096,7 +2396,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
             int64_t nend = nb1;
             if (E > 0 && !h->external_append) nend = ((nend / K + E - 1) / E) * E * (int64_t)K;
             int64_t nM = h->M, nn = nend - ng + 1;
-            const int64_t rows_n = h->cfg.N * (sharded ? h->nranks : 1);
+            const int64_t rows_n = h->cfg.N * shards;
             if (live_max > 0) nn = std::min(live_max, (w_end < g_to) ? g_to - w_end : G);   // a next call is taken to be as long as this one
             if (h->external_append) nn = 0;                      // the caller appends: M is not ours to predict
             else if (E == 0) nM = h->M_app + nbound * rows_n;                    // ... the rows appended now
@@ -2106,14 +2406,16 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
             rc = pc_prepare(h, P, vis_rows, ng + h->rng_offset, nn, nM, vis_rows, nboff);
             if (rc) return rc;
         }
-        // boundaries whose rows generations of this same launch draw from
-        const bool live = live_max > 0 && ((w_end - 1) / K - (g - 1) / K) > 0;
+        // boundaries whose rows generations of this same launch draw from.  With peers EVERY launch is of the LIVE kind: the rows
+        // of the boundary that ended the launch before may still be on their way from another replica's publisher
+        const bool live = live_max > 0 && (((w_end - 1) / K - (g - 1) / K) > 0 || peer);
         P.live_err = h->d_live_err;
         P.live_spin_limit = h->live_spin_limit ? (int32_t)h->live_spin_limit : LIVE_SPIN_LIMIT;
         if (h->live_fault_polls > 0 && g >= h->live_fault_g) P.live_spin_limit = h->live_fault_polls;
         if (h->live_fault_polls < 0 && live && g >= h->live_fault_g)      // "a wave of this launch has already given up": every wave leaves at once
             HIPCHK(h, hipMemsetAsync(h->d_live_err, 0x01, sizeof(unsigned int), h->stream));
         P.acc_out = h->d_acc ? h->d_acc + (size_t)h->acc_next * (size_t)h->acc_waves * 2 : nullptr;
+        if (live) h->err_clean = false;
         rc = launch_window(h, P, live);
         h->after_launch_ev = nullptr;         // (whatever was recorded before this launch says nothing about it)
         if (rc) return rc;
@@ -2127,7 +2429,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         // (one marker per launch on the compute stream: launches that stream are long ones)
         if (h->hs_on && hist) { int32_t rch = stream_history(h, g, w_end); if (rch) return rch; }
         if (nbound > 0 && !h->external_append) {
-            const int64_t rows = h->cfg.N * (sharded ? h->nranks : 1);
+            const int64_t rows = h->cfg.N * shards;
             if (E == 0) {
                 if (kernel_appends) { h->M_app += nbound * rows; h->M = h->M_app; }
                 else { rc = append_after_window(h); if (rc) return rc; }
@@ -2143,7 +2445,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
                     } else {
                         h->pending.back().M_after = h->M_app;
                     }
-                    if (sharded) {
+                    if (rccl_exchange) {
                         ++h->batch_cnt;
                         if (j == J) { rc = exchange_batch(h); if (rc) return rc; }
                     }
@@ -2159,7 +2461,7 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         tev.a = tev.b = nullptr;
         h->timed_launches += timed_launches;
     }
-    if (sharded && E > 0) {                 // nothing stays un-exchanged across calls
+    if (rccl_exchange && E > 0) {           // nothing stays un-exchanged across calls
         int32_t rc = exchange_batch(h);
         if (rc) return rc;
     }
@@ -2655,6 +2957,167 @@ extern "C" int32_t demcz_comm_init(demcz_handle* h, const void* unique_id_128B, 
     h->rank = rank;
     if (const char* tenv = getenv("DEMCZ_COMM_TIMEOUT_MS")) h->comm_timeout_ms = std::max<long long>(0, atoll(tenv));
     HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->d_gather, (size_t)h->cfg.N * h->cfg.d * nranks * sizeof(double)));
+    return peer_setup_ipc(h);
+}
+
+// ---- replicas that publish into each other (round 4) ----------------------------------------------------------------------------
+extern "C" int32_t demcz_peer_group(demcz_handle** handles, int32_t R)
+{
+    if (!handles || R < 2 || R > DEMCZ_MAX_PEERS + 1) return DEMCZ_ERR_INVALID_ARGUMENT;
+    demcz_handle* h0 = handles[0];
+    if (!h0) return DEMCZ_ERR_INVALID_ARGUMENT;
+    for (int r = 0; r < R; ++r) {
+        demcz_handle* m = handles[r];
+        if (!m) return DEMCZ_ERR_INVALID_ARGUMENT;
+        for (int q = 0; q < r; ++q) if (handles[q] == m) return fail(m, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_peer_group: a handle appears twice");
+        if (m->comm || m->peer_mode != 0) return fail(m, DEMCZ_ERR_STATE, "demcz_peer_group: handle is already sharded");
+        if (m->lag != 0 || m->external_append) return fail(m, DEMCZ_ERR_STATE, "demcz_peer_group: append lag 0 and library-owned appends only");
+        if (!m->live_log.empty()) { int32_t rcv = live_verify(m); if (rcv) return rcv; }
+        if (m->cfg.device_id != h0->cfg.device_id || m->cfg.N != h0->cfg.N || m->cfg.d != h0->cfg.d || m->cfg.K != h0->cfg.K ||
+            m->cfg.Mcap != h0->cfg.Mcap || m->cfg.seed != h0->cfg.seed || m->ZS != h0->ZS || m->lanes != h0->lanes ||
+            m->split_kind != h0->split_kind || m->cfg.target_kind != h0->cfg.target_kind || m->cfg.Nblocks != h0->cfg.Nblocks)
+            return fail(m, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_peer_group: the members must be shards of ONE run: same device, N, d, K, Mcap, seed, target, layout");
+        if (m->cfg.chain_id0 != (int64_t)r * m->cfg.N)
+            return fail(m, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_peer_group: chain_id0 of member r must be r * N (equal shards in rank order)");
+        if (m->M != h0->M || m->M_app != h0->M_app || m->g_done != h0->g_done)
+            return fail(m, DEMCZ_ERR_STATE, "demcz_peer_group: the members' archives / generation counters differ");
+    }
+    // The members' launches wait for each other's rows, so they must be able to RUN at the same time.  HIP multiplexes its streams
+    // over a few hardware queues (GPU_MAX_HW_QUEUES, four by default), and two kernels on one hardware queue run one after the
+    // other whatever streams they came from: two members whose streams share a queue would wait for each other until the poll
+    // limit.  So: a rendezvous kernel on every member's stream (each waits, at most 2 ms, until all R have started); if they do
+    // not all meet, the members that own their stream get fresh ones (a new stream goes to the least used queue) and the
+    // rendezvous is tried again.  No luck after a few rounds: the group runs in lockstep from the start (G->failed).
+    bool concurrent = false;
+    {
+        unsigned int* d_rv = nullptr;
+        HIPCHK(h0, hipSetDevice(h0->cfg.device_id));
+        HIPCHK(h0, dev_malloc(h0->cfg.device_id, (void**)&d_rv, 2 * sizeof(unsigned int)));
+        std::vector<hipStream_t> spare;
+        for (int round = 0; round < 6 && !concurrent; ++round) {
+            if (hipMemset(d_rv, 0, 2 * sizeof(unsigned int)) != hipSuccess) break;
+            for (int r = 0; r < R; ++r)
+                hipLaunchKernelGGL(rendezvous_kernel, dim3(1), dim3(1), 0, handles[r]->stream, d_rv, (unsigned int)R, d_rv + 1, 200000ull);
+            bool okl = hipGetLastError() == hipSuccess;
+            for (int r = 0; r < R; ++r) okl = (hipStreamSynchronize(handles[r]->stream) == hipSuccess) && okl;
+            unsigned int rv[2] = {0, 0};
+            if (!okl || hipMemcpy(rv, d_rv, sizeof(rv), hipMemcpyDeviceToHost) != hipSuccess) break;
+            if (rv[1] == (unsigned int)R) { concurrent = true; break; }
+            for (int r = 0; r < R; ++r) {
+                demcz_handle* m = handles[r];
+                if (!m->own_stream) continue;
+                hipStream_t ns = nullptr;
+                if (hipStreamCreateWithFlags(&ns, hipStreamNonBlocking) != hipSuccess) continue;
+                spare.push_back(m->stream);             // (kept alive until the group's streams are settled: the queue
+                m->stream = ns;                          //  assignment of the next new stream depends on what exists)
+                m->after_launch_ev = nullptr;
+            }
+        }
+        for (hipStream_t st : spare) stream_release(h0->cfg.device_id, st, true);
+        (void)dev_free(h0->cfg.device_id, d_rv);
+    }
+    PeerGroup* G = new PeerGroup();
+    for (int r = 0; r < R; ++r) G->members.push_back(handles[r]);
+    G->failed = !peer_capable(h0) || !concurrent;      // (a layout without the hand-off, or streams that cannot overlap: lockstep from the start)
+    for (int r = 0; r < R; ++r) {
+        demcz_handle* m = handles[r];
+        m->group = G;
+        m->peer_mode = 1;
+        m->nranks = R;
+        m->rank = r;
+        m->n_peers = 0;
+        for (int q = 0; q < R; ++q) if (q != r) m->peer_Z[m->n_peers++] = handles[q]->dZ;
+        rec_invalidate(m);                  // (draws made against N rows per boundary no longer apply)
+    }
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_get_peer_status(const demcz_handle* h, int32_t* mode, int32_t* peers)
+{
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (mode) *mode = h->peer_mode;
+    if (peers) *peers = h->n_peers;
+    return DEMCZ_OK;
+}
+
+// demcz_comm_init, second half: every rank's archive becomes a fine-grained allocation of its own (coherent for writers on other
+// GPUs while kernels run), is exported with hipIpcGetMemHandle, the handles travel in one ncclAllGather, and every rank opens
+// the other ranks' archives.  Any refusal anywhere (an allocation flag, IPC, peer access) switches the mode off on ALL ranks
+// (min-reduced), and the run exchanges its rows through ncclAllGather as before.  Returns DEMCZ_OK either way unless the
+// communicator itself fails.
+static int32_t peer_setup_ipc(demcz_handle* h)
+{
+    const bool off = getenv("DEMCZ_NO_PEER") != nullptr;
+    const bool self = getenv("DEMCZ_PEER_SELF") != nullptr;      // a one-rank communicator walks the path too (tests)
+    const int R = h->nranks;
+    if (off || R > DEMCZ_MAX_PEERS + 1 || (R < 2 && !self)) return DEMCZ_OK;
+    HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->d_err_all, 4 * sizeof(unsigned int)));
+    HIPCHK(h, hipMemsetAsync(h->d_err_all, 0, 4 * sizeof(unsigned int), h->stream));
+    struct Rec { hipIpcMemHandle_t mh; int32_t ok; int32_t pad; };
+    static_assert(sizeof(Rec) % 8 == 0, "all-gather record");
+    Rec mine{};
+    mine.ok = peer_capable(h) ? 1 : 0;
+    double* fine = nullptr;
+    if (mine.ok) {
+        // the copy keeps whatever the archive (and, in the arena, the record buffers behind it) already holds: set_state may have run
+        if (hipExtMallocWithFlags((void**)&fine, h->dZ_bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); fine = nullptr; mine.ok = 0; }
+    }
+    if (mine.ok && hipIpcGetMemHandle(&mine.mh, fine) != hipSuccess) { (void)hipGetLastError(); mine.ok = 0; }
+    Rec* d_rec = nullptr;
+    HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&d_rec, sizeof(Rec) * (size_t)(R + 1)));
+    std::vector<Rec> all((size_t)R);
+    int32_t rc = DEMCZ_OK;
+    auto cleanup = [&]() { if (d_rec) (void)dev_free(h->cfg.device_id, d_rec); };
+    if (hipMemcpyAsync(d_rec + R, &mine, sizeof(Rec), hipMemcpyHostToDevice, h->stream) != hipSuccess) { cleanup(); if (fine) (void)hipFree(fine); return fail(h, DEMCZ_ERR_HIP, "demcz_comm_init: upload failed"); }
+    if (ncclAllGather(d_rec + R, d_rec, sizeof(Rec), ncclChar, h->comm, h->stream) != ncclSuccess) { cleanup(); if (fine) (void)hipFree(fine); return fail(h, DEMCZ_ERR_COMM, "demcz_comm_init: all-gather of the IPC handles failed"); }
+    rc = sync_stream(h, h->stream, "demcz_comm_init (IPC handles)");
+    if (rc == DEMCZ_OK && hipMemcpy(all.data(), d_rec, sizeof(Rec) * (size_t)R, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(h, DEMCZ_ERR_HIP, "demcz_comm_init: download failed");
+    if (rc) { cleanup(); if (fine) (void)hipFree(fine); return rc; }
+    unsigned int ok = 1u;
+    for (int r = 0; r < R; ++r) ok &= all[(size_t)r].ok ? 1u : 0u;
+    void* mapped[DEMCZ_MAX_PEERS] = {nullptr};
+    int nmap = 0;
+    if (ok) {
+        for (int r = 0; r < R && ok; ++r) {
+            if (r == h->rank) continue;
+            void* ptr = nullptr;
+            if (hipIpcOpenMemHandle(&ptr, all[(size_t)r].mh, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok = 0u; break; }
+            mapped[nmap++] = ptr;
+        }
+    }
+    // every rank must have opened every archive, or nobody uses any
+    unsigned int* d_ok = reinterpret_cast<unsigned int*>(d_rec);
+    if (hipMemcpyAsync(d_ok, &ok, sizeof(ok), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        ncclAllReduce(d_ok, d_ok, 1, ncclUint32, ncclMin, h->comm, h->stream) != ncclSuccess) rc = fail(h, DEMCZ_ERR_COMM, "demcz_comm_init: reduction failed");
+    if (rc == DEMCZ_OK) rc = sync_stream(h, h->stream, "demcz_comm_init (IPC agreement)");
+    unsigned int all_ok = 0u;
+    if (rc == DEMCZ_OK && hipMemcpy(&all_ok, d_ok, sizeof(all_ok), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(h, DEMCZ_ERR_HIP, "demcz_comm_init: download failed");
+    cleanup();
+    if (rc || !all_ok) {
+        for (int i = 0; i < nmap; ++i) (void)hipIpcCloseMemHandle(mapped[i]);
+        if (fine) (void)hipFree(fine);
+        return rc;
+    }
+    // switch the archive over: same contents, same offsets of what lives behind it in the arena
+    if (hipMemcpyAsync(fine, h->dZ, h->dZ_bytes, hipMemcpyDeviceToDevice, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
+        for (int i = 0; i < nmap; ++i) (void)hipIpcCloseMemHandle(mapped[i]);
+        (void)hipFree(fine);
+        return fail(h, DEMCZ_ERR_HIP, "demcz_comm_init: copy into the fine-grained archive failed");
+    }
+    rec_invalidate(h);
+    const ptrdiff_t shift = reinterpret_cast<unsigned char*>(fine) - reinterpret_cast<unsigned char*>(h->dZ);
+    auto rebase = [&](double*& q) { if (q) q = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(q) + shift); };
+    if (h->arena) {
+        rebase(h->arena_rec[0]); rebase(h->arena_rec[1]); rebase(h->arena_temp);
+        if (h->rec_in_arena) { rebase(h->d_rec[0]); rebase(h->d_rec[1]); }
+    }
+    g_dev_pool.release(h->dZ, h->cfg.device_id);
+    h->dZ = fine;
+    h->archive_fine = true;
+    for (int i = 0; i < nmap; ++i) { h->ipc_mapped[i] = mapped[i]; h->peer_Z[i] = reinterpret_cast<double*>(mapped[i]); }
+    h->n_peers = nmap;
+    h->peer_mode = 2;
+    h->peer_fence = true;
     return DEMCZ_OK;
 }
 
@@ -3009,6 +3472,7 @@ extern "C" int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_
     DEADCHK(h);
     if (every < 4 || g_from < 1 || g_to < g_from) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_run_checked: need every >= 4 and 1 <= g_from <= g_to");
     if (!h->has_state) return fail(h, DEMCZ_ERR_STATE, "demcz_run_checked: call demcz_set_state first");
+    if (h->peer_mode == 1) return fail(h, DEMCZ_ERR_STATE, "demcz_run_checked: members of a replica group are driven call by call (demcz_run, demcz_rhat_partial)");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     // everything before this call is verified first, so that a failed LIVE hand-off inside it rolls back to HERE
     int32_t rc = live_verify(h);
@@ -3021,10 +3485,12 @@ extern "C" int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_
     if (h->live_log.empty()) return rc;
     // the statistics and the stop decision above may rest on a slab whose row hand-off failed: look, and if so
     // undo the whole call and make it again with one launch per K-window (the handle stays in that mode)
-    SYNCCHK(h, h->stream);
-    unsigned int e[4] = {0, 0, 0, 0};
-    HIPCHK(h, hipMemcpy(e, h->d_live_err, sizeof(e), hipMemcpyDeviceToHost));
-    if (!e[0]) { h->live_log.clear(); return rc; }
+    // (a run that failed for another reason on THIS rank only must not leave the others waiting in the reduction below: the
+    //  communicator's deadline covers it)
+    if (rc != DEMCZ_OK && h->peer_mode == 2) return rc;
+    bool failed = false;
+    { int32_t rcf = live_failed(h, failed); if (rcf) return rcf; }
+    if (!failed) { h->live_log.clear(); return rc; }
     std::vector<demcz_handle::RunCall> dropped;
     rc = live_rollback(h, dropped);
     if (rc) return rc;
@@ -3071,6 +3537,7 @@ extern "C" int32_t demcz_debug_kernel_name(const demcz_handle* h, char* buf, int
         if (h->lr_spec) snprintf(tmp, sizeof tmp, "window_kernel_lr8s<%d, %s>", d, lv);
         else if (h->split_kind == 4 && d <= 5) snprintf(tmp, sizeof tmp, "%s<%s, %d, %s, %s>", h->last_ps2 ? "window_kernel_ps2" : "window_kernel_ps", tg, d, lv, tm);
         else if (h->split_kind == 4) snprintf(tmp, sizeof tmp, "window_kernel_pw<%s, %d, %s, %s>", tg, d, lv, tm);
+        else if (h->split_kind == 3 && h->mlb_qb > 0 && h->split_lanes == 16) snprintf(tmp, sizeof tmp, "window_kernel_mlb<%s, %d, %d, true, %s, %d>", tg, d, h->split_lanes, lv, h->mlb_qb);
         else if (h->split_kind == 3) snprintf(tmp, sizeof tmp, "window_kernel_mlb<%s, %d, %d, true, %s>", tg, d, h->split_lanes, lv);
         else if (h->split_kind == 2 && lr) snprintf(tmp, sizeof tmp, "window_kernel_lr16<%d, true, %s>", d, lv);
         else if (h->split_kind == 2) snprintf(tmp, sizeof tmp, "window_kernel_ml<%s, %d, 16, true, %s>", tg, d, lv);

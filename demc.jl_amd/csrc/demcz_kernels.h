@@ -38,7 +38,15 @@ struct TargetParams {
     const double* design;    // LINREG: row-major nobs x d (one observation's regressors contiguous)
     const double* yobs;
     int64_t nobs;
+    // MVNORMAL, round 4: the sums of the quadratic form cut at the block boundaries (oracle: mvn_groups).
+    // ngrp > 1 iff the run's blocks, in order, are consecutive index ranges covering 0..d-1; goff = their ngrp + 1 offsets
+    // (device memory), gstart = bit j set iff parameter j starts a group.  ngrp <= 1: one group, the order of rounds 1-3.
+    int32_t ngrp;
+    const int32_t* goff;
+    uint64_t gstart;
 };
+
+constexpr int DEMCZ_MAX_PEERS = 7;      // replicas besides a handle's own: the eight GPUs of a node
 
 struct WindowParams {
     // archive: row-major on the device, row r at Z + r*ZS (ZS = padded row stride in doubles,
@@ -102,6 +110,14 @@ struct WindowParams {
     // can (window_kernel_ps2) writes it here as it loads it -- N x d (ld N) and N -- instead of two copy launches in front of it.
     double* safe_X;
     double* safe_lp;
+    // Replicated archives (a sharded run whose rows are handed over INSIDE the launch, demcz_kernels_rec.h: live_publish): a
+    // boundary appends brows rows in all -- this handle's chains are rows row_off .. row_off + N of them -- and every row goes
+    // to this handle's own archive AND to the n_peers other replicas (peer GPUs' memory opened over IPC, or other handles of
+    // the process).  Unsharded: brows = N, row_off = 0, n_peers = 0.
+    int64_t brows;
+    int64_t row_off;
+    int32_t n_peers;
+    double* peer_Z[DEMCZ_MAX_PEERS];
 #ifdef DEMCZ_STAMPS
     unsigned long long* stamps;   // diagnostic build only (scripts/stamps.py): 16 values per workgroup (8 stamps, 8 sums)
 #endif
@@ -171,6 +187,60 @@ __device__ __forceinline__ double target_logp(const TargetParams& tp, int d, XF 
 {
     const int dd = (D > 0) ? D : d;
     if constexpr (TARGET == TARGET_MVNORMAL) {
+        if (tp.ngrp > 1) {
+            // grouped by the run's blocks: y_i = P_i0 + P_i1 + ..., q = Q_0 + Q_1 + ... (TargetParams; oracle: target_logp)
+            if constexpr (D > 0) {
+                // compile-time indices for x (it lives in registers); the group starts are a run-time bit mask.  Both forms of
+                // every step are computed and one is selected -- three times the arithmetic of the plain order, on the one path
+                // (one lane per chain, block updates) where it is rarely the bottleneck.
+                double q = 0.0, Qg = 0.0;
+                bool haveq = false;
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    const double* wrow = tp.Wp + (i * (i + 1)) / 2;
+                    double y = 0.0, acc = 0.0;
+                    bool have = false;
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) {
+                        const bool st = (tp.gstart >> j) & 1ull;
+                        const double rr = X(j) - tp.mu[j];
+                        const double ysum = have ? y + acc : acc;
+                        if (st && j > 0) { y = ysum; have = true; }
+                        const double prod = wrow[j] * rr, fm = fma(wrow[j], rr, acc);
+                        acc = st ? prod : fm;
+                    }
+                    y = have ? y + acc : acc;
+                    const bool sti = (tp.gstart >> i) & 1ull;
+                    const double qsum = haveq ? q + Qg : Qg;
+                    if (sti && i > 0) { q = qsum; haveq = true; }
+                    const double sq = y * y, fq = fma(y, y, Qg);
+                    Qg = sti ? sq : fq;
+                }
+                q = haveq ? q + Qg : Qg;
+                return fma(-0.5, q, tp.c0);
+            } else {
+                double q = 0.0;
+                for (int g = 0; g < tp.ngrp; ++g) {
+                    const int lo = tp.goff[g], hi = tp.goff[g + 1];
+                    double Qg = 0.0;
+                    for (int i = lo; i < hi; ++i) {
+                        const double* wrow = tp.Wp + (i * (i + 1)) / 2;
+                        double y = 0.0;
+                        for (int gb = 0; gb <= g; ++gb) {
+                            const int jl = tp.goff[gb];
+                            int jh = tp.goff[gb + 1] - 1;
+                            jh = (jh > i) ? i : jh;
+                            double Pv = wrow[jl] * (X(jl) - tp.mu[jl]);
+                            for (int j = jl + 1; j <= jh; ++j) Pv = fma(wrow[j], X(j) - tp.mu[j], Pv);
+                            y = (gb == 0) ? Pv : y + Pv;
+                        }
+                        Qg = (i == lo) ? y * y : fma(y, y, Qg);
+                    }
+                    q = (g == 0) ? Qg : q + Qg;
+                }
+                return fma(-0.5, q, tp.c0);
+            }
+        }
         double q = 0.0;
 #pragma unroll
         for (int i = 0; i < dd; ++i) {
@@ -273,6 +343,9 @@ __global__ void __launch_bounds__(WINDOW_BS) window_kernel(const WindowParams P)
     [[maybe_unused]] const double c0c = P.tp.c0;
     // the log-density of a point, from the local constants where they exist (the same operation sequence as target_logp)
     auto logp_of = [&](const double (&xq)[D]) -> double {
+        if constexpr (!FULL && TARGET == TARGET_MVNORMAL) {
+            if (P.tp.ngrp > 1) return target_logp<TARGET, D>(P.tp, D, [&](int j) { return xq[j]; });      // sums grouped by the blocks
+        }
         if constexpr (LOCAL_TARGET && TARGET == TARGET_MVNORMAL) {
             double q = 0.0;
 #pragma unroll

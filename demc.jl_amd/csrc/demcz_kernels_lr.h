@@ -260,8 +260,8 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr16(const Wind
 #pragma unroll
                 for (int m = 0; m < NMF; ++m) {
                     const int k = own[m] ? 4 * m + q : 0;
-                    if (is_sentinel(za[m])) za[m] = live_load(&P.Z[ra_c * P.ZS + k]);
-                    if (is_sentinel(zb[m])) zb[m] = live_load(&P.Z[rb_c * P.ZS + k]);
+                    if (is_sentinel(za[m])) za[m] = live_reload(P, &P.Z[ra_c * P.ZS + k]);
+                    if (is_sentinel(zb[m])) zb[m] = live_reload(P, &P.Z[rb_c * P.ZS + k]);
                     bad |= is_sentinel(za[m]) | is_sentinel(zb[m]);
                 }
             }
@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr16(const Wind
                 if (own[m] && active && w == m) {
                     const int k = 4 * m + q;
                     if (P.do_append) {
-                        if constexpr (LIVE) live_store(&P.Zw[(P.M_append + nb * P.N + c) * P.ZS + k], x[m]);
+                        if constexpr (LIVE) live_publish(P, nb, c, k, x[m]);
                         else P.Zw[(P.M_append + nb * P.N + c) * P.ZS + k] = x[m];
                     }
                     if (P.snap) P.snap[nb * P.N * D + c + P.N * k] = x[m];
@@ -664,8 +664,8 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr8s(const Wind
                     const int64_t ra = (int64_t)(uint32_t)ii, rb = (int64_t)(uint32_t)(ii >> 32);
 #pragma unroll
                     for (int m = 0; m < NMF; ++m) {
-                        if (is_sentinel(za[m])) za[m] = live_load(&P.Z[ra * P.ZS + kq[m]]);
-                        if (is_sentinel(zb[m])) zb[m] = live_load(&P.Z[rb * P.ZS + kq[m]]);
+                        if (is_sentinel(za[m])) za[m] = live_reload(P, &P.Z[ra * P.ZS + kq[m]]);
+                        if (is_sentinel(zb[m])) zb[m] = live_reload(P, &P.Z[rb * P.ZS + kq[m]]);
                     }
                 }
             }
@@ -834,7 +834,7 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr8s(const Wind
                 for (int m = 0; m < NMF; ++m) v = (w == m) ? x[m] : v;
                 if (P.do_append) {
                     double* dst = reinterpret_cast<double*>(z_base + (uint64_t)(uint32_t)nb * z_stride);
-                    if constexpr (LIVE) live_store(dst, v);
+                    if constexpr (LIVE) live_publish(P, nb, c, 4 * w + q, v);
                     else *dst = v;
                 }
                 if (P.snap) P.snap[nb * P.N * D + c + P.N * (4 * w + q)] = v;

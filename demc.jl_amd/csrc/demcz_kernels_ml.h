@@ -206,8 +206,8 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
                 for (int k = 0; k < NP; ++k) {
                     const int p = r + L * k;
                     const int pc = (p < D) ? p : 0;
-                    if (is_sentinel(za_c[k])) za_c[k] = live_load(&P.Z[(int64_t)ra_c * P.ZS + pc]);
-                    if (is_sentinel(zb_c[k])) zb_c[k] = live_load(&P.Z[(int64_t)rb_c * P.ZS + pc]);
+                    if (is_sentinel(za_c[k])) za_c[k] = live_reload(P, &P.Z[(int64_t)ra_c * P.ZS + pc]);
+                    if (is_sentinel(zb_c[k])) zb_c[k] = live_reload(P, &P.Z[(int64_t)rb_c * P.ZS + pc]);
                     bad |= is_sentinel(za_c[k]) | is_sentinel(zb_c[k]);
                 }
             }
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
                 const int p = r + L * k;
                 if (p < D && active) {
                     if (P.do_append) {
-                        if constexpr (LIVE) live_store(&P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p], x[k]);
+                        if constexpr (LIVE) live_publish(P, nb, c, p, x[k]);
                         else P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p] = x[k];
                     }
                     if (P.snap) P.snap[nb * P.N * D + c + P.N * p] = x[k];
@@ -331,9 +331,20 @@ constexpr int MLB_MAX_BLOCKS = 64;
 // in a LIVE launch everybody who draws one of their rows falls back to their pace: scripts/mlb_stamps.py).
 constexpr int MLB_REC_WAVES = 4;
 
-template <int TARGET, int D, int L, bool REC = false, bool LIVE = false>
+// QB > 0 (round 4): the run's blocks are D / QB consecutive ranges of QB parameters each (C3: 20 = 4 x 5), so the sums of the
+// quadratic form are cut at their boundaries (TargetParams::ngrp) -- and a block-step, which moves ONE block, recomputes only
+// what that block feeds: the partial dot products P_{i,ib} of the rows at or below the block (a QB-long fma chain instead of a
+// D-long one), y_i = the sum of row i's partials, and the partial sums of squares Q_b of the blocks from ib on; the partials of the
+// other blocks and Q_b of the blocks before ib are kept per chain and committed on accept.  The doubles are those of the full
+// re-evaluation in the same order (oracle: target_logp; src/demcz.jl:189).  QB = 0: any block structure, full evaluation.
+// GM (QB = 0): the sums are cut at the boundaries of ANY consecutive blocks (TargetParams::gstart), full evaluation, the restarts
+// selected by the group-start mask -- an instantiation of its own, so that runs whose sums are not grouped keep their code.
+template <int TARGET, int D, int L, bool REC = false, bool LIVE = false, int QB = 0, bool GM = false>
 __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_mlb(const WindowParams P)
 {
+    static_assert(!GM || (QB == 0 && TARGET == TARGET_MVNORMAL), "grouped full evaluation: MvNormal, not the incremental form");
+    static_assert(QB == 0 || (TARGET == TARGET_MVNORMAL && D % QB == 0 && D / QB >= 2 && D / QB <= 8), "incremental form: equal consecutive blocks");
+    constexpr int QNB = (QB > 0) ? D / QB : 1;
     constexpr int WPW = REC ? MLB_REC_WAVES : 1;                // at most; the launch says how many (blockDim.x / 64: 1 or MLB_REC_WAVES)
     const int wpw = (int)(blockDim.x >> 6);
     const int wv = (int)(threadIdx.x >> 6);
@@ -392,6 +403,46 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
         }
     }
     double lp = P.lpcur[c];
+    // QB > 0: what is kept per chain between block-steps -- Pc[k][b] = P_{p_k, b} of this lane's rows, Qc[b] (every lane of the
+    // chain holds the same) -- started from the state the launch begins with (two LDS hand-offs, once)
+    [[maybe_unused]] double Pc[NP][QNB], Qc[QNB];
+    if constexpr (QB > 0) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int p = r + L * k;
+            if (p < D) rvec[gq * DP + p] = x[k] - muv[k];
+        }
+        wave_lds_handoff();
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int p = r + L * k;
+            double y = 0.0;
+#pragma unroll
+            for (int b = 0; b < QNB; ++b) {
+                double acc = Wrow[k][b * QB] * rvec[gq * DP + b * QB];
+#pragma unroll
+                for (int t = 1; t < QB; ++t) {
+                    const double tt = fma(Wrow[k][b * QB + t], rvec[gq * DP + b * QB + t], acc);
+                    acc = (b * QB + t <= p) ? tt : acc;
+                }
+                Pc[k][b] = acc;
+                y = (b == 0) ? acc : ((b * QB <= p) ? y + acc : y);
+            }
+            if (p < D) yvec[gq * DP + p] = y;
+        }
+        wave_lds_handoff();
+#pragma unroll
+        for (int b = 0; b < QNB; ++b) {
+            double qb = 0.0;
+#pragma unroll
+            for (int t = 0; t < QB; ++t) {
+                const double yy = yvec[gq * DP + b * QB + t];
+                qb = (t == 0) ? yy * yy : fma(yy, yy, qb);
+            }
+            Qc[b] = qb;
+        }
+        wave_lds_handoff();
+    }
     [[maybe_unused]] philox_blocks rng;
     // REC: this lane's entry of a block-step's record: slot boff[ib] + role of chain c, generation gi
     [[maybe_unused]] const double2* rec2 = reinterpret_cast<const double2*>(P.rec_in);
@@ -518,8 +569,8 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
                     for (int k = 0; k < NP; ++k) {
                         const int p = r + L * k;
                         const int pc = (p < D) ? p : 0;
-                        if (is_sentinel(za[k])) za[k] = live_load(&P.Z[row1_c * P.ZS + pc]);
-                        if (is_sentinel(zb[k])) zb[k] = live_load(&P.Z[row2_c * P.ZS + pc]);
+                        if (is_sentinel(za[k])) za[k] = live_reload(P, &P.Z[row1_c * P.ZS + pc]);
+                        if (is_sentinel(zb[k])) zb[k] = live_reload(P, &P.Z[row2_c * P.ZS + pc]);
                         bad |= is_sentinel(za[k]) | is_sentinel(zb[k]);
                     }
                 }
@@ -550,6 +601,70 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
                 if (p < D) rvec[gq * DP + p] = xp[k] - muv[k];
             }
             wave_lds_handoff();
+            double lpp;
+            [[maybe_unused]] double Pn[NP], Qn[QNB];
+            if constexpr (QB > 0) {
+                // the incremental form: block ib (wave-uniform) selects one of QNB straight-line bodies with literal offsets
+                auto body = [&](auto ibc) __attribute__((always_inline)) {
+                    constexpr int IB = decltype(ibc)::value;
+                    double rb[QB];
+#pragma unroll
+                    for (int t = 0; t < QB; ++t) rb[t] = rvec[gq * DP + IB * QB + t];
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        const int p = r + L * k;
+                        double acc = Wrow[k][IB * QB] * rb[0];
+#pragma unroll
+                        for (int t = 1; t < QB; ++t) {
+                            const double tt = fma(Wrow[k][IB * QB + t], rb[t], acc);
+                            acc = (IB * QB + t <= p) ? tt : acc;
+                        }
+                        Pn[k] = acc;
+                        double y = (IB == 0) ? acc : Pc[k][0];
+#pragma unroll
+                        for (int b = 1; b < QNB; ++b) {
+                            const double pb = (b == IB) ? acc : Pc[k][b];
+                            y = (b * QB <= p) ? y + pb : y;
+                        }
+                        if (p < D && p >= IB * QB) yvec[gq * DP + p] = y;      // rows above the block keep their y (not read below)
+                    }
+                    wave_lds_handoff();
+                    double q = 0.0;
+#pragma unroll
+                    for (int b = 0; b < QNB; ++b) {
+                        double qb = Qc[b];
+                        if (b >= IB) {                     // (literals: resolved when the body is instantiated)
+#pragma unroll
+                            for (int t = 0; t < QB; ++t) {
+                                const double yy = yvec[gq * DP + b * QB + t];
+                                qb = (t == 0) ? yy * yy : fma(yy, yy, qb);
+                            }
+                        }
+                        Qn[b] = qb;
+                        q = (b == 0) ? qb : q + qb;
+                    }
+                    lpp = fma(-0.5, q, P.tp.c0);
+                    // commit what the moved block fed, should the step be accepted (the same test as below, on the same values)
+                    double dlq = lpp - lp;
+                    if (P.temperature) dlq = dlq / P.temperature[gi];
+                    const bool accq = logu < dlq;
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) Pc[k][IB] = accq ? Pn[k] : Pc[k][IB];
+#pragma unroll
+                    for (int b = IB; b < QNB; ++b) Qc[b] = accq ? Qn[b] : Qc[b];
+                };
+                static_assert(QNB <= 8, "switch below");
+                switch (ib) {
+                case 0: body(std::integral_constant<int, 0>{}); break;
+                case 1: body(std::integral_constant<int, (1 < QNB) ? 1 : 0>{}); break;
+                case 2: body(std::integral_constant<int, (2 < QNB) ? 2 : 0>{}); break;
+                case 3: body(std::integral_constant<int, (3 < QNB) ? 3 : 0>{}); break;
+                case 4: body(std::integral_constant<int, (4 < QNB) ? 4 : 0>{}); break;
+                case 5: body(std::integral_constant<int, (5 < QNB) ? 5 : 0>{}); break;
+                case 6: body(std::integral_constant<int, (6 < QNB) ? 6 : 0>{}); break;
+                default: body(std::integral_constant<int, (7 < QNB) ? 7 : 0>{}); break;
+                }
+            } else {
             double rj[DP];
 #pragma unroll
             for (int j = 0; j < DP / 2; ++j) {
@@ -557,8 +672,41 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
                 rj[2 * j] = t.x;
                 rj[2 * j + 1] = t.y;
             }
-            double lpp;
             if constexpr (TARGET == TARGET_MVNORMAL) {
+              if constexpr (GM) {
+                // sums cut at the block boundaries, any consecutive blocks: restarts selected by the group-start mask
+                const uint64_t gs = P.tp.gstart;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const int p = r + L * k;
+                    double y = 0.0, acc = 0.0;
+                    bool have = false;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        const bool st = (gs >> j) & 1ull, in = j <= p;
+                        const double ysum = have ? y + acc : acc;
+                        if (st && j > 0 && in) { y = ysum; have = true; }
+                        const double prod = Wrow[k][j] * rj[j], fm = fma(Wrow[k][j], rj[j], acc);
+                        acc = in ? (st ? prod : fm) : acc;
+                    }
+                    y = have ? y + acc : acc;
+                    if (p < D) yvec[gq * DP + p] = y;
+                }
+                wave_lds_handoff();
+                double q = 0.0, Qg = 0.0;
+                bool haveq = false;
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    const double yy = yvec[gq * DP + i];
+                    const bool st = (gs >> i) & 1ull;
+                    const double qsum = haveq ? q + Qg : Qg;
+                    if (st && i > 0) { q = qsum; haveq = true; }
+                    const double sq = yy * yy, fq = fma(yy, yy, Qg);
+                    Qg = st ? sq : fq;
+                }
+                q = haveq ? q + Qg : Qg;
+                lpp = fma(-0.5, q, P.tp.c0);
+              } else {
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
                     const int p = r + L * k;
@@ -579,11 +727,13 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
                     if (2 * j + 1 < D) q = fma(t.y, t.y, q);
                 }
                 lpp = fma(-0.5, q, P.tp.c0);
+              }
             } else {
                 double q = 0.0;
 #pragma unroll
                 for (int j = 0; j < D; ++j) q = (j == 0) ? rj[0] * rj[0] : fma(rj[j], rj[j], q);
                 lpp = -q;
+            }
             }
             double dlt = lpp - lp;
             if (P.temperature) dlt = dlt / P.temperature[gi];
@@ -613,7 +763,7 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
                 const int p = r + L * k;
                 if (p < D) {
                     if (P.do_append) {
-                        if constexpr (LIVE) live_store(&P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p], x[k]);
+                        if constexpr (LIVE) live_publish(P, nb, c, p, x[k]);
                         else P.Zw[(P.M_append + nb * P.N + c) * P.ZS + p] = x[k];
                     }
                     if (P.snap) P.snap[nb * P.N * D + c + P.N * p] = x[k];

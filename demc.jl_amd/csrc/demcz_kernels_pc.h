@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(LIVE ? 64 * PC8_LIVE_WAVES : 64) window_kernel
                     for (int e = l; e < G * D; e += 64) {
                         const int g = e / D, p = e % D;
                         const double v = rows[e];
-                        if (c0 + g < P.N && P.do_append) live_store(&P.Zw[(P.M_append + (int64_t)done * P.N + c0 + g) * P.ZS + p], v);
+                        if (c0 + g < P.N && P.do_append) live_publish(P, (int64_t)done, c0 + g, p, v);
                     }
                     asm volatile("" ::: "memory");
                     ++done;

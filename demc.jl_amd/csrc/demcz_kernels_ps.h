@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
                 if (__builtin_amdgcn_ballot_w64(ready) != 0ull) {
                     if (ready) {
                         const double v = pub_rows[(cw * PS_PUB + (int)(done % PS_PUB)) * D + pp];
-                        if (cl < P.N && P.do_append) live_store(&P.Zw[(P.M_append + (int64_t)done * P.N + cl) * P.ZS + pp], v);
+                        if (cl < P.N && P.do_append) live_publish(P, (int64_t)done, cl, pp, v);
                         ++done;
                     }
                     asm volatile("" ::: "memory");
@@ -439,8 +439,8 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
                 spins = 1;
             }
             if (bad) {
-                if (is_sentinel(za_f)) za_f = live_load(&P.Z[(int64_t)i1 * ZSC + fp]);
-                if (is_sentinel(zb_f)) zb_f = live_load(&P.Z[(int64_t)i2 * ZSC + fp]);
+                if (is_sentinel(za_f)) za_f = live_reload(P, &P.Z[(int64_t)i1 * ZSC + fp]);
+                if (is_sentinel(zb_f)) zb_f = live_reload(P, &P.Z[(int64_t)i2 * ZSC + fp]);
                 bad = is_sentinel(za_f) | is_sentinel(zb_f);
             }
         }

@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
                     const bool ready = pl && seq != done[t];
                     if (ready) {
                         const double v = pub_rows[(cw * PS_PUB + (int)(done[t] % PS_PUB)) * D + pp];
-                        if (cl < P.N && P.do_append) live_store(&P.Zw[(P.M_append + (int64_t)done[t] * P.N + cl) * P.ZS + pp], v);
+                        if (cl < P.N && P.do_append) live_publish(P, (int64_t)done[t], cl, pp, v);
                         ++done[t];
                     }
                     asm volatile("" ::: "memory");
@@ -368,8 +368,8 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
 #pragma unroll
             for (int t = 0; t < NF; ++t) {
                 if (fl[t] && fu[t] < Rn) {
-                    if (is_sentinel(za_f[t])) za_f[t] = live_load(&P.Z[(int64_t)(uint32_t)ixA[t] * ZSC + fp[t]]);
-                    if (is_sentinel(zb_f[t])) zb_f[t] = live_load(&P.Z[(int64_t)(uint32_t)(ixA[t] >> 32) * ZSC + fp[t]]);
+                    if (is_sentinel(za_f[t])) za_f[t] = live_reload(P, &P.Z[(int64_t)(uint32_t)ixA[t] * ZSC + fp[t]]);
+                    if (is_sentinel(zb_f[t])) zb_f[t] = live_reload(P, &P.Z[(int64_t)(uint32_t)(ixA[t] >> 32) * ZSC + fp[t]]);
                 }
             }
         }

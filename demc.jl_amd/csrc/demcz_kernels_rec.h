@@ -178,6 +178,30 @@ __device__ __forceinline__ void live_store(double* p, double v)
 }
 __device__ __forceinline__ bool is_sentinel(double v) { return (unsigned long long)__double_as_longlong(v) == LIVE_SENTINEL; }
 
+// Replicated archives (a sharded run: every rank -- a GPU of the node, or for rehearsal another handle on the same GPU -- holds
+// the whole archive and runs its own shard of the chains).  The hand-off above needs nothing new on the READING side: a wave
+// polls its OWN replica for the sentinel to go away.  The WRITING side stores element p of row `M_append + b * brows + row_off +
+// cl` -- boundary b of the launch, local chain cl -- into its own replica and into every peer's: one more write-through store
+// per peer, at system scope (sc0 sc1: past this GPU's caches, over xGMI into the peer's memory).  Each double is still its own
+// naturally aligned granule written once per replica, so still no flags, fences or ordering; the role the reference gives to
+// its shared archive (`Zshared`, one append per chain under pmap, src/demcz.jl:88-91, 137) without its race.
+__device__ __forceinline__ void live_store_sys(double* p, double v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void live_publish(const WindowParams& P, int64_t b, int64_t cl, int p, double v)
+{
+    const int64_t off = (P.M_append + b * P.brows + P.row_off + cl) * P.ZS + p;
+    live_store(P.Zw + off, v);
+    for (int r = 0; r < P.n_peers; ++r) live_store_sys(P.peer_Z[r] + off, v);
+}
+// a re-read of a row that showed the sentinel: past the caches; rows a PEER writes are asked for at system scope
+__device__ __forceinline__ double live_reload(const WindowParams& P, const double* p)
+{
+    if (P.n_peers > 0) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return live_load(p);
+}
+
 
 // One bounded poll step of a LIVE wait, shared by the consumers: returns true when the wave must give
 // up -- its own poll limit, or another wave's (live_err[0]; looked at every 256 polls so that a failed

@@ -318,6 +318,23 @@ class HipEngine:
         buf = C.create_string_buffer(unique_id, 128)
         self._chk(self._L.demcz_comm_init(self._h, buf, int(nranks), int(rank)))
 
+    @staticmethod
+    def peer_group(engines):
+        """demcz_peer_group: the engines (shards of one run, all in this process on one device) publish their K-boundary rows
+        into each other's archive replicas from inside their launches."""
+        L = engines[0]._L
+        arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+        rc = L.demcz_peer_group(arr, len(engines))
+        if rc != 0:
+            msgs = [(L.demcz_last_error(e._h) or b"").decode() for e in engines]
+            raise DemczError(rc, next((m for m in msgs if m), ""))
+
+    def peer_status(self):
+        """(mode, peers): mode 0 = RCCL exchange or unsharded, 1 = replica group of this process, 2 = IPC peers."""
+        m, n = C.c_int32(0), C.c_int32(0)
+        self._chk(self._L.demcz_get_peer_status(self._h, C.byref(m), C.byref(n)))
+        return int(m.value), int(n.value)
+
     def set_comm_timeout(self, milliseconds: int):
         """Deadline of every host-side wait of a sharded handle; past it the communicators are aborted and calls raise
         DemczError with code ERR_COMM (0 = wait for ever)."""

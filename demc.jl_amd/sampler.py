@@ -124,7 +124,10 @@ class Sharding:
     all-reduces the R-hat moments itself (``demcz_comm_init``).  ``mode="host"``: the driver does
     the exchange through ``all_gather`` / ``all_reduce_sum`` callables on host arrays (any
     backend: torch.distributed gloo/nccl, MPI ...), optionally with several in-process shards
-    (``local_shards`` > 1) -- used to prove that results do not depend on the sharding.
+    (``local_shards`` > 1) -- used to prove that results do not depend on the sharding.  ``mode="peer"``: the
+    ``local_shards`` engines of this process (one device) form a replica group (``demcz_peer_group``): every engine keeps its own
+    archive replica and publishes its K-boundary rows into the others' from inside its launches -- the schedule a multi-GPU run
+    uses over IPC (``demcz_comm_init``), rehearsed on one GPU; no exchange step on the host or in RCCL.
     """
     rank: int = 0
     world_size: int = 1
@@ -150,7 +153,10 @@ class _Runner:
         self.lag = int(append_lag)
         self.pending = []           # host exchange with lag: (visible_from_generation, rows)
         self.lib_exchange = sharding is not None and sharding.mode == "rccl" and sharding.world_size > 1
-        self.host_exchange = sharding is not None and not self.lib_exchange and (
+        self.peer_group = sharding is not None and sharding.mode == "peer"
+        if self.peer_group and (sharding.world_size != 1 or self.lag):
+            raise ValueError("mode='peer' groups the shards of ONE process and runs with append_lag 0")
+        self.host_exchange = sharding is not None and not self.lib_exchange and not self.peer_group and (
             sharding.total_shards > 1 or sharding.host_exchange_always)
         if self.host_exchange:
             for e in engines:
@@ -228,7 +234,7 @@ class _Runner:
 
     def rhat(self, g_from, g_to):
         """Rhat_gelman over all N_total chains, src/utils.jl:2-20."""
-        if not self.host_exchange:
+        if not self.host_exchange and len(self.engines) == 1:
             return self.engines[0].rhat(g_from, g_to)
         d = self.d
         n = (g_to - g_from + 1) // 2
@@ -370,6 +376,8 @@ def make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp,
         if rng_offset:
             e.set_rng_offset(rng_offset)
         engines.append(e)
+    if sh and sh.mode == "peer" and len(engines) > 1:
+        type(engines[0]).peer_group(engines)
     if sh and sh.mode == "rccl" and sh.world_size > 1:
         uid = engines[0].comm_unique_id() if sh.rank == 0 else None
         uid = sh.broadcast_bytes(uid)

@@ -217,6 +217,22 @@ int32_t demcz_end_generation(demcz_handle* h, int64_t g);
 int32_t demcz_comm_unique_id(void* unique_id_128B);
 int32_t demcz_comm_init(demcz_handle* h, const void* unique_id_128B, int32_t nranks, int32_t rank);
 
+/* Rows handed over INSIDE the launches (round 4).  After demcz_comm_init every rank's archive is opened by all other ranks
+ * over HIP IPC (fine-grained device memory), and a rank's publisher waves store a boundary's rows into every replica themselves,
+ * by write-through stores over xGMI; readers poll their own replica.  The all-gather + scatter per K-window is gone and a launch
+ * runs through many K boundaries, as on one GPU: the role of the reference's shared archive under pmap (src/demcz.jl:88-91, 137),
+ * without its race.  If IPC or peer access is refused on any rank, or a hand-off times out, the run falls back to the
+ * ncclAllGather exchange (same results).  DEMCZ_NO_PEER=1 in the environment keeps the exchange from the start.
+ *   demcz_get_peer_status   *mode = 0 exchange through RCCL (or unsharded), 1 replica group of this process, 2 IPC peers;
+ *                           *peers = replicas this handle publishes into besides its own.
+ *   demcz_peer_group        the same schedule for R handles of THIS process on ONE device (each with its own replica and shard:
+ *                           chain_id0 = r * N), so that a one-GPU machine can run and test it: the members publish into each
+ *                           other's replicas directly.  One host thread drives all members and gives every member the same
+ *                           demcz_run calls before it asks any of them for results; demcz_run_checked is not available.
+ *                           Destroying one member ends the group. */
+int32_t demcz_peer_group(demcz_handle** handles, int32_t R);
+int32_t demcz_get_peer_status(const demcz_handle* h, int32_t* mode, int32_t* peers);
+
 /* Deadline of every host-side wait of a sharded handle (a stream or event behind an RCCL collective): default 60 000 ms, or
  * the environment variable DEMCZ_COMM_TIMEOUT_MS at demcz_comm_init; 0 = wait for ever.  While it waits the library polls
  * ncclCommGetAsyncError about once a millisecond.  On expiry or on an asynchronous error: ncclCommAbort on the handle's

@@ -241,13 +241,67 @@ typedef struct oracle_problem {
     int64_t nobs;
 } oracle_problem;
 
+/* Whether the MvNormal sums are grouped by the blocks of the run: 2 <= Nblocks, and block b's index SET is the range
+ * [o_b, o_{b+1}) with o the running sum of the block lengths (the blocks, in order, cut 0..d-1 into consecutive pieces;
+ * the order of the indices inside a block does not matter).  Returns the number of groups (1: not grouped). */
+static int mvn_groups(const oracle_problem* p, int32_t* off /* Nblocks + 1 */)
+{
+    const int d = p->d;
+    if (p->Nblocks < 2 || p->Nblocks > d) return 1;
+    if (p->block_offsets[p->Nblocks] != d) return 1;
+    for (int b = 0; b < p->Nblocks; ++b) {
+        const int lo = p->block_offsets[b], hi = p->block_offsets[b + 1];
+        unsigned char seen[256] = {0};
+        for (int t = lo; t < hi; ++t) {
+            const int j = p->block_indices[t];
+            if (j < lo || j >= hi || seen[j - lo]) return 1;
+            seen[j - lo] = 1;
+        }
+        off[b] = lo;
+    }
+    off[p->Nblocks] = d;
+    return p->Nblocks;
+}
+
 /* logpdf(MvNormal(mu, Sigma), x) as test/example_normpdf.jl:13-16 defines the target:
- * c0 - 0.5 * || W (x - mu) ||^2 with W = L^-1, Sigma = L L'.  Summation order is the spec:
- * y_i = W[i,0] r_0, then fma over j = 1..i; q = y_0^2 then fma over i; logp = fma(-0.5, q, c0). */
+ * c0 - 0.5 * || W (x - mu) ||^2 with W = L^-1, Sigma = L L'.  Summation order is the spec.
+ *   One group (Nblocks == 1, or blocks that are not consecutive ranges -- every case of rounds 1-3):
+ *     y_i = W[i,0] r_0, then fma over j = 1..i; q = y_0^2 then fma over i; logp = fma(-0.5, q, c0).
+ *   Grouped by the blocks (round 4; mvn_groups): with groups g = [o_g, o_{g+1}),
+ *     P_ig = W[i,o_g] r_{o_g}, then fma over the further j of group g with j <= i      (the part of row i's dot product
+ *                                                                                        that block g's coordinates feed)
+ *     y_i  = P_i0 + P_i1 + ... + P_i,g(i)      plain additions, in group order, g(i) = the group of i
+ *     Q_g  = y_{o_g}^2, then fma(y_i, y_i, Q_g) over the further i of group g
+ *     q    = Q_0 + Q_1 + ...                   plain additions, in group order;   logp = fma(-0.5, q, c0).
+ *   Why: update_blocks (src/demcz.jl:167-172) moves ONE block per block-step and re-evaluates the whole log-density
+ *   (src/demcz.jl:189).  With the sums cut at the block boundaries a device kernel can keep P_ig and Q_g per chain and recompute
+ *   only what the moved block feeds -- and get the very doubles this full re-evaluation gives.  A sum of d products has no
+ *   canonical order in the reference (its arithmetic lives in Distributions / PDMats); with one group this is rounds 1-3's. */
 static double target_logp(const oracle_problem* p, const double* x)
 {
     const int d = p->d;
     if (p->target_kind == ORACLE_TARGET_MVNORMAL) {
+        int32_t off[258];
+        const int ng = (p->Nblocks + 1 <= 258) ? mvn_groups(p, off) : 1;
+        if (ng > 1) {
+            double q = 0.0;
+            for (int g = 0; g < ng; ++g) {
+                double Qg = 0.0;
+                for (int i = off[g]; i < off[g + 1]; ++i) {
+                    double y = 0.0;
+                    for (int gb = 0; gb <= g; ++gb) {
+                        const int jl = off[gb], jh = (off[gb + 1] - 1 < i) ? off[gb + 1] - 1 : i;
+                        double P = p->W[i + (int64_t)d * jl] * (x[jl] - p->mu[jl]);
+                        for (int j = jl + 1; j <= jh; ++j)
+                            P = fma(p->W[i + (int64_t)d * j], x[j] - p->mu[j], P);
+                        y = (gb == 0) ? P : y + P;
+                    }
+                    Qg = (i == off[g]) ? y * y : fma(y, y, Qg);
+                }
+                q = (g == 0) ? Qg : q + Qg;
+            }
+            return fma(-0.5, q, p->c0);
+        }
         double q = 0.0;
         for (int i = 0; i < d; ++i) {
             double acc = p->W[i] * (x[0] - p->mu[0]);

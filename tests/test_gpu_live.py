@@ -75,15 +75,17 @@ def test_forced_handoff_timeout_inside_run_checked(demc, oracle, layout):
     assert np.array_equal(cha, ref["chain"]) and np.array_equal(Za, ref["Z"])
 
 
-def test_one_live_handle_per_device(demc, oracle):
-    """Two handles on one GPU: the first keeps the device's LIVE slot, the second runs one launch per
-    K-window (its consumer waves could otherwise starve the first one's); both are bit-exact, and the slot
-    is free again once the first is destroyed."""
-    N, d, K, G = 256, 5, 5, 60
-    w = demc.workloads.mvnormal_problem(d, N)
-    a = _engine(demc, w, N, d, K, G, 7)
-    b = _engine(demc, w, N, d, K, G, 8)
-    a.run(1, G, w["gamma"])
+def test_live_budget_per_device(demc, oracle):
+    """The consumer waves of LIVE launches wait for each other, so what a process has in flight on a device must fit the chip at
+    once: every handle claims its share of the device's LIVE capacity (round 4: a budget, where there used to be one owner).
+    A 1024-chain handle takes all of it -- the next handle runs one launch per K-window -- two 256-chain handles share it; all
+    of them bit-exact, and a share is free again once its handle is destroyed."""
+    d, K, G = 5, 5, 60
+    wa = demc.workloads.mvnormal_problem(d, 1024)
+    w = demc.workloads.mvnormal_problem(d, 256)
+    a = _engine(demc, wa, 1024, d, K, G, 7)
+    b = _engine(demc, w, 256, d, K, G, 8)
+    a.run(1, G, wa["gamma"])
     b.run(1, G, w["gamma"])
     a.synchronize(); b.synchronize()
     assert a.live_status()[0] and not b.live_status()[0]
@@ -91,12 +93,17 @@ def test_one_live_handle_per_device(demc, oracle):
     cha, _ = a.get_history(1, G)
     chb, _ = b.get_history(1, G)
     a.close()
-    c = _engine(demc, w, N, d, K, G, 9)
-    c.run(1, G, w["gamma"]); c.synchronize()
-    assert c.live_status()[0]
-    b.close(); c.close()
-    for ch, seed in ((cha, 7), (chb, 8)):
-        ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed)
+    c = _engine(demc, w, 256, d, K, 2 * G, 9)
+    c.run(1, G, w["gamma"])
+    b2 = _engine(demc, w, 256, d, K, G, 10)
+    b2.run(1, G, w["gamma"])
+    c.synchronize(); b2.synchronize()
+    assert c.live_status()[0] and b2.live_status()[0], "two small handles share the budget"
+    chc, _ = c.get_history(1, G)
+    chb2, _ = b2.get_history(1, G)
+    b.close(); c.close(); b2.close()
+    for ch, seed, ww, n in ((cha, 7, wa, 1024), (chb, 8, w, 256), (chc, 9, w, 256), (chb2, 10, w, 256)):
+        ref = oracle_sample(oracle, ww["target"], ww["Zinit"], n, K, G, None, ww["eps_scale"], ww["gamma"], seed)
         assert np.array_equal(ch, ref["chain"])
 
 

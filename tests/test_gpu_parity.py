@@ -152,7 +152,8 @@ def test_host_closure_mode_equals_device_target(demc, oracle):
     trajectory equals the device-target run bit for bit."""
     d, N, G = 6, 24, 25
     w = demc.workloads.mvnormal_problem(d, N)
-    prob = oracle.Problem(1, d, 10, 10, w["eps_scale"], 0, target=w["target"].spec())
+    # (the oracle's log-density of a run with THESE blocks: its sums are cut at their boundaries, DESIGN.md section 3)
+    prob = oracle.Problem(1, d, 10, 10, w["eps_scale"], 0, blocks=BLOCKS_D6, target=w["target"].spec())
     closure = lambda x: float(oracle.logp(prob, x[None, :])[0])      # noqa: E731
     a, Za = demc.demcz_sample(closure, w["Zinit"], N, 10, G, 3, BLOCKS_D6, w["eps_scale"], 2.38, verbose=False, seed=3)
     b, Zb = demc.demcz_sample(w["target"], w["Zinit"], N, 10, G, 3, BLOCKS_D6, w["eps_scale"], 2.38, verbose=False, seed=3)
@@ -665,7 +666,7 @@ def test_host_closure_path_equals_oracle(demc, oracle, tempered):
     d, N, G, K, seed = 6, 21, 25, 5, 77
     w = demc.workloads.mvnormal_problem(d, N)
     blocks = [[0], [1, 2], [5, 3, 4]]
-    prob1 = oracle.Problem(1, d, K, 10, w["eps_scale"], 0, target=w["target"].spec())
+    prob1 = oracle.Problem(1, d, K, 10, w["eps_scale"], 0, blocks=blocks, target=w["target"].spec())      # (same blocks: same summation order)
     closure = lambda x: float(oracle.logp(prob1, np.asarray(x)[None, :])[0])
     T = _temps_with_zeros(G) if tempered else None
     if tempered:
