@@ -40,11 +40,12 @@ def algorithmic_bytes_per_update(d, K):
 
 def measured_traffic(n_loc, d, K, lanes, gens_per_launch):
     """HBM-side bytes per window-kernel launch from the committed rocprofv3 PMC passes of THIS command
-    (scripts/collect_profiles.sh + summarize_profiles.py: FETCH_SIZE and WRITE_SIZE in separate passes, KiB
-    units, gfx950 corrections as DESIGN.md section 6 describes).  A counter cannot be read from inside the
-    run it counts, so the figure comes from the profile file -- and is only reported when the profiled
-    launches had the shape of the launches just timed (same chains, d, K, layout, generations per launch);
-    otherwise null.  Returns (raw, fetch-doubled upper bound, source) or None."""
+    (scripts/collect_profiles.sh + collect_calibration.sh + summarize_profiles.py: FETCH_SIZE and WRITE_SIZE in separate
+    passes, KiB units, and FETCH_SIZE calibrated on the kernel's own two read patterns -- 64-byte row gathers are counted in
+    full, the draw-record pieces at half their bytes: profiles/fetch_calibration.json).  A counter cannot be read from inside
+    the run it counts, so the figure comes from the profile file -- and is only reported when the profiled launches had the
+    shape of the launches just timed (same chains, d, K, layout, generations per launch); otherwise null.
+    Returns (calibrated bytes per launch, source) or None."""
     f = ROOT / "profiles" / "latest_traffic.json"
     if not f.exists():
         return None
@@ -54,20 +55,9 @@ def measured_traffic(n_loc, d, K, lanes, gens_per_launch):
         return None
     if abs(float(shape.get("generations_per_launch", -1)) - gens_per_launch) > 1e-9:
         return None
-    # (the wave-per-chain layout's window launch is two kernels -- consumer, and producer half on a side stream: their sum)
-    prefixes = shape.get("kernel_prefixes") or [shape.get("kernel_prefix", "void demcz::window_kernel")]
-    raw = x2 = 0.0
-    found = 0
-    for pre in prefixes:
-        for k, v in prof["kernels"].items():
-            if k.startswith(pre):
-                raw += v.get("bytes_per_launch_raw") or 0.0
-                x2 += v.get("bytes_per_launch_fetch_x2") or 0.0
-                found += 1
-                break
-    if found != len(prefixes):
+    if shape.get("bytes_per_launch_calibrated") is None:
         return None
-    return raw, x2, f"profiles/{prof.get('tag')}_traffic.json"
+    return float(shape["bytes_per_launch_calibrated"]), f"profiles/{prof.get('tag')}_traffic.json"
 
 
 def throughput_point(demc, N, d, K, seed, gens, device_id):
@@ -589,10 +579,9 @@ def main():
         bytes_per_launch = B * n_loc * gens_per_launch
         avg_launch_s = (ev_ms / 1e3) / max(launches, 1)
         achieved = bytes_per_launch / avg_launch_s / 1e9
-        # PMC bytes per launch from the committed rocprofv3 passes of this same command; null unless the profiled
-        # launches had this shape.  `traffic` = FETCH_SIZE + WRITE_SIZE as counted; `traffic_fetch_x2` = the upper
-        # bound with every fetched byte doubled (MI355X_MICROARCH.md, HBM: gfx950 halves coalesced streaming reads)
-        traffic = measured_traffic(n_loc, d, K, lanes, gens_per_launch) or (None, None, None)
+        # PMC bytes per launch from the committed rocprofv3 passes of this same command, FETCH_SIZE calibrated on the kernel's own
+        # read patterns (one number); null unless the profiled launches had this shape
+        traffic = measured_traffic(n_loc, d, K, lanes, gens_per_launch) or (None, None)
         out = {
             "metric": "chain-updates/sec (N x gens/s) + gens-to-Rhat<1.05, MvNormal d=5 N=1024",
             "value": N * gens / dt, "unit": "chain-updates/s", "n_gpus": world, "steps": S, "warmup": W,
@@ -624,7 +613,8 @@ def main():
             "value_window_kernels_only": N * gens / (ev_ms / 1e3) if ev_ms > 0 else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "frac_of_measured_copy": achieved / 6290.0,        # MI355X_MICROARCH.md: 6.29 TB/s measured copy rate
-                         "traffic": traffic[0], "traffic_fetch_x2": traffic[1], "traffic_source": traffic[2],
+                         "traffic": traffic[0], "traffic_over_algorithmic": (traffic[0] / bytes_per_launch) if traffic[0] else None,
+                         "traffic_source": traffic[1],
                          "kernel": m["kernel"] + (f" (+ demcz::produce_kernel<{d}> beside it)" if lanes == 164 else ""),
                          "kernel_counts": m["kernel_counts"],
                          "launches": launches, "generations_per_launch": gens_per_launch,

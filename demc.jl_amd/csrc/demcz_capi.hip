@@ -922,6 +922,10 @@ static void peer_detach(demcz_handle* h)
         for (demcz_handle* m : G->members) { m->n_peers = 0; }
         if (G->members.empty()) delete G;
         h->group = nullptr;
+    } else if (h->peer_mode == 3) {
+        // (the host has made the ranks meet before this call: demcz_peer_export)
+        for (int r = 0; r < DEMCZ_MAX_PEERS; ++r)
+            if (h->ipc_mapped[r]) { (void)hipIpcCloseMemHandle(h->ipc_mapped[r]); h->ipc_mapped[r] = nullptr; }
     } else if (h->peer_mode == 2) {
         bool met = false;
         if (!h->comm_dead && h->comm && h->d_err_all) {
@@ -1815,6 +1819,11 @@ static int32_t live_verify(demcz_handle* h)
     int32_t rc = live_failed(h, failed);
     if (rc) return rc;
     if (!failed) { h->live_log.clear(); return DEMCZ_OK; }
+    if (h->peer_mode == 3) {
+        h->no_live = true;
+        return fail(h, DEMCZ_ERR_STATE, "a row another rank should have published never became visible (in-launch hand-off, host-mediated IPC peers): "
+                                        "results since the last verified point are void on every rank");
+    }
     std::vector<demcz_handle::RunCall> calls;
     rc = live_rollback(h, calls);
     if (rc) return rc;
@@ -2218,6 +2227,9 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         if (h->external_append && nb == 1 && (g_to % K) != 0)
             return fail(h, DEMCZ_ERR_STATE, "demcz_run: with external append the K boundary must be the last generation of the call");
     }
+    if (h->peer_mode == 3 && !peer)
+        return fail(h, DEMCZ_ERR_STATE, "demcz_run: host-mediated IPC peers run with the in-launch hand-off only (it is not available: a timed-out "
+                                        "hand-off, an append lag, caller-owned appends, or more chains than a LIVE launch holds)");
     if (h->peer_mode == 1 && !peer && !h->replaying) {
         // A replica group that lost (or never had) its in-launch hand-off: its members cannot exchange rows by themselves, so
         // the call is only logged here and executed for ALL members in lockstep, one launch per K-window, at the next
@@ -2677,6 +2689,18 @@ static int32_t rhat_enqueue(demcz_handle* h, int64_t g_from, int64_t g_to, doubl
             h->after_launch_ev = h->diag_ev;
         }
         qs = h->prod_stream;
+    } else if (side && h->comm && h->peer_mode == 2 && !h->no_live && h->comm_side && h->comm_stream && h->lag == 0) {
+        // sharded with the rows handed over inside the launches: nothing else of this handle uses the side communicator, and the
+        // compute stream carries no collective between two slabs -- the statistic goes beside the next slab
+        if (!h->diag_ev) HIPCHK(h, hipEventCreateWithFlags(&h->diag_ev, hipEventDisableTiming));
+        if (h->after_launch_ev) {
+            HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->after_launch_ev, 0));
+        } else {
+            HIPCHK(h, hipEventRecord(h->diag_ev, h->stream));
+            HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->diag_ev, 0));
+            h->after_launch_ev = h->diag_ev;
+        }
+        qs = h->comm_stream;
     } else if (side && !h->comm) {
         if (!h->diag_stream) HIPCHK(h, stream_acquire(h->cfg.device_id, &h->diag_stream));
         if (!h->diag_ev) HIPCHK(h, hipEventCreateWithFlags(&h->diag_ev, hipEventDisableTiming));
@@ -2704,15 +2728,16 @@ static int32_t rhat_enqueue(demcz_handle* h, int64_t g_from, int64_t g_to, doubl
     }
     // stage 0 -> all-reduce -> stage 1 with the grand mean formed on the device -> all-reduce ->
     // utils.jl:13-18 on the device: one copy and one synchronisation per check
-    hipLaunchKernelGGL(rhat_reduce_kernel, dim3(d), dim3(256), 0, h->stream, r.mean_j, r.s2_j, r.N, d, 0, (const double*)nullptr, 1.0, sums);
+    const ncclComm_t cq = (qs == h->comm_stream && qs != h->stream) ? h->comm_side : h->comm;
+    hipLaunchKernelGGL(rhat_reduce_kernel, dim3(d), dim3(256), 0, qs, r.mean_j, r.s2_j, r.N, d, 0, (const double*)nullptr, 1.0, sums);
     HIPCHK(h, hipGetLastError());
-    NCCLCHK(h, ncclAllReduce(sums, sums, (size_t)d, ncclDouble, ncclSum, h->comm, h->stream));
-    hipLaunchKernelGGL(rhat_reduce_kernel, dim3(d), dim3(256), 0, h->stream, r.mean_j, r.s2_j, r.N, d, 1, (const double*)sums, (double)m, sums + d);
+    NCCLCHK(h, ncclAllReduce(sums, sums, (size_t)d, ncclDouble, ncclSum, cq, qs));
+    hipLaunchKernelGGL(rhat_reduce_kernel, dim3(d), dim3(256), 0, qs, r.mean_j, r.s2_j, r.N, d, 1, (const double*)sums, (double)m, sums + d);
     HIPCHK(h, hipGetLastError());
-    NCCLCHK(h, ncclAllReduce(sums + d, sums + d, (size_t)2 * d, ncclDouble, ncclSum, h->comm, h->stream));
-    hipLaunchKernelGGL(rhat_final_kernel, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, h->stream, (const double*)(sums + d), d, (double)n, (double)m, sums + 3 * d);
+    NCCLCHK(h, ncclAllReduce(sums + d, sums + d, (size_t)2 * d, ncclDouble, ncclSum, cq, qs));
+    hipLaunchKernelGGL(rhat_final_kernel, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, qs, (const double*)(sums + d), d, (double)n, (double)m, sums + 3 * d);
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(out, sums + 3 * d, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(out, sums + 3 * d, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, qs));
     return DEMCZ_OK;
 }
 
@@ -3040,69 +3065,26 @@ extern "C" int32_t demcz_get_peer_status(const demcz_handle* h, int32_t* mode, i
     return DEMCZ_OK;
 }
 
-// demcz_comm_init, second half: every rank's archive becomes a fine-grained allocation of its own (coherent for writers on other
-// GPUs while kernels run), is exported with hipIpcGetMemHandle, the handles travel in one ncclAllGather, and every rank opens
-// the other ranks' archives.  Any refusal anywhere (an allocation flag, IPC, peer access) switches the mode off on ALL ranks
-// (min-reduced), and the run exchanges its rows through ncclAllGather as before.  Returns DEMCZ_OK either way unless the
-// communicator itself fails.
-static int32_t peer_setup_ipc(demcz_handle* h)
+// The archive moves into a fine-grained allocation of its own (coherent for writers on other GPUs while kernels run; the pool's
+// buffers are ordinary coarse-grained device memory), with whatever it -- and, in the arena, the record buffers behind it --
+// already holds (set_state may have run), and is exported with hipIpcGetMemHandle.  `ok` = false: an allocation flag or IPC
+// refused; the handle is unchanged then.
+static int32_t archive_make_fine(demcz_handle* h, hipIpcMemHandle_t* mh, bool* ok)
 {
-    const bool off = getenv("DEMCZ_NO_PEER") != nullptr;
-    const bool self = getenv("DEMCZ_PEER_SELF") != nullptr;      // a one-rank communicator walks the path too (tests)
-    const int R = h->nranks;
-    if (off || R > DEMCZ_MAX_PEERS + 1 || (R < 2 && !self)) return DEMCZ_OK;
-    HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->d_err_all, 4 * sizeof(unsigned int)));
-    HIPCHK(h, hipMemsetAsync(h->d_err_all, 0, 4 * sizeof(unsigned int), h->stream));
-    struct Rec { hipIpcMemHandle_t mh; int32_t ok; int32_t pad; };
-    static_assert(sizeof(Rec) % 8 == 0, "all-gather record");
-    Rec mine{};
-    mine.ok = peer_capable(h) ? 1 : 0;
+    *ok = false;
+    if (h->archive_fine) {
+        *ok = hipIpcGetMemHandle(mh, h->dZ) == hipSuccess;
+        if (!*ok) (void)hipGetLastError();
+        return DEMCZ_OK;
+    }
     double* fine = nullptr;
-    if (mine.ok) {
-        // the copy keeps whatever the archive (and, in the arena, the record buffers behind it) already holds: set_state may have run
-        if (hipExtMallocWithFlags((void**)&fine, h->dZ_bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); fine = nullptr; mine.ok = 0; }
-    }
-    if (mine.ok && hipIpcGetMemHandle(&mine.mh, fine) != hipSuccess) { (void)hipGetLastError(); mine.ok = 0; }
-    Rec* d_rec = nullptr;
-    HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&d_rec, sizeof(Rec) * (size_t)(R + 1)));
-    std::vector<Rec> all((size_t)R);
-    int32_t rc = DEMCZ_OK;
-    auto cleanup = [&]() { if (d_rec) (void)dev_free(h->cfg.device_id, d_rec); };
-    if (hipMemcpyAsync(d_rec + R, &mine, sizeof(Rec), hipMemcpyHostToDevice, h->stream) != hipSuccess) { cleanup(); if (fine) (void)hipFree(fine); return fail(h, DEMCZ_ERR_HIP, "demcz_comm_init: upload failed"); }
-    if (ncclAllGather(d_rec + R, d_rec, sizeof(Rec), ncclChar, h->comm, h->stream) != ncclSuccess) { cleanup(); if (fine) (void)hipFree(fine); return fail(h, DEMCZ_ERR_COMM, "demcz_comm_init: all-gather of the IPC handles failed"); }
-    rc = sync_stream(h, h->stream, "demcz_comm_init (IPC handles)");
-    if (rc == DEMCZ_OK && hipMemcpy(all.data(), d_rec, sizeof(Rec) * (size_t)R, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(h, DEMCZ_ERR_HIP, "demcz_comm_init: download failed");
-    if (rc) { cleanup(); if (fine) (void)hipFree(fine); return rc; }
-    unsigned int ok = 1u;
-    for (int r = 0; r < R; ++r) ok &= all[(size_t)r].ok ? 1u : 0u;
-    void* mapped[DEMCZ_MAX_PEERS] = {nullptr};
-    int nmap = 0;
-    if (ok) {
-        for (int r = 0; r < R && ok; ++r) {
-            if (r == h->rank) continue;
-            void* ptr = nullptr;
-            if (hipIpcOpenMemHandle(&ptr, all[(size_t)r].mh, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok = 0u; break; }
-            mapped[nmap++] = ptr;
-        }
-    }
-    // every rank must have opened every archive, or nobody uses any
-    unsigned int* d_ok = reinterpret_cast<unsigned int*>(d_rec);
-    if (hipMemcpyAsync(d_ok, &ok, sizeof(ok), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
-        ncclAllReduce(d_ok, d_ok, 1, ncclUint32, ncclMin, h->comm, h->stream) != ncclSuccess) rc = fail(h, DEMCZ_ERR_COMM, "demcz_comm_init: reduction failed");
-    if (rc == DEMCZ_OK) rc = sync_stream(h, h->stream, "demcz_comm_init (IPC agreement)");
-    unsigned int all_ok = 0u;
-    if (rc == DEMCZ_OK && hipMemcpy(&all_ok, d_ok, sizeof(all_ok), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(h, DEMCZ_ERR_HIP, "demcz_comm_init: download failed");
-    cleanup();
-    if (rc || !all_ok) {
-        for (int i = 0; i < nmap; ++i) (void)hipIpcCloseMemHandle(mapped[i]);
-        if (fine) (void)hipFree(fine);
-        return rc;
-    }
-    // switch the archive over: same contents, same offsets of what lives behind it in the arena
+    if (hipExtMallocWithFlags((void**)&fine, h->dZ_bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return DEMCZ_OK; }
+    if (hipIpcGetMemHandle(mh, fine) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(fine); return DEMCZ_OK; }
+    { int32_t rcq = quiesce_all(h); if (rcq) { (void)hipFree(fine); return rcq; } }
+    if (h->prod_stream) (void)hipStreamSynchronize(h->prod_stream);
     if (hipMemcpyAsync(fine, h->dZ, h->dZ_bytes, hipMemcpyDeviceToDevice, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
-        for (int i = 0; i < nmap; ++i) (void)hipIpcCloseMemHandle(mapped[i]);
         (void)hipFree(fine);
-        return fail(h, DEMCZ_ERR_HIP, "demcz_comm_init: copy into the fine-grained archive failed");
+        return fail(h, DEMCZ_ERR_HIP, "copy into the fine-grained archive failed");
     }
     rec_invalidate(h);
     const ptrdiff_t shift = reinterpret_cast<unsigned char*>(fine) - reinterpret_cast<unsigned char*>(h->dZ);
@@ -3114,10 +3096,125 @@ static int32_t peer_setup_ipc(demcz_handle* h)
     g_dev_pool.release(h->dZ, h->cfg.device_id);
     h->dZ = fine;
     h->archive_fine = true;
+    *ok = true;
+    return DEMCZ_OK;
+}
+
+// opens the other ranks' archives (handles in rank order, this rank's own skipped); all or nothing
+static bool peers_open(demcz_handle* h, const hipIpcMemHandle_t* handles, int R, int rank)
+{
+    void* mapped[DEMCZ_MAX_PEERS] = {nullptr};
+    int nmap = 0;
+    for (int r = 0; r < R; ++r) {
+        if (r == rank) continue;
+        void* ptr = nullptr;
+        if (hipIpcOpenMemHandle(&ptr, handles[r], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+            (void)hipGetLastError();
+            for (int i = 0; i < nmap; ++i) (void)hipIpcCloseMemHandle(mapped[i]);
+            return false;
+        }
+        mapped[nmap++] = ptr;
+    }
     for (int i = 0; i < nmap; ++i) { h->ipc_mapped[i] = mapped[i]; h->peer_Z[i] = reinterpret_cast<double*>(mapped[i]); }
     h->n_peers = nmap;
+    return true;
+}
+
+// demcz_comm_init, second half: every rank's archive becomes a fine-grained allocation of its own, its IPC handle travels in one
+// ncclAllGather, and every rank opens the other ranks' archives.  Any refusal anywhere (an allocation flag, IPC, peer access)
+// switches the mode off on ALL ranks (min-reduced), and the run exchanges its rows through ncclAllGather as before.  Returns
+// DEMCZ_OK either way unless the communicator itself fails.
+static int32_t peer_setup_ipc(demcz_handle* h)
+{
+    const bool off = getenv("DEMCZ_NO_PEER") != nullptr;
+    const bool self = getenv("DEMCZ_PEER_SELF") != nullptr;      // a one-rank communicator walks the path too (tests)
+    const int R = h->nranks;
+    if (off || R > DEMCZ_MAX_PEERS + 1 || (R < 2 && !self)) return DEMCZ_OK;
+    HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->d_err_all, 4 * sizeof(unsigned int)));
+    HIPCHK(h, hipMemsetAsync(h->d_err_all, 0, 4 * sizeof(unsigned int), h->stream));
+    struct Rec { hipIpcMemHandle_t mh; int32_t ok; int32_t pad; };
+    static_assert(sizeof(Rec) % 8 == 0, "all-gather record");
+    Rec mine{};
+    if (peer_capable(h)) {
+        bool okf = false;
+        int32_t rcf = archive_make_fine(h, &mine.mh, &okf);
+        if (rcf) return rcf;
+        mine.ok = okf ? 1 : 0;
+    }
+    Rec* d_rec = nullptr;
+    HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&d_rec, sizeof(Rec) * (size_t)(R + 1)));
+    std::vector<Rec> all((size_t)R);
+    int32_t rc = DEMCZ_OK;
+    auto cleanup = [&]() { if (d_rec) (void)dev_free(h->cfg.device_id, d_rec); };
+    if (hipMemcpyAsync(d_rec + R, &mine, sizeof(Rec), hipMemcpyHostToDevice, h->stream) != hipSuccess) { cleanup(); return fail(h, DEMCZ_ERR_HIP, "demcz_comm_init: upload failed"); }
+    if (ncclAllGather(d_rec + R, d_rec, sizeof(Rec), ncclChar, h->comm, h->stream) != ncclSuccess) { cleanup(); return fail(h, DEMCZ_ERR_COMM, "demcz_comm_init: all-gather of the IPC handles failed"); }
+    rc = sync_stream(h, h->stream, "demcz_comm_init (IPC handles)");
+    if (rc == DEMCZ_OK && hipMemcpy(all.data(), d_rec, sizeof(Rec) * (size_t)R, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(h, DEMCZ_ERR_HIP, "demcz_comm_init: download failed");
+    if (rc) { cleanup(); return rc; }
+    unsigned int ok = 1u;
+    for (int r = 0; r < R; ++r) ok &= all[(size_t)r].ok ? 1u : 0u;
+    if (ok) {
+        std::vector<hipIpcMemHandle_t> hs((size_t)R);
+        for (int r = 0; r < R; ++r) hs[(size_t)r] = all[(size_t)r].mh;
+        ok = peers_open(h, hs.data(), R, h->rank) ? 1u : 0u;
+    }
+    // every rank must have opened every archive, or nobody uses any
+    unsigned int* d_ok = reinterpret_cast<unsigned int*>(d_rec);
+    if (hipMemcpyAsync(d_ok, &ok, sizeof(ok), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        ncclAllReduce(d_ok, d_ok, 1, ncclUint32, ncclMin, h->comm, h->stream) != ncclSuccess) rc = fail(h, DEMCZ_ERR_COMM, "demcz_comm_init: reduction failed");
+    if (rc == DEMCZ_OK) rc = sync_stream(h, h->stream, "demcz_comm_init (IPC agreement)");
+    unsigned int all_ok = 0u;
+    if (rc == DEMCZ_OK && hipMemcpy(&all_ok, d_ok, sizeof(all_ok), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(h, DEMCZ_ERR_HIP, "demcz_comm_init: download failed");
+    cleanup();
+    if (rc || !all_ok) {
+        for (int i = 0; i < DEMCZ_MAX_PEERS; ++i) if (h->ipc_mapped[i]) { (void)hipIpcCloseMemHandle(h->ipc_mapped[i]); h->ipc_mapped[i] = nullptr; }
+        h->n_peers = 0;
+        return rc;
+    }
     h->peer_mode = 2;
     h->peer_fence = true;
+    // a second communicator and stream for the monitoring R-hat of a finished slab (rhat_enqueue): its two small all-reduces then
+    // run beside the next slab's launch instead of holding every rank's compute stream until all ranks have joined
+    // (collective: every rank is here -- the agreement above was unanimous)
+    if (!h->comm_stream) HIPCHK(h, stream_acquire(h->cfg.device_id, &h->comm_stream));
+    if (!h->comm_side) NCCLCHK(h, ncclCommSplit(h->comm, 0, h->rank, &h->comm_side, nullptr));
+    return DEMCZ_OK;
+}
+
+// The same set-up with the HOST carrying the handles (any transport: torch.distributed, MPI, Distributed.jl) and doing the two
+// things a communicator does in mode 2: the ranks must meet (a barrier of the host's) between demcz_set_state and the first
+// demcz_run, and between the last synchronising call and demcz_destroy; and a hand-off that timed out is an error on the rank
+// that saw it (DEMCZ_ERR_STATE), not an automatic redo -- the ranks have no way here to agree on one.
+extern "C" int32_t demcz_peer_export(demcz_handle* h, int32_t nranks, int32_t rank, void* handle_64B)
+{
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    if (!h || !handle_64B || nranks < 2 || nranks > DEMCZ_MAX_PEERS + 1 || rank < 0 || rank >= nranks) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (h->comm || h->peer_mode != 0) return fail(h, DEMCZ_ERR_STATE, "demcz_peer_export: handle is already sharded");
+    if (!peer_capable(h)) return fail(h, DEMCZ_ERR_STATE, "demcz_peer_export: this layout has no in-launch hand-off");
+    if (h->cfg.chain_id0 != (int64_t)rank * h->cfg.N) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_peer_export: chain_id0 must be rank * N");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    if (!h->live_log.empty()) { int32_t rcv = live_verify(h); if (rcv) return rcv; }
+    hipIpcMemHandle_t mh;
+    bool ok = false;
+    int32_t rc = archive_make_fine(h, &mh, &ok);
+    if (rc) return rc;
+    if (!ok) return fail(h, DEMCZ_ERR_HIP, "demcz_peer_export: fine-grained allocation or hipIpcGetMemHandle refused");
+    std::memcpy(handle_64B, &mh, sizeof(mh));
+    h->nranks = nranks;
+    h->rank = rank;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_peer_attach(demcz_handle* h, const void* handles_64B_each)
+{
+    if (!h || !handles_64B_each) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (!h->archive_fine || h->peer_mode != 0 || h->nranks < 2) return fail(h, DEMCZ_ERR_STATE, "demcz_peer_attach: call demcz_peer_export first");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    std::vector<hipIpcMemHandle_t> hs((size_t)h->nranks);
+    std::memcpy(hs.data(), handles_64B_each, sizeof(hipIpcMemHandle_t) * (size_t)h->nranks);
+    if (!peers_open(h, hs.data(), h->nranks, h->rank)) return fail(h, DEMCZ_ERR_HIP, "demcz_peer_attach: hipIpcOpenMemHandle refused (peer access between the devices?)");
+    h->peer_mode = 3;
+    rec_invalidate(h);
     return DEMCZ_OK;
 }
 
@@ -3455,6 +3552,7 @@ static int32_t run_checked_body(demcz_handle* h, int64_t g_from, int64_t g_to, d
     if (rc == DEMCZ_OK) rc = sync_stream(h, h->stream, "demcz_run_checked");
     if (rc == DEMCZ_OK && h->diag_stream) rc = sync_stream(h, h->diag_stream, "demcz_run_checked");
     if (rc == DEMCZ_OK && h->prod_stream) rc = sync_stream(h, h->prod_stream, "demcz_run_checked");
+    if (rc == DEMCZ_OK && h->comm_stream) rc = sync_stream(h, h->comm_stream, "demcz_run_checked");
     if (rc == DEMCZ_OK) {
         for (int32_t i = 0; i < checks; ++i)
             if (rhat_max && i < n_max) rhat_max[i] = max_of(pinned + (size_t)i * d);
@@ -3472,7 +3570,7 @@ extern "C" int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_
     DEADCHK(h);
     if (every < 4 || g_from < 1 || g_to < g_from) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_run_checked: need every >= 4 and 1 <= g_from <= g_to");
     if (!h->has_state) return fail(h, DEMCZ_ERR_STATE, "demcz_run_checked: call demcz_set_state first");
-    if (h->peer_mode == 1) return fail(h, DEMCZ_ERR_STATE, "demcz_run_checked: members of a replica group are driven call by call (demcz_run, demcz_rhat_partial)");
+    if (h->peer_mode == 1 || h->peer_mode == 3) return fail(h, DEMCZ_ERR_STATE, "demcz_run_checked: replica groups and host-mediated peers are driven call by call (demcz_run, demcz_rhat_partial)");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     // everything before this call is verified first, so that a failed LIVE hand-off inside it rolls back to HERE
     int32_t rc = live_verify(h);

@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
                 // The chain waves reach their boundaries at different moments.  Looking for ready rows only once the
                 // store before this one is complete lets the rows that arrived during its flight leave TOGETHER (a store
                 // issued at once would sit behind the earlier one just as long, with one row in it).
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                publisher_wait(P);
                 const unsigned int seq = __hip_atomic_load(&pub_seq[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const bool ready = pl && seq != done;
                 if (__builtin_amdgcn_ballot_w64(ready) != 0ull) {

@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             const int64_t cl = (int64_t)bxs * PS_CHAINS + cw;
             unsigned int done = 0u;
             while (true) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                publisher_wait(P);
                 const unsigned int seq = __hip_atomic_load(&pub_seq[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const bool ready = pl && seq != done;
                 if (__builtin_amdgcn_ballot_w64(ready) != 0ull) {

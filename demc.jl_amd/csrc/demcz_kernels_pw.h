@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
 #pragma unroll
             for (int t = 0; t < NPL; ++t) done[t] = 0u;
             while (true) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                publisher_wait(P);
                 bool any = false, allgone = true;
 #pragma unroll
                 for (int t = 0; t < NPL; ++t) {

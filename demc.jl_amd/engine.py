@@ -329,6 +329,18 @@ class HipEngine:
             msgs = [(L.demcz_last_error(e._h) or b"").decode() for e in engines]
             raise DemczError(rc, next((m for m in msgs if m), ""))
 
+    def peer_export(self, nranks: int, rank: int) -> bytes:
+        """demcz_peer_export: the archive becomes fine-grained, IPC-exportable memory; returns its 64-byte handle."""
+        buf = C.create_string_buffer(64)
+        self._chk(self._L.demcz_peer_export(self._h, int(nranks), int(rank), buf))
+        return buf.raw
+
+    def peer_attach(self, handles):
+        """demcz_peer_attach: `handles` = the 64-byte handles of all ranks in rank order (this rank's own included)."""
+        blob = b"".join(handles)
+        buf = C.create_string_buffer(blob, len(blob))
+        self._chk(self._L.demcz_peer_attach(self._h, buf))
+
     def peer_status(self):
         """(mode, peers): mode 0 = RCCL exchange or unsharded, 1 = replica group of this process, 2 = IPC peers."""
         m, n = C.c_int32(0), C.c_int32(0)

@@ -223,7 +223,8 @@ int32_t demcz_comm_init(demcz_handle* h, const void* unique_id_128B, int32_t nra
  * runs through many K boundaries, as on one GPU: the role of the reference's shared archive under pmap (src/demcz.jl:88-91, 137),
  * without its race.  If IPC or peer access is refused on any rank, or a hand-off times out, the run falls back to the
  * ncclAllGather exchange (same results).  DEMCZ_NO_PEER=1 in the environment keeps the exchange from the start.
- *   demcz_get_peer_status   *mode = 0 exchange through RCCL (or unsharded), 1 replica group of this process, 2 IPC peers;
+ *   demcz_get_peer_status   *mode = 0 exchange through RCCL (or unsharded), 1 replica group of this process, 2 IPC peers, 3 IPC peers
+ *                           set up by the host (demcz_peer_export / demcz_peer_attach);
  *                           *peers = replicas this handle publishes into besides its own.
  *   demcz_peer_group        the same schedule for R handles of THIS process on ONE device (each with its own replica and shard:
  *                           chain_id0 = r * N), so that a one-GPU machine can run and test it: the members publish into each
@@ -232,6 +233,15 @@ int32_t demcz_comm_init(demcz_handle* h, const void* unique_id_128B, int32_t nra
  *                           Destroying one member ends the group. */
 int32_t demcz_peer_group(demcz_handle** handles, int32_t R);
 int32_t demcz_get_peer_status(const demcz_handle* h, int32_t* mode, int32_t* peers);
+/* The IPC set-up with the HOST carrying the 64-byte handles (torch.distributed, MPI, Distributed.jl ...) instead of RCCL -- for
+ * hosts that shard without the library's communicator, and what lets two PROCESSES on one GPU test the cross-process half of the
+ * path (mode 3 of demcz_get_peer_status).  demcz_peer_export moves the archive into fine-grained memory and returns its IPC
+ * handle; the host all-gathers the handles; demcz_peer_attach(handles: nranks x 64 bytes in rank order) opens the others'.  The
+ * host then owes two meetings of all ranks (barriers): after demcz_set_state / before the first demcz_run, and after the last
+ * synchronising call / before demcz_destroy.  A hand-off that times out is DEMCZ_ERR_STATE on the rank that saw it: there is
+ * no automatic redo in this mode. */
+int32_t demcz_peer_export(demcz_handle* h, int32_t nranks, int32_t rank, void* handle_64B);
+int32_t demcz_peer_attach(demcz_handle* h, const void* handles_64B_each);
 
 /* Deadline of every host-side wait of a sharded handle (a stream or event behind an RCCL collective): default 60 000 ms, or
  * the environment variable DEMCZ_COMM_TIMEOUT_MS at demcz_comm_init; 0 = wait for ever.  While it waits the library polls

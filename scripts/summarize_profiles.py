@@ -5,11 +5,15 @@
                            bench -- the shape of the profiled launches (chains, d, K, layout, generations per launch)
                            that bench.py compares its own launches with before it reports `roofline.traffic`
 Correction (MI355X_MICROARCH.md, HBM section): counters are in KiB; on gfx950 FETCH_SIZE reports
-half the bytes of a coalesced streaming read, WRITE_SIZE is exact.  Calibration in THIS access
-pattern: rhat_moments_kernel streams a known byte count (N*d*w*8, 8 B per lane, coalesced) and
-its FETCH_SIZE reads exactly half of it, so streaming kernels get x2; the window kernel's reads
-are single-line random gathers (one 64-byte request per row) for which the raw count matches the
-lines touched, so it is reported raw with the x2 figure beside it as an upper bound.
+half the bytes of a coalesced streaming read, WRITE_SIZE is exact.  Calibration of the window
+kernel's OWN two read patterns (round 4: scripts/probes/fetch_calibration.hip through
+scripts/collect_calibration.sh <tag>): random 64-byte-row gathers of three 16-byte pieces are counted
+in full as lines (factor ~1.00 of rows x 64 B); the draw-record pieces (16 bytes a lane, consecutive
+lanes consecutive addresses, every byte of a (field, chain) row once) are counted at ~0.51 of their
+bytes -- like the plain stream (0.50).  The consumer's FETCH_SIZE is the sum of the two, and the record
+bytes of a launch are known exactly ((d + 2) x chains x generations x 8), so
+    fetched = (FETCH_SIZE - f_records x record_bytes) / f_gather + record_bytes
+and `bytes_per_launch_calibrated` = that + WRITE_SIZE (+ the producer kernel's WRITE_SIZE).
 usage: summarize_profiles.py <tag> [latest]      (`latest`: also write profiles/latest_traffic.json, the file bench.py reads)"""
 import csv, glob, json, shutil, sys, collections
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
@@ -35,6 +39,34 @@ for k, v in out.items():
     v["bytes_per_launch_raw"] = (f_ + w_) * 1024
     v["bytes_per_launch_fetch_x2"] = (2 * f_ + w_) * 1024
 doc = {"tag": tag, "kernels": out}
+# calibration factors: FETCH_SIZE of the probe's kernels / their known bytes (this tag's passes, else the last ones kept)
+cal = None
+try:
+    known = None
+    for ln in open(f"gpurun_out/{tag}_cal.json"):
+        if ln.startswith("{"):
+            known = json.loads(ln)
+    fc = glob.glob(f"gpurun_out/{tag}_cal/*/*counter_collection.csv")
+    if known and fc:
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(fc[0])):
+            if r["Counter_Name"] == "FETCH_SIZE":
+                agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]) * 1024.0)
+        mean = {k: sum(v) / len(v) for k, v in agg.items()}
+        cal = {"f_gather_per_line_byte": mean["cal_gather"] / known["cal_gather"]["lines_bytes"],
+               "f_records_per_unique_byte": mean["cal_records"] / known["cal_records"]["unique_bytes"],
+               "f_stream": mean["cal_stream"] / known["cal_stream"]["unique_bytes"],
+               "probe": "scripts/probes/fetch_calibration.hip", "known_bytes": known,
+               "FETCH_SIZE_bytes": {k: mean[k] for k in ("cal_gather", "cal_records", "cal_stream")}}
+        json.dump(cal, open("profiles/fetch_calibration.json", "w"), indent=1, sort_keys=True)
+except FileNotFoundError:
+    pass
+if cal is None:
+    try:
+        cal = json.load(open("profiles/fetch_calibration.json"))
+    except FileNotFoundError:
+        cal = None
+doc["calibration"] = cal
 # the bench's own JSON line (under the trace pass) tells what the profiled launches looked like
 shape = None
 try:
@@ -52,6 +84,26 @@ try:
 except FileNotFoundError:
     pass
 if shape:
+    if cal:
+        # one calibrated number per launch of the window kernel (+ its producer beside it)
+        rec_bytes = (shape["dim"] + 2) * shape["chains"] * shape["generations_per_launch"] * 8.0
+        tot = 0.0
+        parts = {}
+        for pre in shape["kernel_prefixes"]:
+            for k, v in out.items():
+                if k.startswith(pre):
+                    f_, w_ = v.get("FETCH_SIZE_KiB_per_launch_mean", 0.0) * 1024.0, v.get("WRITE_SIZE_KiB_per_launch_mean", 0.0) * 1024.0
+                    if "window_kernel" in k:
+                        fetched = (f_ - cal["f_records_per_unique_byte"] * rec_bytes) / cal["f_gather_per_line_byte"] + rec_bytes
+                        parts[k] = {"fetch_calibrated": fetched, "of_which_records": rec_bytes, "write": w_}
+                    else:
+                        fetched = f_ / max(cal["f_stream"], 1e-9)
+                        parts[k] = {"fetch_calibrated": fetched, "write": w_}
+                    v["bytes_per_launch_calibrated"] = fetched + w_
+                    tot += fetched + w_
+                    break
+        shape["bytes_per_launch_calibrated"] = tot
+        shape["calibrated_parts"] = parts
     doc["launch_shape"] = shape
     # the warm-up call's first launch of the LIVE instantiation and the timed ones have the same shape; PMC means are over all of them
 json.dump(doc, open(f"profiles/{tag}_traffic.json", "w"), indent=1, sort_keys=True)

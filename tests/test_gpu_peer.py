@@ -234,3 +234,39 @@ def test_ipc_set_up_with_a_one_rank_communicator(demc, oracle, monkeypatch):
     e.close()
     ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed)
     assert np.array_equal(ch, ref["chain"]) and np.array_equal(Z, ref["Z"])
+
+
+@pytest.mark.parametrize("d,pieces", [(5, "600,400"), (20, "300")])
+def test_two_processes_on_one_gpu_hand_rows_over_through_ipc(demc, oracle, tmp_path, d, pieces):
+    """The cross-PROCESS half of the multi-GPU path, as far as one GPU can show it: two processes, each with its own HIP context,
+    its own archive replica in fine-grained memory and half of the chains; each opens the other's archive with
+    hipIpcOpenMemHandle (demcz_peer_export / demcz_peer_attach, the 64-byte handles carried by gloo) and its publisher waves
+    store every boundary's rows into both replicas from inside its launches; readers poll their own replica.  What this cannot
+    show is the store crossing xGMI to ANOTHER GPU's memory.  Both ranks' results: the oracle's unsharded run, bit for bit."""
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 2
+    case = str(Path(__file__).resolve().parent / "peer_ipc_case.py")
+    procs = [subprocess.Popen([sys.executable, case, str(r), str(world), str(port), str(tmp_path), str(d), pieces],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, (p.returncode, so[-1500:], se[-3000:])
+    N, K, seed = 1024, 10, 2024 + d
+    G = sum(int(v) for v in pieces.split(","))
+    w = demc.workloads.mvnormal_problem(d, N)
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed, threads=THREADS)
+    rs = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for r in rs:
+        assert (int(r["mode"]), int(r["peers"])) == (3, 1) and int(r["live"]) == 1 and int(r["redos"]) == 0
+        assert int(r["launches"]) <= 6, "LIVE launches through the boundaries: a handful per run"
+        assert int(r["M"]) == ref["M"] and np.array_equal(r["Z"], ref["Z"]), "a replica differs from the oracle's archive"
+    assert np.array_equal(np.concatenate([r["chain"] for r in rs], axis=0), ref["chain"])
+    assert np.array_equal(np.concatenate([r["log_obj"] for r in rs], axis=0), ref["log_obj"])
+    assert np.array_equal(np.concatenate([r["X"] for r in rs], axis=0), ref["X"])
