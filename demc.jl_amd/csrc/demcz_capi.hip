@@ -1250,10 +1250,27 @@ static void launch_ps(const demcz_handle* h, const WindowParams& P, int64_t bloc
     }
 }
 
+// d = 20, MvNormal, LIVE: candidates and log-densities on the FP64 matrix instruction (demcz_kernels_pw.h, MF).  Built, bit-exact
+// (tests/test_gpu_long_oracle.py) -- and measured 4 % SLOWER than the scalar form at C4's shard (6.55-6.60 against 6.2-6.4 us
+// per K-window, interleaved runs, profiles/r04i_pw_mfma.txt): 36 matrix instructions at 65 clocks each are the vector rate,
+// as DESIGN.md section 9 had costed.  Kept behind DEMCZ_PW_MFMA=1 as the measured experiment; off by default.
+static bool pw_matrix_form(const demcz_handle* h)
+{
+    const char* on = getenv("DEMCZ_PW_MFMA");
+    return on && atoi(on) != 0 && h->cfg.d == 20 && h->cfg.target_kind == DEMCZ_TARGET_MVNORMAL;
+}
+
 template <int TARGET, int D>
 static void launch_pw(const demcz_handle* h, const WindowParams& P, int64_t blocks, bool live)
 {
     const dim3 grid((unsigned)blocks), wg(64 * PS_CHAINS), wgl(64 * (PS_CHAINS + 1));
+    if constexpr (D == 20 && TARGET == TARGET_MVNORMAL) {
+        if (live && pw_matrix_form(h)) {
+            if (P.temperature) hipLaunchKernelGGL((window_kernel_pw<TARGET, D, true, true, true>), grid, wgl, 0, h->stream, P);
+            else hipLaunchKernelGGL((window_kernel_pw<TARGET, D, true, false, true>), grid, wgl, 0, h->stream, P);
+            return;
+        }
+    }
     if (P.temperature) {
         if (live) hipLaunchKernelGGL((window_kernel_pw<TARGET, D, true, true>), grid, wgl, 0, h->stream, P);
         else hipLaunchKernelGGL((window_kernel_pw<TARGET, D, false, true>), grid, wg, 0, h->stream, P);
@@ -1979,7 +1996,14 @@ static int pw_live_blocks_per_cu()
     int a = 0, b = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, D, true, false>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) a = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, D, true, true>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) b = 0;
-    return std::min(a, b);
+    int m = std::min(a, b);
+    if constexpr (D == 20) {        // (the matrix form of the same launches)
+        int c = 0, e = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, D, true, false, true>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) c = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&e, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, D, true, true, true>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) e = 0;
+        m = std::min(m, std::min(c, e));
+    }
+    return m;
 }
 
 static int64_t live_wg_capacity(demcz_handle* h)
@@ -3634,6 +3658,7 @@ extern "C" int32_t demcz_debug_kernel_name(const demcz_handle* h, char* buf, int
     if (h->lanes == DEMCZ_LAYOUT_SPLIT) {
         if (h->lr_spec) snprintf(tmp, sizeof tmp, "window_kernel_lr8s<%d, %s>", d, lv);
         else if (h->split_kind == 4 && d <= 5) snprintf(tmp, sizeof tmp, "%s<%s, %d, %s, %s>", h->last_ps2 ? "window_kernel_ps2" : "window_kernel_ps", tg, d, lv, tm);
+        else if (h->split_kind == 4 && h->last_live && pw_matrix_form(h)) snprintf(tmp, sizeof tmp, "window_kernel_pw<%s, %d, %s, %s, true>", tg, d, lv, tm);
         else if (h->split_kind == 4) snprintf(tmp, sizeof tmp, "window_kernel_pw<%s, %d, %s, %s>", tg, d, lv, tm);
         else if (h->split_kind == 3 && h->mlb_qb > 0 && h->split_lanes == 16) snprintf(tmp, sizeof tmp, "window_kernel_mlb<%s, %d, %d, true, %s, %d>", tg, d, h->split_lanes, lv, h->mlb_qb);
         else if (h->split_kind == 3) snprintf(tmp, sizeof tmp, "window_kernel_mlb<%s, %d, %d, true, %s>", tg, d, h->split_lanes, lv);

@@ -23,11 +23,25 @@
 
 namespace demcz {
 
-template <int TARGET, int D, bool LIVE, bool TEMPER>
+// MF (round 4; MvNormal, d = 20, LIVE launches): the 31 candidates of a pass and their log-densities on the FP64 matrix
+// instruction, v_mfma_f64_16x16x4_f64, whose accumulation IS the sequential fma chain, k ascending (scripts/probes/
+// mfma_f64_order.hip) -- so the doubles are the oracle's:
+//   candidates   C = x 1' + Delta T      Delta (d x 5: the pass's increments), T (5 x 32: 1.0 where node j's path takes generation u):
+//                c_pj = fma(delta_pu, t_uj, c_pj), u ascending = ((x + d_1) + d_2) ... with "+ 0 * delta" where the serial order
+//                adds -0.0 (equal unless a coordinate is exactly -0.0);
+//   whitening    Y = W R,  R = C - mu 1' : the accumulator layout of C (lane l, element v <-> parameter 4 v + l / 16, candidate l % 16)
+//                IS the B-operand layout of the next product, so R never leaves the registers; W's tiles (zero above the
+//                diagonal: fma(0, r_j, y) = y) sit in nine registers;
+//   q            the DIAGONAL of Y' Y by the same trick (A = B = Y's accumulator elements): q_j = fma(y_ij, y_ij, q_j), i ascending.
+// 8 + 18 + 10 matrix instructions (65 clocks each) replace 100 adds behind 50 LDS reads and 210 fmas behind 27 scalar loads, on
+// all 64 lanes instead of 31.  A non-finite increment (0 * inf) would poison candidates that do not take it: such a pass flags
+// the launch, and the library redoes it with the scalar kernels (live_verify) -- the reason this form is LIVE-only.
+template <int TARGET, int D, bool LIVE, bool TEMPER, bool MF = false>
 __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_kernel_pw(const WindowParams P)
 {
     static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "split layout: MvNormal / isotropic targets");
     static_assert(D >= 6 && D <= 24, "d <= 5: window_kernel_ps");
+    static_assert(!MF || (LIVE && TARGET == TARGET_MVNORMAL && D > 16 && D <= 20 && PS_R == 5), "matrix form: MvNormal, 16 < d <= 20, LIVE");
     constexpr int HW = (D + 1) / 2;                        // 16-byte pieces of an archive row
     constexpr int ZSC = ((D + 7) / 8) * 8;                 // archive row stride in doubles (demcz_create: ZS)
     constexpr int DP = ((D + 1) / 2) * 2;                  // increments row in LDS
@@ -141,6 +155,32 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         }
     }
     const bool nodel = lane >= 1 && lane < 32;
+    // MF: what this lane is in the matrix instruction's layouts: g = lane / 16 (k index of the A / B operands, row group of the
+    // accumulator), c16 = lane % 16 (row of A, column of B and of the accumulator)
+    typedef double mf4 __attribute__((ext_vector_type(4)));
+    [[maybe_unused]] const int mg = lane >> 4, mc = lane & 15;
+    [[maybe_unused]] double mT[2][2], mW[2][5], mmu0[4], mmu1;
+    if constexpr (MF) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int j = 16 * ct + mc, u1 = 4 * ks + mg + 1;           // candidate, generation (1-based) of the pass
+                const int lj = j ? 32 - __builtin_clz((unsigned)j) : 0;
+                const bool take = j != 0 && u1 <= PS_R && ((u1 == lj) || (u1 < lj && ((j >> (lj - 1 - u1)) & 1)));
+                mT[ct][ks] = take ? 1.0 : 0.0;
+            }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ks = 0; ks < 5; ++ks) {
+                const int i = 16 * rt + mc, j = 4 * ks + mg;
+                mW[rt][ks] = (i < D && j <= i) ? P.tp.Wp[(i * (i + 1)) / 2 + j] : 0.0;
+            }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) mmu0[v] = P.tp.mu[4 * v + mg];
+        mmu1 = (16 + mg < D) ? P.tp.mu[16 + mg] : 0.0;
+    }
     const int lgo = (FL0 + 3 * D) * 16 + (lev - 1) * 8;
     [[maybe_unused]] const int tko = TL0 * 16 + (lev - 1) * 8;
     const int ixo = (FL0 + 3 * (D + 1)) * 16;
@@ -411,8 +451,46 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         const double logu_c = logu;
         [[maybe_unused]] const double temp_c = temp;
         wave_lds_handoff();
+        [[maybe_unused]] mf4 macc[2][2];          // MF: candidates, then residuals: [row tile][column tile]
+        if constexpr (MF) {
+            // C = x 1' + Delta T: the state down the accumulator's rows, the pass's increments as the A operand
+            lp = ct_w[D];
+            mf4 x0, x1;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) x0[v] = ct_w[4 * v + mg];
+            x1[0] = (16 + mg < D) ? ct_w[16 + mg] : 0.0; x1[1] = 0.0; x1[2] = 0.0; x1[3] = 0.0;
+            double da[2][2];
+            bool nonfinite = false;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int pp = 16 * rt + mc, u = 4 * ks + mg;
+                    const bool ok = pp < D && u < PS_R;
+                    da[rt][ks] = ok ? sd_w[(ok ? u : 0) * DP + (ok ? pp : 0)] : 0.0;
+                    nonfinite |= !(fabs(da[rt][ks]) < __builtin_inf());
+                }
+            if (__builtin_amdgcn_ballot_w64(nonfinite) != 0ull) {
+                // 0 * inf would reach candidates that never take that generation: not this kernel's case -- the launch is
+                // flagged like a timed-out hand-off and redone by the scalar kernels (live_verify)
+                if (lane == 0 && atomicCAS(P.live_err, 0u, 1u) == 0u) { P.live_err[1] = (unsigned)g0; P.live_err[2] = 0xffffffffu; P.live_err[3] = blockIdx.x; }
+                leave();
+                return;
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                macc[0][ct] = x0;
+                macc[1][ct] = x1;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    macc[0][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(da[0][ks], mT[ct][ks], macc[0][ct], 0, 0, 0);
+                    macc[1][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(da[1][ks], mT[ct][ks], macc[1][ct], 0, 0, 0);
+                }
+            }
+        }
         // every node's candidate: state + its rows, in order, straight from LDS
-        double cand[D];
+        double cand[MF ? 1 : D];
+        if constexpr (!MF) {
 #pragma unroll
         for (int q = 0; q < CR / 2; ++q) {
             const double2 t = reinterpret_cast<const double2*>(ct_w)[q];      // (wave-uniform address)
@@ -435,19 +513,63 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
 #pragma unroll
             for (int p = 0; p < D; ++p) asm volatile("" : "+v"(cand[p]));
         }
+        }
         PW_T(0);                 // state row + candidate adds straight from LDS
         wave_lds_handoff();      // (the front end below rewrites the increments)
         store_history();
         const bool bad_n = front(slot, qR(1), qR(3), g3, g5, true);
         PW_T(1);                 // history stores, DMA wait, next pass's increments, DMA issue
         // the candidates go to rows 1..31 of the table (row 0 keeps the state the pass started from); the log-density follows
+        double lpp;
+        if constexpr (MF) {
+            // table rows from the accumulators (element v of row tile rt <-> parameter 16 rt + 4 v + g, candidate 16 ct + c16)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int j = 16 * ct + mc;
+                if (j != 0) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) ct_w[j * CR + 4 * v + mg] = macc[0][ct][v];
+                    if (16 + mg < D) ct_w[j * CR + 16 + mg] = macc[1][ct][0];
+                }
+            }
+            // R = C - mu 1', in place; Y = W R; q = diag(Y' Y)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) macc[0][ct][v] = macc[0][ct][v] - mmu0[v];
+                macc[1][ct][0] = macc[1][ct][0] - mmu1;
+            }
+            double qd[2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                mf4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(mW[0][ks], macc[0][ct][ks], y0, 0, 0, 0);
+                    y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(mW[1][ks], macc[0][ct][ks], y1, 0, 0, 0);
+                }
+                y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(mW[1][4], macc[1][ct][0], y1, 0, 0, 0);
+                mf4 qq = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qq = __builtin_amdgcn_mfma_f64_16x16x4f64(y0[ks], y0[ks], qq, 0, 0, 0);
+                qq = __builtin_amdgcn_mfma_f64_16x16x4f64(y1[0], y1[0], qq, 0, 0, 0);
+                // the diagonal: candidate c16 of this column tile is row 4 v + g of the accumulator when c16 == 4 v + g
+                const int vq = mc >> 2;
+                qd[ct] = (vq == 0) ? qq[0] : (vq == 1) ? qq[1] : (vq == 2) ? qq[2] : qq[3];
+            }
+            if ((mc & 3) == mg) {          // a diagonal lane: the log-densities of candidates c16 and 16 + c16 go to the table
+                if (mc != 0) ct_w[mc * CR + D] = fma(-0.5, qd[0], P.tp.c0);
+                ct_w[(16 + mc) * CR + D] = fma(-0.5, qd[1], P.tp.c0);
+            }
+            wave_lds_handoff();
+            lpp = ct_w[(nodel ? lane : 0) * CR + D];
+        } else {
         if (nodel) {
 #pragma unroll
             for (int q = 0; q < D / 2; ++q) reinterpret_cast<double2*>(ct_w + lane * CR)[q] = make_double2(cand[2 * q], cand[2 * q + 1]);
             if constexpr (D & 1) ct_w[lane * CR + D - 1] = cand[D - 1];
         }
         // The log-density: target_logp's operation sequence; mu from the workgroup's LDS copy
-        double lpp;
         {
             double (&rr)[D] = cand;           // (the candidate itself is in the table by now)
 #pragma unroll
@@ -487,6 +609,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             }
         }
         if (nodel) ct_w[lane * CR + D] = lpp;
+        }
         PW_T(2);                 // table write, log-density (W through scalar loads)
         unsigned long long mask, chg_a, chg_r;
         {

@@ -210,6 +210,21 @@ set_append_lag(h, E) = chk(ccall((:demcz_set_append_lag, libdemcz), Int32, (Ptr{
 set_comm_timeout(h, ms) = chk(ccall((:demcz_set_comm_timeout, libdemcz), Int32, (Ptr{Cvoid}, Int64), h, ms), h)
 synchronize(h) = chk(ccall((:demcz_synchronize, libdemcz), Int32, (Ptr{Cvoid},), h), h)
 # (LIVE launches in use, times an in-launch row hand-off timed out and was redone with one launch per K-window)
+# Rows handed over inside the launches (include/demcz.h): mode 0 = exchange through RCCL (or unsharded), 1 = replica group of this
+# process, 2 = IPC peers set up by comm_init, 3 = IPC peers set up by the host (peer_export / peer_attach)
+function peer_status(h)
+    m = Ref{Int32}(0); n = Ref{Int32}(0)
+    chk(ccall((:demcz_get_peer_status, libdemcz), Int32, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}), h, m, n), h)
+    Int(m[]), Int(n[])
+end
+# hosts that shard without the library's communicator carry the 64-byte IPC handles themselves (Distributed.jl, MPI ...)
+function peer_export(h, nranks, rank)
+    buf = zeros(UInt8, 64)
+    chk(ccall((:demcz_peer_export, libdemcz), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}), h, nranks, rank, buf), h)
+    buf
+end
+peer_attach(h, handles::Vector{Vector{UInt8}}) = (blob = reduce(vcat, handles);
+    chk(ccall((:demcz_peer_attach, libdemcz), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), h, blob), h))
 function live_status(h)
     on = Ref{Int32}(0); redos = Ref{Int32}(0)
     chk(ccall((:demcz_get_live_status, libdemcz), Int32, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}), h, on, redos), h)

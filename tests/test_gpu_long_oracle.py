@@ -151,3 +151,21 @@ def test_c2_tempered_live_run_equals_oracle(demc, oracle):
     assert counts["ps2"] == 3 and counts["ps_general"] == 0 and live == (True, 0), (counts, live)
     ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed, temperature=T, threads=THREADS)
     _same(dict(chain=ch, log_obj=lo, X=X, logp=lp, Z=Z, M=M, changed_total=tot), ref)
+
+
+def test_matrix_form_of_the_wave_per_chain_kernel_equals_oracle(demc, oracle, monkeypatch):
+    """window_kernel_pw<0, 20, LIVE, ., MF = true> (DEMCZ_PW_MFMA=1): the 31 candidates of a pass, their whitened residuals and
+    their sums of squares as 36 v_mfma_f64_16x16x4_f64 instructions whose accumulation is the oracle's sequential fma chain
+    (demcz_kernels_pw.h).  Measured slower than the scalar form and therefore off by default -- but it is
+    the same doubles: C4's shard for 2000 generations, plain and tempered, against the oracle."""
+    monkeypatch.setenv("DEMCZ_PW_MFMA", "1")
+    d, N, K, G, seed = 20, 1024, 10, 2000, 4242
+    w = demc.workloads.mvnormal_problem(d, N)
+    a = _hip(demc, w, N, d, K, G, [range(d)], seed, w["gamma"], pieces=[700, 5, 1295])
+    assert a["lanes"] == SPLIT_WAVE and a["live"] == (True, 0)
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed, threads=THREADS)
+    _same(a, ref)
+    T = np.array([demc.tempbaseline(g, 300, 3.0, 1e-3) for g in range(1, 301)])
+    b = _hip(demc, w, N, d, K, 300, [range(d)], seed + 1, w["gamma"], temperature=T)
+    refb = oracle_sample(oracle, w["target"], w["Zinit"], N, K, 300, None, w["eps_scale"], w["gamma"], seed + 1, temperature=T, threads=THREADS)
+    _same(b, refb)
