@@ -632,7 +632,7 @@ def main():
         if world == 1 and not args.no_sweep and (n_loc, d) == (1024, 5):
             try:     # reporting only: throughput regime of the same path
                 out["chain_count_sweep"] = [throughput_point(demc, n, d, K, seed, g, local_rank)
-                                            for n, g in ((4096, 1000), (16384, 400), (131072, 200), (1048576, 100))]
+                                            for n, g in ((2048, 1000), (4096, 1000), (16384, 400), (131072, 200), (1048576, 100))]
             except Exception as e:
                 out["chain_count_sweep"] = f"failed: {e}"
         if world == 1 and not args.no_configs:

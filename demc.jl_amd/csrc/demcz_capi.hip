@@ -9,6 +9,7 @@
 #include "demcz_kernels_lr.h"
 #include "demcz_kernels_ps.h"
 #include "demcz_kernels_ps2.h"
+#include "demcz_kernels_ps2d.h"
 #include "demcz_kernels_pw.h"
 
 #include <rccl/rccl.h>
@@ -196,7 +197,7 @@ struct demcz_handle {
     bool has_state = false;
     int64_t launches = 0;
     mutable int64_t kernel_counts[1] = {0};               // demcz_debug_kernel_counts: launches taken by window_kernel_ps2
-    int last_live = 0, last_ps2 = 0, last_temper = 0;     // demcz_debug_kernel_name: what the most recent window launch was
+    int last_live = 0, last_ps2 = 0, last_temper = 0, last_dual = 0;     // demcz_debug_kernel_name: what the most recent window launch was
     bool external_append = false;
     // host-closure mode
     double* dXprop = nullptr;
@@ -236,6 +237,8 @@ struct demcz_handle {
     int rec_cur = 0;
     bool host_paced = false;          // inside demcz_run_checked (a blocking call): see launch_window_pc
     int wpw = 1;                      // waves per consumer workgroup of the lane-cooperative kernels (window_kernel_ml / _mlb): 1 or 4, by population
+    bool ps_dual = false;             // split_kind 4, d <= 5: two chains to a wave in regular launches (window_kernel_ps2d)
+    bool dual_now = false;            // ... and the launch being prepared is one of those
     bool lr_spec = false;             // split_kind 2, regression target: window_kernel_lr8s (eight chains per workgroup, two generations per pass)
     mutable bool lds_raised = false, lds_raised_spec = false;  // hipFuncAttributeMaxDynamicSharedMemorySize raised on this handle's device (the attribute is per device)
     bool no_live = false;             // a LIVE hand-off failed on this handle: one launch per K-window from then on
@@ -757,7 +760,22 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
             h->split_per_wg = PS_CHAINS;
             // The library's own choice also asks that the consumers of a LIVE launch all fit the chip at once (one launch
             // per K-window is where this layout loses to the replicated consumer): MI355X, d = 5: 1024 chains.
-            if (cfg->lanes_per_chain == 0 && (cfg->N + PS_CHAINS - 1) / PS_CHAINS > live_wg_capacity(h)) {
+            // Two chains to a wave (window_kernel_ps2d, d <= 5, K a multiple of five): where one chain per wave no longer fits a LIVE
+            // launch (N > 1024 on MI355X) but half as many waves do -- up to 2048 chains.  DEMCZ_PS_DUAL=1 forces it at any N (tests).
+            const bool dual_env = getenv("DEMCZ_PS_DUAL") != nullptr && atoi(getenv("DEMCZ_PS_DUAL")) != 0;
+            const bool dual_ok = d >= 2 && d <= 5 && cfg->K % 5 == 0 && !getenv("DEMCZ_NO_PS2") && !getenv("DEMCZ_NO_PS_DUAL");
+            const bool single_fits = (cfg->N + PS_CHAINS - 1) / PS_CHAINS <= live_wg_capacity(h);
+            if (dual_ok && (dual_env || (!single_fits && cfg->lanes_per_chain == 0))) {
+                h->ps_dual = true;
+                h->split_per_wg = 2 * PS_CHAINS;
+                h->live_wg_cap = -1;
+                if (!dual_env && (cfg->N + 2 * PS_CHAINS - 1) / (2 * PS_CHAINS) > live_wg_capacity(h)) {      // not even that fits
+                    h->ps_dual = false;
+                    h->split_per_wg = PS_CHAINS;
+                    h->live_wg_cap = -1;
+                }
+            }
+            if (!h->ps_dual && cfg->lanes_per_chain == 0 && !single_fits) {
                 h->split_kind = kind;
                 h->split_per_wg = per_wg_default;
                 h->live_wg_cap = -1;
@@ -810,7 +828,9 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
             // (record buffers as demcz_run would size them: a LIVE launch's span, bounded by the history window; a caller that
             //  outruns the arena gets separate buffers and the general kernel)
             const int64_t per_gen = (int64_t)(d + 2) * N_for_arena * (int64_t)sizeof(double);
-            int64_t ag = std::max<int64_t>(cfg->K, std::min<int64_t>((int64_t)(64ll << 20) / per_gen, 1 << 20));
+            // (64 MiB of records per buffer: 1170 generations at C2; a two-chain handle has up to twice the chains: 128 MiB, so that
+            //  an autostop slab of 1000 generations is still ONE launch at 2048 chains)
+            int64_t ag = std::max<int64_t>(cfg->K, std::min<int64_t>((int64_t)((h->ps_dual ? 128ll : 64ll) << 20) / per_gen, 1 << 20));
             if (cfg->Gcap > 0) ag = std::min<int64_t>(ag, std::max<int64_t>(cfg->Gcap, 1024));      // (no history kept: launches are as long as a call)
             ag = std::max<int64_t>(ag, (int64_t)cfg->K * 4);
             const size_t zb = (zbytes + 255) & ~(size_t)255;
@@ -829,6 +849,7 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
             }
         }
         if (!h->arena) { CRCHK(g_dev_pool.acquire((void**)&h->dZ, zbytes, cfg->device_id)); h->dZ_bytes = zbytes; }
+        if (h->ps_dual && !h->arena) { h->ps_dual = false; h->split_per_wg = PS_CHAINS; h->live_wg_cap = -1; }      // (the two-chain kernel addresses the arena)
         h->pooled_dev = true;
     }
     // (the reference pads with zeros, demcz.jl:11; rows at or beyond M never leave the device, and here they hold
@@ -880,7 +901,8 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
         // waves that run chains in one window launch (every one writes its two counters)
         int64_t waves;
         if (h->lanes == DEMCZ_LAYOUT_SPLIT) {
-            const int64_t wgs = (N + h->split_per_wg - 1) / h->split_per_wg;
+            // (a two-chain handle's irregular launches run one chain per wave: twice the waves)
+            const int64_t wgs = (N + (h->ps_dual ? PS_CHAINS : h->split_per_wg) - 1) / (h->ps_dual ? PS_CHAINS : h->split_per_wg);
             waves = wgs * ((h->split_kind == 2 && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? LR16_WAVES : (h->split_kind == 4) ? PS_CHAINS : (h->split_kind == 3 || h->split_kind == 2) ? h->wpw : 1);
         } else if (h->lanes > 1) {
             const int per_wave = 64 / h->lanes;
@@ -1230,7 +1252,18 @@ template <int TARGET, int D>
 static void launch_ps(const demcz_handle* h, const WindowParams& P, int64_t blocks, bool live)
 {
     const dim3 grid((unsigned)blocks), wg(64 * PS_CHAINS), wgl(64 * (PS_CHAINS + 1));     // LIVE: chain waves + publisher wave
-    if (ps2_applicable(h, P)) {               // the regular launch: the steady-state kernel
+    if (h->dual_now && ps2_applicable(h, P)) {      // ... with two chains to a wave
+        ++h->kernel_counts[0];
+        if (P.temperature) {
+            if (live) hipLaunchKernelGGL((window_kernel_ps2d<TARGET, D, true, true>), grid, wgl, 0, h->stream, P);
+            else hipLaunchKernelGGL((window_kernel_ps2d<TARGET, D, false, true>), grid, wg, 0, h->stream, P);
+        } else {
+            if (live) hipLaunchKernelGGL((window_kernel_ps2d<TARGET, D, true, false>), grid, wgl, 0, h->stream, P);
+            else hipLaunchKernelGGL((window_kernel_ps2d<TARGET, D, false, false>), grid, wg, 0, h->stream, P);
+        }
+        return;
+    }
+    if (!h->ps_dual && ps2_applicable(h, P)) {               // the regular launch: the steady-state kernel
         ++h->kernel_counts[0];
         if (P.temperature) {
             if (live) hipLaunchKernelGGL((window_kernel_ps2<TARGET, D, true, true>), grid, wgl, 0, h->stream, P);
@@ -1350,7 +1383,9 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
             // take the whole chip.
             static const size_t throttle_env = getenv("DEMCZ_PRODUCE_LDS") ? (size_t)atol(getenv("DEMCZ_PRODUCE_LDS")) : PRODUCE_THROTTLE_LDS;
             // (regression target: what a consumer workgroup leaves of its CU's LDS holds ONE 8 KB producer workgroup)
-            const size_t dyn = (ps != h->stream) ? (h->lr_spec ? (size_t)8192 : throttle_env) : 0;
+            // (two chains to a wave: one 40 KB consumer workgroup per CU at 2048 chains leaves room for three 32 KB producer
+            //  workgroups, and the producer has twice the draws to make per launch: 131 against 144 us per launch, profiles/r04j_dual.txt)
+            const size_t dyn = (ps != h->stream) ? (h->lr_spec ? (size_t)8192 : (h->ps_dual && !getenv("DEMCZ_PRODUCE_LDS")) ? (size_t)32768 : throttle_env) : 0;
             switch (P.d) {
             case 2: hipLaunchKernelGGL((produce_kernel<2>), pg, pw, dyn, ps, P); break;
             case 3: hipLaunchKernelGGL((produce_kernel<3>), pg, pw, dyn, ps, P); break;
@@ -1525,7 +1560,7 @@ static int32_t pc_prepare(demcz_handle* h, WindowParams& P, int64_t cur_rows, in
         dc.valid = true; dc.g_first = P.g_first; dc.M = P.M; dc.ngen = P.ngen; dc.rows = cur_rows; dc.boff = cur_boff;
     }
     P.rec_in = h->d_rec[cur];
-    const int per_wg = h->split_per_wg;
+    const int per_wg = (h->ps_dual && !h->dual_now) ? PS_CHAINS : h->split_per_wg;      // (an irregular launch of a two-chain handle: one chain per wave)
     P.consumer_blocks = (int32_t)((P.N + per_wg - 1) / per_wg);
     P.rec_out = h->d_rec[cur ^ 1];
     P.next_g_first = next_g; P.next_ngen = (int32_t)std::max<int64_t>(next_ngen, 0); P.next_M = next_M;
@@ -1595,13 +1630,14 @@ static int32_t launch_window(demcz_handle* h, const WindowParams& P, bool live =
     if (P.consumer_blocks > 0 || h->lanes != DEMCZ_LAYOUT_SPLIT) {      // (not the producer-only launches)
         h->last_live = live ? 1 : 0;
         h->last_temper = P.temperature ? 1 : 0;
-        h->last_ps2 = (h->lanes == DEMCZ_LAYOUT_SPLIT && h->split_kind == 4 && !h->lr_spec && ps2_applicable(h, P)) ? 1 : 0;
+        h->last_ps2 = (h->lanes == DEMCZ_LAYOUT_SPLIT && h->split_kind == 4 && !h->lr_spec && ps2_applicable(h, P) && (!h->ps_dual || h->dual_now)) ? 1 : 0;
+        h->last_dual = h->dual_now ? 1 : 0;
     }
     if (h->snap_pending) {
         // the redo snapshot of the state (demcz_run): window_kernel_ps2 writes it as it loads the state -- two 5 us copy launches
         // less in front of every autostop slab -- any other kernel gets the copies
         h->snap_pending = false;
-        if (h->lanes == DEMCZ_LAYOUT_SPLIT && !h->lr_spec && ps2_applicable(h, P)) {
+        if (h->lanes == DEMCZ_LAYOUT_SPLIT && !h->lr_spec && ps2_applicable(h, P) && (!h->ps_dual || h->dual_now)) {
             WindowParams Q = P;
             Q.safe_X = h->d_safe_X;
             Q.safe_lp = h->d_safe_lp;
@@ -2006,11 +2042,28 @@ static int pw_live_blocks_per_cu()
     return m;
 }
 
+template <int D>
+static int ps2d_live_blocks_per_cu()
+{
+    int a = 0, b = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&window_kernel_ps2d<TARGET_MVNORMAL, D, true, false>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) a = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(&window_kernel_ps2d<TARGET_MVNORMAL, D, true, true>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) b = 0;
+    return std::min(a, b);
+}
+
 static int64_t live_wg_capacity(demcz_handle* h)
 {
     if (h->live_wg_cap >= 0) return h->live_wg_cap;
     int per_cu = 0;
-    if (h->split_kind == 4) {
+    if (h->split_kind == 4 && h->ps_dual) {      // (its LIVE launches are all of the two-chain kernel)
+        switch (h->cfg.d) {
+        case 2: per_cu = ps2d_live_blocks_per_cu<2>(); break;
+        case 3: per_cu = ps2d_live_blocks_per_cu<3>(); break;
+        case 4: per_cu = ps2d_live_blocks_per_cu<4>(); break;
+        case 5: per_cu = ps2d_live_blocks_per_cu<5>(); break;
+        default: per_cu = 0;
+        }
+    } else if (h->split_kind == 4) {
         switch (h->cfg.d) {
         case 2: per_cu = std::min(ps_live_blocks_per_cu<2>(), ps2_live_blocks_per_cu<2>()); break;
         case 3: per_cu = std::min(ps_live_blocks_per_cu<3>(), ps2_live_blocks_per_cu<3>()); break;
@@ -2134,7 +2187,7 @@ static int64_t live_span(demcz_handle* h)
     // C5 22.3 -> 21.5 (profiles/r03f_launch_span.txt)
     static const int64_t env_mib = getenv("DEMCZ_REC_MIB") ? atol(getenv("DEMCZ_REC_MIB")) : 0;
     // (block updates, split kind 3: flat between 64 and 256 MiB, 4 % slower at 1 GiB -- 128)
-    const int64_t mib = env_mib > 0 ? env_mib : (h->arena ? 64 : (h->split_kind == 3) ? 128 : 1024);
+    const int64_t mib = env_mib > 0 ? env_mib : (h->arena ? (h->ps_dual ? 128 : 64) : (h->split_kind == 3) ? 128 : 1024);
     const int64_t span = (int64_t)(mib << 20) / per_gen;
     return std::max<int64_t>(h->cfg.K, std::min<int64_t>(span, 1 << 20));
 }
@@ -2383,7 +2436,24 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         }
         // Split layout on one GPU: the launch runs on through the boundaries; waves hand the appended rows
         // to each other inside it (LIVE, demcz_kernels_pc.h), so the schedule is still the synchronous one.
-        const int64_t live_max = live_span(h);
+        int64_t live_max = live_span(h);
+        h->dual_now = false;
+        if (h->ps_dual) {
+            // A two-chain handle runs its REGULAR launches (start, boundary distance and length multiples of five; everything
+            // reachable through the arena) on window_kernel_ps2d; anything else takes the general kernel, one chain per wave, and
+            // -- twice the waves: they would not all be resident -- never across a K boundary.
+            const int64_t tb0 = next_boundary - g + 1, rest = g_to - g + 1;
+            const bool temp_ok = !temperature || temp_in_arena;
+            const bool hist_ok = !hist || (double)h->cfg.N * (h->cfg.d + 1) * (double)h->cfg.Gcap * 8.0 < 4293918720.0;
+            const bool reg = K % PS2_R == 0 && tb0 % PS2_R == 0 && rest >= PS2_R && temp_ok && hist_ok && h->arena && h->rec_in_arena;
+            if (reg) {
+                h->dual_now = true;
+                if (live_max > 0) live_max = std::max<int64_t>((std::min(live_max, rest) / PS2_R) * PS2_R, PS2_R);
+                else w_end = g + ((w_end - g + 1) / PS2_R) * PS2_R - 1;       // (a K-window cut short by the call's end: whole passes only)
+            } else {
+                live_max = 0;
+            }
+        }
         if (live_max > 0) {
             // How far this launch goes: as far as the records allow -- but no further than the draws that ARE there, where the
             // launch before prepared fewer than that (a call longer than the last one); and a launch whose draws have to be made
@@ -2398,9 +2468,10 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
                 if (dc.ngen < n) n = std::max<int64_t>((dc.ngen / K) * K, K);
             } else {
                 const int64_t per_gen = rec_fields(h) * h->cfg.N * (int64_t)sizeof(double);
-                const int64_t cold = std::max<int64_t>(K, ((int64_t)(64ll << 20) / per_gen / K) * K);
+                const int64_t cold = std::max<int64_t>(K, ((int64_t)((h->ps_dual ? 128ll : 64ll) << 20) / per_gen / K) * K);
                 n = std::min(n, cold);
             }
+            if (h->dual_now) n = std::max<int64_t>((n / PS2_R) * PS2_R, PS2_R);
             w_end = g + n - 1;
         }
         int32_t rc = admit_pending(h, g);
@@ -2451,6 +2522,8 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         if (h->live_fault_polls < 0 && live && g >= h->live_fault_g)      // "a wave of this launch has already given up": every wave leaves at once
             HIPCHK(h, hipMemsetAsync(h->d_live_err, 0x01, sizeof(unsigned int), h->stream));
         P.acc_out = h->d_acc ? h->d_acc + (size_t)h->acc_next * (size_t)h->acc_waves * 2 : nullptr;
+        if (h->ps_dual && P.acc_out)     // (its two kernels write different numbers of waves' counters into a slot of the ring)
+            HIPCHK(h, hipMemsetAsync(P.acc_out, 0, (size_t)h->acc_waves * 2 * sizeof(unsigned int), h->stream));
         if (live) h->err_clean = false;
         rc = launch_window(h, P, live);
         h->after_launch_ev = nullptr;         // (whatever was recorded before this launch says nothing about it)
@@ -3657,7 +3730,7 @@ extern "C" int32_t demcz_debug_kernel_name(const demcz_handle* h, char* buf, int
     const bool lr = h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE;
     if (h->lanes == DEMCZ_LAYOUT_SPLIT) {
         if (h->lr_spec) snprintf(tmp, sizeof tmp, "window_kernel_lr8s<%d, %s>", d, lv);
-        else if (h->split_kind == 4 && d <= 5) snprintf(tmp, sizeof tmp, "%s<%s, %d, %s, %s>", h->last_ps2 ? "window_kernel_ps2" : "window_kernel_ps", tg, d, lv, tm);
+        else if (h->split_kind == 4 && d <= 5) snprintf(tmp, sizeof tmp, "%s<%s, %d, %s, %s>", (h->last_ps2 && h->last_dual) ? "window_kernel_ps2d" : h->last_ps2 ? "window_kernel_ps2" : "window_kernel_ps", tg, d, lv, tm);
         else if (h->split_kind == 4 && h->last_live && pw_matrix_form(h)) snprintf(tmp, sizeof tmp, "window_kernel_pw<%s, %d, %s, %s, true>", tg, d, lv, tm);
         else if (h->split_kind == 4) snprintf(tmp, sizeof tmp, "window_kernel_pw<%s, %d, %s, %s>", tg, d, lv, tm);
         else if (h->split_kind == 3 && h->mlb_qb > 0 && h->split_lanes == 16) snprintf(tmp, sizeof tmp, "window_kernel_mlb<%s, %d, %d, true, %s, %d>", tg, d, h->split_lanes, lv, h->mlb_qb);

@@ -1,0 +1,594 @@
+// demcz_kernels_ps2d.h -- window_kernel_ps2 (demcz_kernels_ps2.h) with TWO chains to a wave (round 4).
+//
+// A pass of the steady-state wave-per-chain consumer uses 31 of a wave's 64 lanes for the tree of outcomes; lanes 32..63 only
+// shadowed lanes 0..31.  Here they run a second chain: lane l works for chain NCH * wave + (l >> 5), as node l & 31 of THAT
+// chain's tree.  What a wave has once per chain: a KiB of every raw slot and a DMA instruction per pass (a pass's rows, normals,
+// log u and indices are 54 of an instruction's 64 lanes), a block of increments, half of the candidate table (rows 0..31 /
+// 32..63), a row in the publisher's ring.  What it has once: the pass structure, the boundary counter, the history store (30 + 30
+// of its lanes), the accept compare -- one ballot whose halves are the two chains' masks -- and the instruction stream: the pass
+// costs what it cost (one DMA instruction more) and resolves five generations of TWO chains.  The LIVE launch therefore holds
+// 2048 chains where it held 1024 (one five-wave workgroup of eight chains per CU), at the same time per launch.
+// An odd population: the last wave's second half shadows the last chain (reads what it reads, writes nothing, counts nothing).
+// Same arithmetic on the same values as window_kernel_ps2, hence the oracle's bits.
+#pragma once
+
+#include "demcz_kernels_ps2.h"
+
+#pragma clang fp contract(off)
+
+namespace demcz {
+
+template <int TARGET, int D, bool LIVE, bool TEMPER>
+__global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_kernel_ps2d(const WindowParams P)
+{
+    static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "split layout: MvNormal / isotropic targets");
+    static_assert(D >= 2 && D <= 5, "a pass's rows, normals, log u and indices are one 64-lane DMA");
+    constexpr int R = PS2_R;
+    constexpr int NCH = 2;                                 // chains of a wave: lanes 0..31 run one, lanes 32..63 the other
+    constexpr int HW = (D + 1) / 2;                        // 16-byte pieces of an archive row
+    constexpr int ZSC = (D <= 2) ? 2 : (D <= 4) ? 4 : 8;   // archive row stride in doubles (demcz_create: ZS)
+    constexpr int ZSH = (ZSC == 2) ? 4 : (ZSC == 4) ? 5 : 6;      // log2 of the row stride in bytes
+    constexpr int DP = ((D + 1) / 2) * 2;                  // increments row in LDS
+    constexpr int CR = ((D + 2) / 2) * 2;                  // candidate row in LDS: D doubles, log-density, pad
+    // lanes of the DMA: [0, ROWL) archive rows (generation u, first / second row, piece j); then NF fields of three pieces
+    // (six generations) each: 0..D-1 normals, D log u, D+1 this pass's row indices, D+2 the row indices of the pass two after
+    // this one (the same record field, AHEAD passes on), D+3 temperatures; the rest idle (they fetch row 0)
+    constexpr int ROWL = R * 2 * HW;
+    constexpr int FL0 = ROWL;
+    constexpr int NF = D + 3 + (TEMPER ? 1 : 0);
+    constexpr int TL0 = FL0 + 3 * NF;
+    static_assert(TL0 <= 64, "one DMA instruction per pass");
+    constexpr int F_LOGU = D, F_IXOWN = D + 1, F_IXNEXT = D + 2, F_TEMP = D + 3;
+    constexpr int SDN = (R + 1) * DP + 2;                  // sdelta: R rows of increments, the row of negative zeros, pad
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if constexpr (!LIVE) {
+        // short launches: the producer half rides in the same grid (demcz_kernels_ps.h)
+        if ((int64_t)blockIdx.x >= P.consumer_blocks) {
+            pc_produce<D>(P, ((int64_t)blockIdx.x - P.consumer_blocks) * PS_CHAINS + w, lane);
+            return;
+        }
+    }
+#if PS2_XCD_SWIZZLE
+    const int bxs = xcd_block(P);          // XCD x runs the x-th eighth of the chains: demcz_kernels.h
+#else
+    const int bxs = (int)blockIdx.x;
+#endif
+    __shared__ __attribute__((aligned(16))) unsigned char raw[PS_CHAINS][PS2_SLOTS][NCH * 1024];
+    __shared__ __attribute__((aligned(16))) double sdelta[PS_CHAINS][NCH][SDN];
+    __shared__ __attribute__((aligned(16))) double ctab[PS_CHAINS][64 * CR];       // row l: lane l's candidate (rows 0..31: the first chain's tree, 32..63: the second's)
+    __shared__ double pub_rows[LIVE ? PS_CHAINS * PS_PUB * NCH * D : 1];
+    __shared__ unsigned int pub_seq[PS_CHAINS], pub_done[PS_CHAINS], pub_exit[PS_CHAINS];
+    if constexpr (LIVE) {
+        if (threadIdx.x < PS_CHAINS) { pub_seq[threadIdx.x] = 0u; pub_done[threadIdx.x] = 0u; pub_exit[threadIdx.x] = 0u; }
+        __syncthreads();
+        if (w == PS_CHAINS) {
+            // the publisher wave: demcz_kernels_ps.h (identical protocol; it never leaves before its chain waves)
+            const bool pl = lane < PS_CHAINS * NCH * D;
+            const int cw = pl ? lane / (NCH * D) : 0, ph = pl ? (lane / D) % NCH : 0, pp = pl ? lane % D : 0;
+            const int64_t cl = ((int64_t)bxs * PS_CHAINS + cw) * NCH + ph;
+            unsigned int done = 0u;
+            while (true) {
+                publisher_wait(P);
+                const unsigned int seq = __hip_atomic_load(&pub_seq[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const bool ready = pl && seq != done;
+                if (__builtin_amdgcn_ballot_w64(ready) != 0ull) {
+                    if (ready) {
+                        const double v = pub_rows[((cw * PS_PUB + (int)(done % PS_PUB)) * NCH + ph) * D + pp];
+                        if (cl < P.N && P.do_append) live_publish(P, (int64_t)done, cl, pp, v);
+                        ++done;
+                    }
+                    asm volatile("" ::: "memory");
+                    if (ready && pp == 0 && ph == 0) __hip_atomic_store(&pub_done[cw], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    continue;
+                }
+                const bool gone = !pl || (__hip_atomic_load(&pub_exit[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u &&
+                                          __hip_atomic_load(&pub_seq[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == done);
+                if (__builtin_amdgcn_ballot_w64(!gone) == 0ull) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            return;
+        }
+    }
+    auto leave = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (LIVE) {
+            if (lane == 0) __hip_atomic_store(&pub_exit[w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    const int64_t wv = (int64_t)bxs * PS_CHAINS + w;       // this wave among the chain waves; its chains: NCH * wv, NCH * wv + 1
+    if (wv * NCH >= P.N) {
+        wave_store_counts(P, wv, 0u, 0u);
+        leave();
+        return;
+    }
+    const int hh = lane >> 5, l5 = lane & 31;               // which of the wave's chains this lane works for; its place in that half
+    const bool act = wv * NCH + hh < P.N;                  // (an odd population: the last wave's second half shadows the last chain
+    const int64_t c = act ? wv * NCH + hh : P.N - 1;       //  -- it reads what that chain reads and writes nothing)
+    const unsigned long long actm = (wv * NCH + 1 < P.N) ? ~0ull : 0xffffffffull;
+    if constexpr (LIVE) {
+        if (__hip_atomic_load(P.live_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            // Another wave has already given up.  This chain's row of the redo snapshot is still owed (the host made no copy
+            // in front of this launch: launch_window): Xcur / lpcur of chain c are only ever written by this wave, at the
+            // launch's end, so they still hold the state the launch started from.
+            if (P.safe_X && act) {
+                if (l5 < D) P.safe_X[c + P.N * l5] = P.Xcur[c + P.N * l5];
+                if (l5 == 0) P.safe_lp[c] = P.lpcur[c];
+            }
+            leave();
+            return;
+        }
+    }
+    __builtin_amdgcn_s_setprio(3);
+    unsigned char* const raw_w = &raw[w][0][0];
+    double* const sd_w = &sdelta[w][hh][0];
+    double* const ct_w = &ctab[w][0];
+    const unsigned raw_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)raw_w);
+
+    // ---- what this lane is, in each of its parts ----------------------------------------------------------------
+    // node of its chain's tree of outcomes: nn = 0 is the state itself (lanes 0 and 32), 1..31 the nodes
+    const int nn = l5;
+    const int lev = nn ? 32 - __builtin_clz((unsigned)nn) : 0;
+    const double* mrow[R];                 // rows of sdelta this node adds, in order: an accepted generation on its path or its
+#pragma unroll                             // own -> that generation's increments, anything else -> the row of negative zeros
+    for (int j = 1; j <= R; ++j) {
+        const bool take = nn != 0 && ((j == lev) || (j < lev && ((nn >> (lev - 1 - j)) & 1)));
+        mrow[j - 1] = sd_w + (take ? j - 1 : R) * DP;
+    }
+    int anc = nn;
+    while (anc > 1 && (anc & 1) == 0) anc >>= 1;
+    anc = (anc <= 1) ? 0 : (anc >> 1);
+    const int anc4 = (hh * 32 + anc) * 4;
+    unsigned int need1 = 0u, need0 = 0u;
+#pragma unroll
+    for (int t = 1; t < R; ++t) {
+        if (t < lev) {
+            const unsigned int a = (unsigned int)nn >> (lev - t);
+            if ((nn >> (lev - 1 - t)) & 1) need1 |= 1u << a; else need0 |= 1u << a;
+        }
+    }
+    const unsigned int needm = need1 | need0;
+    const int levc = lev ? lev : 1;
+    const int lgo = hh * 1024 + (FL0 + 3 * F_LOGU) * 16 + (levc - 1) * 8;          // its log u, inside a raw slot
+    [[maybe_unused]] const int tko = hh * 1024 + (FL0 + 3 * F_TEMP) * 16 + (levc - 1) * 8;
+    // increments: lane (u, p) forms element p of generation u of the pass
+    const bool fl = l5 < R * D;
+    const int fu = fl ? l5 / D : 0, fp = fl ? l5 % D : 0;
+    const int zao = hh * 1024 + ((fu * 2) * HW) * 16 + fp * 8;          // second row: + HW * 16  (its own chain's KiB of the slot)
+    const int zto = hh * 1024 + (FL0 + 3 * fp) * 16 + fu * 8;
+    const int ixown = hh * 1024 + (FL0 + 3 * F_IXOWN) * 16 + fu * 8;    // this pass's row indices (LIVE re-reads)
+    const double eps_p = P.eps[fp];
+    const double scale = P.gamma / sqrt((double)(2 * D));
+    double* const sdw_p = sd_w + (fl ? fu * DP + fp : R * DP + DP);     // (idle lanes: the pad)
+    // DMA: rows (ru, which, piece), record fields (f, piece)
+    const bool rowl = lane < ROWL;
+    const int ru = rowl ? lane / (2 * HW) : 0, rwhich = rowl ? (lane / HW) % 2 : 0, rj = rowl ? lane % HW : 0;
+    const bool fieldl = lane >= FL0 && lane < TL0;
+    const int ff = fieldl ? (lane - FL0) / 3 : 0, fj = fieldl ? (lane - FL0) % 3 : 0;
+    const int ixnext = (FL0 + 3 * F_IXNEXT) * 16 + ru * 8;              // where a row lane finds the indices of the pass two on
+    // which half of the packed index pair a row lane takes (v_perm byte selectors; 0x0c = the constant 0x00)
+    const unsigned int selv = !rowl ? 0x0c0c0c0cu : (rwhich ? 0x07060504u : 0x03020100u);
+    const unsigned char* const zbase = reinterpret_cast<const unsigned char*>(P.Z);
+    // (every one of a pass's NCH DMA instructions uses all 64 lanes in these roles, for the wave's k-th chain)
+    int64_t ck[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) ck[k] = (wv * NCH + k < P.N) ? wv * NCH + k : P.N - 1;
+    unsigned int dma_off[NCH], dma_inc;
+    {
+        const unsigned int rec_off = (unsigned int)(reinterpret_cast<const unsigned char*>(P.rec_in) - zbase);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            if (rowl) { dma_off[k] = (unsigned int)rj * 16u; }
+            else if (fieldl && ff != F_TEMP) {
+                const int rf = (ff == F_IXOWN || ff == F_IXNEXT) ? D + 1 : ff;
+                dma_off[k] = rec_off + (unsigned int)((((int64_t)rf * P.N + ck[k]) * P.rec_stride + (ff == F_IXNEXT ? PS2_AHEAD * R : 0)) * 8) + (unsigned int)fj * 16u;
+            } else if (fieldl) {
+                dma_off[k] = (unsigned int)(reinterpret_cast<const unsigned char*>(P.temperature) - zbase) + (unsigned int)fj * 16u;
+            } else { dma_off[k] = 0u; }
+        }
+        dma_inc = fieldl ? (unsigned int)(R * 8) : 0u;
+    }
+    // history: lane (j, p) stores element p of generation j's row (p == D: log_obj); chain and log_obj are one allocation
+    const bool hl = l5 < R * (D + 1) && act;
+    const int hj = hl ? l5 / (D + 1) : 0, hp = hl ? l5 % (D + 1) : 0;
+    const unsigned int hmask = (hj + 1 >= 5) ? 0xffffffffu : ((1u << (1u << (hj + 1))) - 1u);     // the state + nodes of generations 1..hj+1
+    const bool hist = P.chain != nullptr;
+    unsigned int h_off, h_inc;
+    if (hl && hist && hp < D) {
+        h_off = (unsigned int)((((P.slot_first + hj) * D + hp) * P.N + c) * 8);
+        h_inc = (unsigned int)((int64_t)R * D * P.N * 8);
+    } else if (hl && hist) {
+        h_off = (unsigned int)((reinterpret_cast<const unsigned char*>(P.logobj) - reinterpret_cast<const unsigned char*>(P.chain)) +
+                               ((P.slot_first + hj) * P.N + c) * 8);
+        h_inc = (unsigned int)((int64_t)R * P.N * 8);
+    } else { h_off = 0xffffff00u; h_inc = 0u; }
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hist ? reinterpret_cast<unsigned char*>(P.chain) : const_cast<unsigned char*>(zbase),
+                                                                           0, hist ? (int)0xfffff000u : 0, 0x00020000);
+    const double* const tab_h = ct_w + hh * 32 * CR + hp;   // + winner row (of its own chain's tree) * CR
+
+    // target constants
+    double muc[D], Wc[(TARGET == TARGET_MVNORMAL) ? D * (D + 1) / 2 : 1];
+#pragma unroll
+    for (int p = 0; p < D; ++p) muc[p] = P.tp.mu[p];
+    if constexpr (TARGET == TARGET_MVNORMAL) {
+#pragma unroll
+        for (int i = 0; i < D * (D + 1) / 2; ++i) Wc[i] = P.tp.Wp[i];
+    }
+    const double c0v = P.tp.c0;
+
+    const int npass = P.ngen / R;
+    int tb = P.to_boundary / R;                            // passes up to and including the next boundary pass
+    const int tbK = P.K / R;
+
+    // state of the chain: every lane holds a copy
+    double x[D], xlp;
+#pragma unroll
+    for (int p = 0; p < D; ++p) x[p] = P.Xcur[c + P.N * p];
+    xlp = P.lpcur[c];
+    if (P.safe_X && act) {                 // the state this launch starts from, kept for a redo (WindowParams::safe_X)
+        double xv = x[0];
+#pragma unroll
+        for (int p = 1; p < D; ++p) xv = (l5 == p) ? x[p] : xv;
+        if (l5 < D) P.safe_X[c + P.N * l5] = xv;
+        if (l5 == 0) P.safe_lp[c] = xlp;
+    }
+    if (l5 < DP + 2) sd_w[R * DP + l5] = (l5 < DP) ? -0.0 : 0.0;
+
+    // the first two passes' row indices by ordinary loads; then everything that was loaded is in registers before the first DMA
+    uint64_t pp[NCH][PS2_AHEAD];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        const double* rec_ix = P.rec_in + ((int64_t)(D + 1) * P.N + ck[q]) * P.rec_stride;
+#pragma unroll
+        for (int k = 0; k < PS2_AHEAD; ++k) pp[q][k] = (uint64_t)__double_as_longlong(rec_ix[k * R + ru]);
+    }
+#pragma unroll
+    for (int p = 0; p < D; ++p) asm volatile("" :: "v"(x[p]));
+    asm volatile("" :: "v"(xlp), "v"(eps_p));
+#pragma unroll
+    for (int q = 0; q < NCH; ++q)
+#pragma unroll
+        for (int k = 0; k < PS2_AHEAD; ++k) asm volatile("" :: "v"(pp[q][k]));
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+    // the DMAs of one pass: one instruction per chain of the wave, into that chain's KiB of the slot
+    auto issue = [&](const uint64_t (&pack)[NCH], int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const unsigned int sel = __builtin_amdgcn_perm((unsigned int)(pack[q] >> 32), (unsigned int)pack[q], selv);
+            const unsigned int off = (sel << ZSH) + dma_off[q];
+            dma_off[q] += dma_inc;
+            ps2_dma16(zbase, off, raw_lds + (unsigned)(slot * NCH + q) * 1024u);
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < PS2_AHEAD; ++k) {
+        const uint64_t pk[NCH] = {pp[0][k], pp[1][k]};
+        issue(pk, k);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    double hv = 0.0;
+    // (all 64 lanes execute the store -- lanes with nothing to store point out of range -- so the count of vector-memory
+    //  operations between a DMA and its wait is the same on every path)
+    auto store_history = [&](unsigned int off) __attribute__((always_inline)) {
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const unsigned long long vb = (unsigned long long)__double_as_longlong(hv);
+        const u32x2 vv = {(unsigned int)vb, (unsigned int)(vb >> 32)};
+        __builtin_amdgcn_raw_buffer_store_b64(vv, hrsrc, (int)off, 0, 0);
+    };
+
+    double m[R][D];
+    auto mget = [&](int j, int p) __attribute__((always_inline)) -> double { return m[j][p]; };
+    constexpr int NPIECE = DP / 2;
+    double logu = 0.0;
+    [[maybe_unused]] double temp = 1.0;
+    double za_f = 0.0, zb_f = 0.0, zt_f = 0.0;
+    // (Measured and dropped: running the pass on lanes 0..31 only and reading, per node, only the rows it adds -- 22 KB of LDS
+    //  traffic per pass down to 8 KB: 103 -> 99.5 us per 1000 generations, for hand-set lane masks the compiler does not know of.)
+    auto load_rows = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+#pragma unroll
+            for (int q = 0; q < DP / 2; ++q) {
+                const double2 t = reinterpret_cast<const double2*>(mrow[j])[q];
+                m[j][2 * q] = t.x;
+                if (2 * q + 1 < D) m[j][2 * q + 1] = t.y;
+            }
+    };
+    auto write_increment = [&]() __attribute__((always_inline)) {
+        const double diff = za_f - zb_f;
+        const double t1 = scale * diff;
+        const double t2 = eps_p * zt_f;
+        *sdw_p = t1 + t2;              // (every lane stores: the lanes that form nothing write the pad -- no branch in the pass)
+    };
+    // Front end of the pass whose raw slot is `slot`, in three parts that the pass loop places where their latencies hide:
+    // (1) the raw values out of the slot (LDS reads); (2) the increments into LDS; (3) the DMA of the pass AHEAD after it (into
+    // `slot_dma`) and this pass's node rows into registers.
+    uint64_t pr_f[NCH] = {0, 0};
+    double logu_n = 0.0;
+    [[maybe_unused]] double temp_n = 1.0;
+    auto front_reads = [&](int slot, bool counted) __attribute__((always_inline)) {
+        const unsigned char* rw = raw_w + slot * (NCH * 1024);
+        // behind this slot's last DMA in program order: AHEAD - 1 whole passes (a store and NCH DMAs each) and this pass's store
+        if (counted) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((1 + NCH) * (PS2_AHEAD - 1) + 1) : "memory");
+        za_f = *reinterpret_cast<const double*>(rw + zao);
+        zb_f = *reinterpret_cast<const double*>(rw + zao + HW * 16);
+        zt_f = *reinterpret_cast<const double*>(rw + zto);
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) pr_f[q] = *reinterpret_cast<const uint64_t*>(rw + q * 1024 + ixnext);
+        logu_n = *reinterpret_cast<const double*>(rw + lgo);
+        if constexpr (TEMPER) temp_n = *reinterpret_cast<const double*>(rw + tko);
+    };
+    auto front_bad = [&]() __attribute__((always_inline)) -> bool {
+        if constexpr (LIVE) return fl && (is_sentinel(za_f) | is_sentinel(zb_f));
+        return false;
+    };
+    auto front_rest = [&](int slot_dma) __attribute__((always_inline)) {
+        issue(pr_f, slot_dma);
+        wave_lds_handoff();
+        load_rows();
+    };
+    // LIVE: rows that other waves had not published when the DMA read them -- asked for again (sc1 loads) until they are
+    // there, increments and node rows redone.  Returns true when the wait was abandoned.
+    auto reread = [&](bool bad, int slot, int gpass) __attribute__((always_inline)) -> bool {
+        const uint64_t ix = *reinterpret_cast<const uint64_t*>(raw_w + slot * (NCH * 1024) + ixown);
+        const uint32_t i1 = (uint32_t)ix, i2 = (uint32_t)(ix >> 32);
+        int spins = 0;
+        while (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
+            if (spins > 0) {
+                if (live_poll_abandon(P, spins, bad, is_sentinel(za_f) ? i1 : i2, gpass)) return true;
+                __builtin_amdgcn_s_sleep(1);
+            } else {
+                spins = 1;
+            }
+            if (bad) {
+                if (is_sentinel(za_f)) za_f = live_reload(P, &P.Z[(int64_t)i1 * ZSC + fp]);
+                if (is_sentinel(zb_f)) zb_f = live_reload(P, &P.Z[(int64_t)i2 * ZSC + fp]);
+                bad = is_sentinel(za_f) | is_sentinel(zb_f);
+            }
+        }
+        wave_lds_handoff();
+        write_increment();
+        wave_lds_handoff();
+        load_rows();
+        return false;
+    };
+
+    {
+        front_reads(0, false);                           // the first pass's front end (its DMA: that of pass AHEAD)
+        const bool bad0 = front_bad();
+        write_increment();
+        front_rest(PS2_AHEAD);
+        logu = logu_n;
+        if constexpr (TEMPER) temp = temp_n;
+        if constexpr (LIVE) {
+            if (__builtin_amdgcn_ballot_w64(bad0) != 0ull) {
+                if (reread(bad0, 0, 0)) { leave(); return; }
+            }
+        }
+    }
+
+    int ip = 0;
+    int64_t nb = 0;
+    unsigned int cnt_total = 0, cnt_first = 0;
+#ifdef DEMCZ_STAMPS
+    // diagnostic build (scripts/ps2_stamps.py): shader-clock sums per segment of a pass.  A stamp drains the wave's outstanding
+    // LDS / scalar-memory operations, so the segments add up to MORE than an unstamped pass: read them as proportions.
+    unsigned long long sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sa_nbad = 0;
+    const unsigned long long sa_start = __builtin_readcyclecounter();
+    const unsigned long long sa_rt0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz, the same clock on every CU: start skew
+#define PS2_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); sa[i] += t_ - sa_t; sa_t = t_; } while (0)
+#else
+#define PS2_T(i) do { } while (0)
+#endif
+    const bool lane_state = nn == 0;
+    // one pass; S = ip mod 3 (its own raw slot: the one its front end's DMA refills).  Returns 0: go on, 1: that was the last
+    // pass, 2: a LIVE wait was abandoned.
+    auto pass = [&](auto slot_tag, auto first_tag) __attribute__((always_inline)) -> int {
+        constexpr int S = decltype(slot_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;       // the launch's first pass: no history of a pass before it to store
+        constexpr int SN = (S + 1) % PS2_SLOTS;
+#ifdef DEMCZ_STAMPS
+        unsigned long long sa_t = __builtin_readcyclecounter();
+#endif
+        // The pass is written in the order it should ISSUE (one wave per SIMD issues in order: a stalled instruction stalls
+        // everything behind it), and the scheduling barriers keep the compiler from re-ordering across the phases:
+        //   A  history store of the pass before, the next pass's raw values out of its slot      (LDS latency hides under B)
+        //   B  every node's candidate: state + its rows in order                                 (25 dependent-in-fives adds)
+        //   C  log-density of the candidates; the next pass's increments into LDS between its fmas
+        //   D  ancestor's log-density asked for (bpermute); in its shadow the table write, the DMA, the next pass's node rows
+        //   E  accept tests, the path taken, the winner; its row asked for
+        //   F  in that read's shadow: history values, counts, the boundary, the sentinel check
+        const bool boundary = (--tb == 0);
+        [[maybe_unused]] unsigned int pub_seen = 0u;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FIRST) {
+            store_history(0xffffff00u);                   // (nothing yet: out of range, but the operation is there to be counted)
+        } else {
+            store_history(h_off);                         // the pass before's
+            h_off += h_inc;
+        }
+        front_reads(SN, true);
+        if constexpr (LIVE) {
+            if (boundary) pub_seen = __hip_atomic_load(&pub_done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const double logu_c = logu;
+        [[maybe_unused]] const double temp_c = temp;
+        double cand[D];
+#pragma unroll
+        for (int p = 0; p < D; ++p) cand[p] = x[p];
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+#pragma unroll
+            for (int p = 0; p < D; ++p) cand[p] = cand[p] + mget(j, p);
+        PS2_T(0);                      // history store, raw values asked for, candidate adds
+        __builtin_amdgcn_sched_barrier(0);
+        write_increment();
+        const bool bad_n = front_bad();
+        double lpp;
+        if constexpr (TARGET == TARGET_MVNORMAL) {
+            double q = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double acc = Wc[(i * (i + 1)) / 2] * (cand[0] - muc[0]);
+#pragma unroll
+                for (int j = 1; j <= i; ++j) acc = fma(Wc[(i * (i + 1)) / 2 + j], cand[j] - muc[j], acc);
+                q = (i == 0) ? acc * acc : fma(acc, acc, q);
+            }
+            lpp = fma(-0.5, q, c0v);
+        } else {
+            double q = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const double rr = cand[i] - muc[i];
+                q = (i == 0) ? rr * rr : fma(rr, rr, q);
+            }
+            lpp = -q;
+        }
+        PS2_T(1);                      // log-density + the next pass's increments
+        __builtin_amdgcn_sched_barrier(0);
+        // the state's own row keeps the state's log-density (lane 0's candidate IS the state)
+        const double lb = lane_state ? xlp : lpp;
+        unsigned int m32, path, accp;
+        unsigned long long chg_a, chg_r, m64, path64;
+        const unsigned long long lbb = (unsigned long long)__double_as_longlong(lb);
+        // The ancestor's log-density: two ds_bpermute, FIRST in the LDS queue, so that the table write, the DMA and the next
+        // pass's row reads are issued in their shadow.  Written as asm: the compiler sinks the builtin to its first use (behind
+        // those reads: the accept tests would then wait for all of them), and its own wait for the result would be lgkmcnt(0).
+        unsigned int blo, bhi;
+        asm volatile("ds_bpermute_b32 %0, %2, %3\n\tds_bpermute_b32 %1, %2, %4"
+                     : "=&v"(blo), "=&v"(bhi) : "v"(anc4), "v"((unsigned int)lbb), "v"((unsigned int)(lbb >> 32)) : "memory");
+        {
+            double row[CR];
+#pragma unroll
+            for (int p = 0; p < CR; ++p) row[p] = (p < D) ? cand[p] : ((p == D) ? lb : 0.0);
+#pragma unroll
+            for (int q = 0; q < CR / 2; ++q) reinterpret_cast<double2*>(ct_w + lane * CR)[q] = make_double2(row[2 * q], row[2 * q + 1]);
+        }
+        issue(pr_f, S);
+        wave_lds_handoff();
+        load_rows();
+        PS2_T(2);                      // bpermute asked for, table write, DMA issue, node rows asked for
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            // behind the two bpermutes in this wave's LDS queue: CR/2 table writes and R * NPIECE row reads; LDS operations
+            // complete in order, and the wait's field holds at most 15
+            constexpr int BEHIND = CR / 2 + R * NPIECE;
+            asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(BEHIND < 15 ? BEHIND : 15) : "memory");
+            asm volatile("" : "+v"(blo), "+v"(bhi));
+            const double lpb = __longlong_as_double((long long)(((unsigned long long)bhi << 32) | blo));
+            const double d0 = lpp - lpb;
+            double dlt = d0;
+            if constexpr (TEMPER) dlt = dlt / temp_c;
+            m64 = __builtin_amdgcn_ballot_w64(logu_c < dlt);
+            m32 = hh ? (unsigned int)(m64 >> 32) : (unsigned int)m64;           // its own chain's accept mask
+            chg_a = __builtin_amdgcn_fcmp(d0, 0.0, 14 /* UNE */);
+            chg_r = __builtin_amdgcn_fcmp(lpb - lpb, 0.0, 14);
+            // on the path actually taken: every ancestor decided the way that leads here
+            const bool onp = ((m32 ^ need1) & needm) == 0u;
+            path64 = __builtin_amdgcn_ballot_w64(onp) & 0xfffffffefffffffeull;
+            path = hh ? (unsigned int)(path64 >> 32) : (unsigned int)path64;
+            accp = path & m32;
+        }
+        PS2_T(3);                      // accept tests, path
+        const unsigned int accp1 = accp | 1u;                                   // bit 0: the state the pass started from
+        const unsigned int win = 31u - (unsigned int)__builtin_clz(accp1);
+        wave_lds_handoff();
+        // the new state: the winner's row of the table, every lane reading the same address
+        {
+            const double* wr = ct_w + (hh * 32 + win) * CR;
+#pragma unroll
+            for (int q = 0; q < CR / 2; ++q) {
+                const double2 t = reinterpret_cast<const double2*>(wr)[q];
+                if (2 * q < D) x[2 * q] = t.x; else if (2 * q == D) xlp = t.x;
+                if (2 * q + 1 < D) x[2 * q + 1] = t.y; else if (2 * q + 1 == D) xlp = t.y;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        logu = logu_n;
+        if constexpr (TEMPER) temp = temp_n;
+        // history rows of the pass: read now, stored during the next pass
+        {
+            const unsigned int wa = accp1 & hmask;
+            const unsigned int wj = 31u - (unsigned int)__builtin_clz(wa);
+            hv = tab_h[wj * CR];
+        }
+        {
+            const unsigned long long chm = ((path64 & m64 & chg_a) | (path64 & ~m64 & chg_r)) & actm;
+            cnt_total += (unsigned int)__builtin_popcountll(chm);
+            if constexpr (FIRST) cnt_first = (unsigned int)((chm >> 1) & 1ull) + (unsigned int)((chm >> 33) & 1ull);
+        }
+        PS2_T(4);                      // winner's row asked for, history values, counts
+        if (boundary) {                // a generation divisible by K ended the pass: runchain!'s append, demcz.jl:88-91
+            const double v = ct_w[(hh * 32 + win) * CR + ((l5 < D) ? l5 : 0)];
+            if constexpr (LIVE) {
+                while (pub_seen + (unsigned int)PS_PUB <= (unsigned int)nb) {          // (bounded by the publisher: demcz_kernels_rec.h)
+                    __builtin_amdgcn_s_sleep(1);
+                    pub_seen = __hip_atomic_load(&pub_done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (l5 < D) pub_rows[((w * PS_PUB + (int)((unsigned int)nb % PS_PUB)) * NCH + hh) * D + l5] = v;
+                asm volatile("" ::: "memory");
+                if (lane == 0) __hip_atomic_store(&pub_seq[w], (unsigned int)nb + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                if (l5 < D && act && P.do_append) P.Zw[(P.M_append + nb * P.N + c) * P.ZS + l5] = v;
+            }
+            if (l5 < D && act && P.snap) P.snap[nb * P.N * D + c + P.N * l5] = v;
+            ++nb;
+            tb = tbK;
+        }
+        PS2_T(5);                      // boundary: hand the row to the publisher
+        if (++ip == npass) return 1;
+        if constexpr (LIVE) {
+            // only now -- this wave's own row is on its way -- may it wait for rows of other waves
+            if (__builtin_amdgcn_ballot_w64(bad_n) != 0ull) {
+#ifdef DEMCZ_STAMPS
+                ++sa_nbad;
+#endif
+                if (reread(bad_n, SN, ip * R)) return 2;
+            }
+        }
+        PS2_T(6);                      // waiting for rows other waves had not published
+        wave_lds_handoff();
+        return 0;
+    };
+    int st = pass(std::integral_constant<int, 0>{}, std::true_type{});
+    while (!st) {
+        st = pass(std::integral_constant<int, 1>{}, std::false_type{});
+        if (st) break;
+        st = pass(std::integral_constant<int, 2>{}, std::false_type{});
+        if (st) break;
+        if constexpr (PS2_SLOTS >= 4) {
+            st = pass(std::integral_constant<int, 3 % PS2_SLOTS>{}, std::false_type{});
+            if (st) break;
+        }
+        if constexpr (PS2_SLOTS >= 5) {
+            st = pass(std::integral_constant<int, 4 % PS2_SLOTS>{}, std::false_type{});
+            if (st) break;
+        }
+        st = pass(std::integral_constant<int, 0>{}, std::false_type{});
+    }
+    if (st == 2) { leave(); return; }
+    store_history(h_off);     // the last pass's
+    {
+        double xv = x[0];
+#pragma unroll
+        for (int p = 1; p < D; ++p) xv = (l5 == p) ? x[p] : xv;
+        if (l5 < D && act) P.Xcur[c + P.N * l5] = xv;
+        if (l5 == 0 && act) P.lpcur[c] = xlp;
+    }
+    wave_store_counts(P, wv, cnt_total, cnt_first);
+#ifdef DEMCZ_STAMPS
+    if (P.stamps && lane == 0 && wv < 65536) {
+        unsigned long long* o = P.stamps + (size_t)wv * 16;
+        for (int i = 0; i < 7; ++i) o[i] = sa[i];
+        o[8] = __builtin_readcyclecounter() - sa_start; o[11] = sa_nbad; o[14] = (unsigned long long)npass; o[15] = 2;
+        o[9] = sa_rt0; o[10] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+#undef PS2_T
+    leave();
+}
+
+}  // namespace demcz

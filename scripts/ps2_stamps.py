@@ -38,6 +38,11 @@ e.set_kernel_timing(True)
 e.run(G // 2 + 1, G, 2.38)
 nl, ms = e.get_kernel_time()
 lib = _lib.load()
+kname = e.kernel_name()
+NCHAINS = N
+if "ps2d" in kname:          # two chains to a wave: the stamps are per WAVE
+    N = (N + 1) // 2
+print(f"kernel {kname}: {NCHAINS} chains, {N} chain waves")
 buf = np.zeros((N, 16), dtype=np.uint64)
 lib.demcz_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 rc = lib.demcz_debug_read_stamps(e._h, buf.ctypes.data_as(C.c_void_p), N)
