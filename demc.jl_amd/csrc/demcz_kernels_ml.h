@@ -403,6 +403,7 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
         }
     }
     double lp = P.lpcur[c];
+    [[maybe_unused]] const double qscale = (QB == 1) ? P.gamma : P.gamma / sqrt((double)(2 * (QB > 0 ? QB : 1)));
     // QB > 0: what is kept per chain between block-steps -- Pc[k][b] = P_{p_k, b} of this lane's rows, Qc[b] (every lane of the
     // chain holds the same) -- started from the state the launch begins with (two LDS hand-offs, once)
     [[maybe_unused]] double Pc[NP][QNB], Qc[QNB];
@@ -448,13 +449,20 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
     [[maybe_unused]] const double2* rec2 = reinterpret_cast<const double2*>(P.rec_in);
     [[maybe_unused]] double2 e_pre = make_double2(0.0, 0.0);        // entry of the block-step issue_draws is called for next
     [[maybe_unused]] int64_t row1_n = 0, row2_n = 0, row1_c = 0, row2_c = 0;
+    // (QB > 0: equal blocks -- length, Philox blocks per step, a block's offset and a parameter's place in it are arithmetic,
+    //  not look-ups in the LDS tables: four dependent LDS round trips less per block-step, C3 45.9 -> 41.5 us per K-window.
+    //  Tried next and dropped: every lane fetching its own pieces of the record -- row pair, log u, its normals: four small loads a
+    //  block-step ahead -- instead of one entry per lane handed round through LDS: 43.2-43.7 us, the extra vector-memory
+    //  instructions cost more than the LDS write, three reads and two hand-offs they replace.)
+    constexpr int QSB = (QB > 0) ? 2 + (QB + 1) / 2 : 0;
     auto load_entry = [&](int gi, int ib) {
-        const int b = blen_l[ib];
+        const int b = (QB > 0) ? QB : blen_l[ib];
         const int nn = (b == 1) ? 1 : b;
         const int Sb = 2 + (nn + 1) / 2;
         const int role = (r < Sb) ? r : Sb - 1;
         const int g = (gi < P.ngen) ? gi : P.ngen - 1;
-        return rec2[((size_t)g * (size_t)P.N + (size_t)c) * (size_t)P.S + (size_t)(boff_l[ib] + role)];
+        const int bo = (QB > 0) ? ib * QSB : boff_l[ib];
+        return rec2[((size_t)g * (size_t)P.N + (size_t)c) * (size_t)P.S + (size_t)(bo + role)];
     };
     if constexpr (REC) {
         if constexpr (LIVE) {       // an earlier launch of the run already failed: do not wait again
@@ -467,7 +475,7 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
     double za[NP], zb[NP], zt[NP], logu_next;
     int tslot[NP];
     auto issue_draws = [&](int gi, int ib) {
-        const int b = blen_l[ib];
+        const int b = (QB > 0) ? QB : blen_l[ib];
         const int nn = (b == 1) ? 1 : b;
         const int Sb = 2 + (nn + 1) / 2;
         const int role = (r < Sb) ? r : Sb - 1;
@@ -488,7 +496,7 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
             for (int k = 0; k < NP; ++k) {
                 const int p = r + L * k;
                 const int pc = (p < D) ? p : 0;
-                const int ts = (p < D) ? slot_l[ib * D + pc] : -1;
+                const int ts = (QB > 0) ? ((p < D && p >= ib * QB && p < ib * QB + QB) ? p - ib * QB : -1) : ((p < D) ? slot_l[ib * D + pc] : -1);
                 tslot[k] = ts;
                 const int zi = (b == 1 || ts < 0) ? 0 : ts;
                 zt[k] = reinterpret_cast<const double*>(rec)[(gq * L + 1 + zi / 2) * 2 + (zi & 1)];
@@ -500,7 +508,7 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
             return;
         }
         uint64_t r1, r2, i1, i2;
-        rng.block(P.seed, chain, (uint64_t)(P.g_first + gi - 1) * (uint64_t)P.S + (uint64_t)(boff_l[ib] + role), r1, r2);
+        rng.block(P.seed, chain, (uint64_t)(P.g_first + gi - 1) * (uint64_t)P.S + (uint64_t)(((QB > 0) ? ib * QSB : boff_l[ib]) + role), r1, r2);
         const double lg = dm_log(u_open(r1));
         double z0, z1;
         {
@@ -523,7 +531,7 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
         for (int k = 0; k < NP; ++k) {
             const int p = r + L * k;
             const int pc = (p < D) ? p : 0;
-            const int ts = (p < D) ? slot_l[ib * D + pc] : -1;
+            const int ts = (QB > 0) ? ((p < D && p >= ib * QB && p < ib * QB + QB) ? p - ib * QB : -1) : ((p < D) ? slot_l[ib * D + pc] : -1);
             tslot[k] = ts;
             const int zi = (b == 1 || ts < 0) ? 0 : ts;
             zt[k] = reinterpret_cast<const double*>(rec)[(gq * L + 1 + zi / 2) * 2 + (zi & 1)];
@@ -577,7 +585,7 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
             }
             double delta[NP];
             bool inb[NP];
-            const double scale = bscale_l[ib];
+            const double scale = (QB > 0) ? qscale : bscale_l[ib];
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const double diff = za[k] - zb[k];
