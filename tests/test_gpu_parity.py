@@ -61,7 +61,11 @@ BLOCKS_D20 = [range(0, 5), range(5, 10), range(10, 15), range(15, 20)]
 
 @pytest.mark.parametrize("N,d,G,blocks", [(70, 6, 35, BLOCKS_D6), (256, 20, 23, BLOCKS_D20), (64, 20, 21, None),
                                           (33, 10, 30, [range(0, 10)]), (40, 5, 30, [[4, 3, 2, 1, 0]]),
-                                          (16, 13, 25, [range(0, 7), range(7, 13)]), (8, 64, 12, None)])
+                                          (16, 13, 25, [range(0, 7), range(7, 13)]), (8, 64, 12, None),
+                                          # consecutive blocks of unequal length: the sums cut at their boundaries
+                                          # through the group-start mask -- one-lane, 8- / 16-lane and generic kernels
+                                          (48, 10, 30, [range(0, 7), [9, 7, 8]]), (130, 20, 22, [range(0, 10), range(10, 13), range(13, 20)]),
+                                          (24, 5, 40, [[1, 0], [2], [4, 3]]), (20, 7, 25, [[0, 1, 2], [3, 4], [6, 5]])])
 @pytest.mark.parametrize("lanes", [1, 0])
 def test_mvnormal_blocks_and_generic_d_bit_exact(demc, oracle, N, d, G, blocks, lanes):
     """Block updates (C3 layout), permuted single block (not the FULL fast path), runtime-d kernel;

@@ -30,3 +30,64 @@ def test_iso_quad_and_linreg(oracle, demc):
     B = w["beta"] + 0.1 * np.random.default_rng(1).standard_normal((40, 10))
     ref = np.array([-0.5 * np.sum((w["y"] - w["design"] @ b) ** 2) for b in B])
     assert np.allclose(oracle.logp(prob, B), ref, rtol=1e-12)
+
+
+def _grouped_logp_python(t, x, offs):
+    """DESIGN.md section 3, "grouped by the blocks", written out with Python floats and math.fma-free exact steps is not
+    possible (no fma in Python 3.10): the restatement below uses numpy longdouble products rounded ONCE per fma, which is what
+    an fma is for operands whose product fits 80-bit precision's 64-bit significand only approximately -- so it is compared at
+    1 ulp, and the GROUPING (which terms go into which partial sum, in which order) is what it pins."""
+    d = len(t.mu)
+    r = np.asarray(x, dtype=np.float64) - t.mu
+    W = np.asarray(t.W)
+
+    def fma(a, b, c):
+        return float(np.longdouble(a) * np.longdouble(b) + np.longdouble(c))
+    ng = len(offs) - 1
+    q = 0.0
+    for g in range(ng):
+        Qg = 0.0
+        for i in range(offs[g], offs[g + 1]):
+            y = 0.0
+            for gb in range(g + 1):
+                jl, jh = offs[gb], min(offs[gb + 1] - 1, i)
+                P = float(W[i, jl] * r[jl])
+                for j in range(jl + 1, jh + 1):
+                    P = fma(W[i, j], r[j], P)
+                y = P if gb == 0 else y + P
+            Qg = y * y if i == offs[g] else fma(y, y, Qg)
+        q = Qg if g == 0 else q + Qg
+    return fma(-0.5, q, t.c0)
+
+
+@pytest.mark.parametrize("d,blocks", [(20, [list(range(0, 5)), list(range(5, 10)), list(range(10, 15)), list(range(15, 20))]),
+                                      (6, [[0], [1, 2], [5, 3, 4]]), (5, [[1, 0], [2], [4, 3]]), (10, [list(range(0, 7)), [7, 8, 9]])])
+def test_mvnormal_sums_grouped_by_consecutive_blocks(oracle, demc, d, blocks):
+    """Round 4: with blocks that are consecutive index ranges the oracle cuts the quadratic form's sums at the block boundaries
+    (oracle/demcz_oracle.c: mvn_groups, target_logp).  The grouped value follows the written-out order to the last bit or one,
+    agrees with the one-group order (and scipy) to rounding, and differs from it in the last bits somewhere -- it IS another order."""
+    w = demc.workloads.mvnormal_problem(d, 8)
+    t = w["target"]
+    grouped = oracle.Problem(8, d, 10, 100, w["eps_scale"], 1, blocks=blocks, target=t.spec())
+    plain = oracle.Problem(8, d, 10, 100, w["eps_scale"], 1, target=t.spec())
+    rng = np.random.default_rng(100 + d)
+    X = w["mu"] + rng.standard_normal((300, d)) * 0.2
+    a, b = oracle.logp(grouped, X), oracle.logp(plain, X)
+    assert np.allclose(a, b, rtol=1e-13, atol=1e-11)
+    assert np.any(a != b), "the grouped order must be a different summation order"
+    offs = [0] + list(np.cumsum([len(bl) for bl in blocks]))
+    ref = np.array([_grouped_logp_python(t, x, offs) for x in X[:60]])
+    assert np.all(np.abs(a[:60] - ref) <= 2 * np.spacing(np.abs(ref))), "grouping differs from the written-out order"
+    assert np.allclose(a, stats.multivariate_normal(w["mu"], w["Sigma"]).logpdf(X), rtol=1e-11, atol=1e-9)
+
+
+@pytest.mark.parametrize("blocks", [[[3], [0], [4], [1], [2]], [[0, 2], [1, 3, 4]], [[0, 1, 2]], [[0, 1], [1, 2, 3, 4]], [[0, 1, 2, 3, 4]]])
+def test_mvnormal_sums_stay_in_one_group_otherwise(oracle, demc, blocks):
+    """Blocks that are not consecutive ranges in order (permuted, interleaved, not covering, overlapping) or a single block keep
+    the order of rounds 1-3: bit-equal to the run without block structure."""
+    d = 5
+    w = demc.workloads.mvnormal_problem(d, 8)
+    X = w["mu"] + np.random.default_rng(3).standard_normal((100, d)) * 0.3
+    a = oracle.logp(oracle.Problem(8, d, 10, 100, w["eps_scale"], 1, blocks=blocks, target=w["target"].spec()), X)
+    b = oracle.logp(oracle.Problem(8, d, 10, 100, w["eps_scale"], 1, target=w["target"].spec()), X)
+    assert np.array_equal(a, b)
