@@ -51,3 +51,12 @@ def test_product_does_not_reference_oracle():
         if p.is_file() and p.suffix in (".py", ".h", ".hip", ".cpp"):
             txt = p.read_text()
             assert "oracle_py" not in txt and "libdemcz_oracle" not in txt and "demcz_oracle" not in txt, p
+
+
+def test_two_chain_kernel_is_what_its_generator_makes():
+    """demcz_kernels_ps2d.h is derived from demcz_kernels_ps2.h by scripts/gen_ps2d.py; a change to the one-chain kernel must be
+    carried over (re-run the script) or the two drift apart."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "gen_ps2d.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, "demcz_kernels_ps2d.h differs from what scripts/gen_ps2d.py generates: " + r.stderr[-500:]
