@@ -950,6 +950,9 @@ static void peer_detach(demcz_handle* h)
             if (h->ipc_mapped[r]) { (void)hipIpcCloseMemHandle(h->ipc_mapped[r]); h->ipc_mapped[r] = nullptr; }
     } else if (h->peer_mode == 2) {
         bool met = false;
+        // (every rank destroys its handle at the same point of the program; one that does not -- a handle left to a garbage
+        //  collector -- must not hold the others for the full communication deadline: five seconds, then the archive is leaked)
+        h->comm_timeout_ms = (h->comm_timeout_ms > 0) ? std::min<int64_t>(h->comm_timeout_ms, 5000) : 5000;
         if (!h->comm_dead && h->comm && h->d_err_all) {
             if (ncclAllReduce(h->d_err_all + 1, h->d_err_all + 1, 1, ncclUint32, ncclMax, h->comm, h->stream) == ncclSuccess)
                 met = sync_stream(h, h->stream, "demcz_destroy (peers)") == DEMCZ_OK;

@@ -332,6 +332,9 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     // Front end of the pass whose raw slot is `slot`, in three parts that the pass loop places where their latencies hide:
     // (1) the raw values out of the slot (LDS reads); (2) the increments into LDS; (3) the DMA of the pass AHEAD after it (into
     // `slot_dma`) and this pass's node rows into registers.
+#ifdef DEMCZ_STAMPS
+    unsigned long long sa_spins = 0;       // poll iterations of all waits (scripts/ps2_stamps.py)
+#endif
     uint64_t pr_f = 0;
     double logu_n = 0.0;
     [[maybe_unused]] double temp_n = 1.0;
@@ -376,6 +379,9 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
                 bad = is_sentinel(za_f) | is_sentinel(zb_f);
             }
         }
+#ifdef DEMCZ_STAMPS
+        sa_spins += (unsigned long long)spins;
+#endif
         wave_lds_handoff();
         write_increment();
         wave_lds_handoff();
@@ -609,7 +615,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     if (P.stamps && lane == 0 && c < 65536) {
         unsigned long long* o = P.stamps + (size_t)c * 16;
         for (int i = 0; i < 7; ++i) o[i] = sa[i];
-        o[8] = __builtin_readcyclecounter() - sa_start; o[11] = sa_nbad; o[14] = (unsigned long long)npass; o[15] = 2;
+        o[8] = __builtin_readcyclecounter() - sa_start; o[11] = sa_nbad; o[12] = sa_spins; o[14] = (unsigned long long)npass; o[15] = 2;
         o[9] = sa_rt0; o[10] = __builtin_amdgcn_s_memrealtime();
     }
 #endif

@@ -195,16 +195,21 @@ __device__ __forceinline__ void live_publish(const WindowParams& P, int64_t b, i
     live_store(P.Zw + off, v);
     for (int r = 0; r < P.n_peers; ++r) live_store_sys(P.peer_Z[r] + off, v);
 }
-// The publisher's wait in front of a round of stores.  One replica: for ALL its earlier stores (the rows that arrive during their
-// flight then leave together in one instruction -- demcz_kernels_ps.h).  With peers a round is n_peers + 1 stores per lane and an
-// acknowledgement from another GPU's memory takes a few microseconds over xGMI: waiting for it before every round would hold
-// the publisher -- and through its ring the chain waves -- to one boundary per link round trip.  Nothing needs the
-// acknowledgement (readers look at the data; the launch's end waits for everything), so with peers the publisher only keeps the
-// number of stores in flight within what the wave's counter can count (at most 63): up to 40 outstanding before a round.
-__device__ __forceinline__ void publisher_wait(const WindowParams& P)
+// The publisher's wait in front of a round of stores: none for their acknowledgements -- nothing needs them (readers look at
+// the data; the launch's end waits for everything) -- only that the number of stores in flight stays within what the wave's
+// counter can count (at most 63): up to 40 outstanding before a round of n_peers + 1 stores per lane (pw: two rounds).  With
+// peers an acknowledgement crosses xGMI (microseconds): waiting for it would hold the publisher -- and through its ring the
+// chain waves -- to one boundary per link round trip.  On one GPU rounds 2-3 waited for ALL earlier stores ("the rows that arrive
+// during their flight then leave together in one instruction"); measured in round 4 (scripts/ab_pubwait.sh,
+// profiles/r04n_publisher_wait.txt): without the wait C2's launch is 140.1-141.4 us against 142.6-143.8, the other configs
+// unchanged within noise -- a row no longer waits behind the acknowledgement of its workgroup neighbours' rows.
+__device__ __forceinline__ void publisher_wait(const WindowParams&)
 {
-    if (P.n_peers == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+#ifdef DEMCZ_PUB_WAIT          // the A/B's other side only (scripts/ab_pubwait.sh): rounds 2-3's wait for all earlier stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+#endif
 }
 // a re-read of a row that showed the sentinel: past the caches; rows a PEER writes are asked for at system scope
 __device__ __forceinline__ double live_reload(const WindowParams& P, const double* p)

@@ -59,6 +59,9 @@ names = ["history store, DMA wait, raw values asked for, candidate adds", "log-d
 for i, nm in enumerate(names):
     print(f"  {(s[:, i] / n).mean():8.0f} per pass  ({100 * s[:, i].sum() / s[:, 8].sum():5.1f} %)  {nm}")
 print(f"  passes that waited for a row: {100 * (s[:, 11] / n).mean():.2f} %")
+if s[:, 11].sum() > 0:
+    print(f"  per waiting pass: {s[:, 6].sum() / s[:, 11].sum():.0f} clocks in the wait segment, {s[:, 12].sum() / s[:, 11].sum():.1f} polls "
+          f"(a poll = one round of past-the-caches loads of the rows still missing + s_sleep), {s[:, 6].sum() / max(s[:, 12].sum(), 1):.0f} clocks per poll")
 if buf[:, 9].max() > 0:      # window_kernel_ps2: when each chain wave began and ended (100 MHz clock common to all CUs)
     t0, t1 = buf[:, 9].astype(np.int64), buf[:, 10].astype(np.int64)
     b = (t0 - t0.min()) / 100.0
