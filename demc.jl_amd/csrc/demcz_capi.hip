@@ -172,6 +172,7 @@ struct demcz_handle {
     double* dX = nullptr;
     double* dlp = nullptr;
     double* dchain = nullptr;
+    double* dchain_alloc = nullptr;   // what the pool gave (dchain may sit a few bytes into it: DEMCZ_DEBUG_HIST_SKEW)
     double* dlogobj = nullptr;
     double* dlp_origin = nullptr;   // log_obj of every chain when the history window opened
     bool origin_valid = false;
@@ -571,9 +572,9 @@ static void free_all(demcz_handle* h)
         } else {
             g_dev_pool.discard(h->dZ);
         }
-        if (h->hist_joint) { if (drained) g_dev_pool.release(h->dchain, h->cfg.device_id); else g_dev_pool.discard(h->dchain); }
+        if (h->hist_joint) { if (drained) g_dev_pool.release(h->dchain_alloc, h->cfg.device_id); else g_dev_pool.discard(h->dchain_alloc); }
         h->dZ = nullptr;
-        if (h->hist_joint) h->dchain = nullptr;
+        if (h->hist_joint) { h->dchain = nullptr; h->dchain_alloc = nullptr; }
     }
     if (h->hs_stream) stream_release(h->cfg.device_id, h->hs_stream, drained);
     if (drained) { g_host_pool.release(h->hs_chain, -1); g_host_pool.release(h->hs_logobj, -1); }
@@ -860,7 +861,10 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
     CRCHK(dev_malloc(h->cfg.device_id, (void**)&h->dlp, (size_t)N * sizeof(double)));
     if (cfg->Gcap > 0) {
         // (one allocation: a window kernel's history store of a pass covers both arrays with one buffer descriptor)
-        CRCHK(g_dev_pool.acquire((void**)&h->dchain, (size_t)N * (d + 1) * cfg->Gcap * sizeof(double), cfg->device_id));
+        // (DEMCZ_DEBUG_HIST_SKEW=<bytes>: the history that many bytes into its allocation -- scripts/ps2_stamps.py, address classes)
+        const size_t skew = getenv("DEMCZ_DEBUG_HIST_SKEW") ? ((size_t)atol(getenv("DEMCZ_DEBUG_HIST_SKEW")) & ~(size_t)7) : 0;
+        CRCHK(g_dev_pool.acquire((void**)&h->dchain_alloc, (size_t)N * (d + 1) * cfg->Gcap * sizeof(double) + skew, cfg->device_id));
+        h->dchain = h->dchain_alloc + skew / sizeof(double);
         h->dlogobj = h->dchain + (size_t)N * d * cfg->Gcap;
         h->hist_joint = true;
         CRCHK(hipMemsetAsync(h->dchain, 0, (size_t)N * (d + 1) * cfg->Gcap * sizeof(double), h->stream));   // demcz.jl:24

@@ -4,7 +4,7 @@
 // shadowed lanes 0..31.  Here they run a second chain: lane l works for chain NCH * wave + (l >> 5), as node l & 31 of THAT
 // chain's tree.  What a wave has once per chain: a KiB of every raw slot and a DMA instruction per pass (a pass's rows, normals,
 // log u and indices are 54 of an instruction's 64 lanes), a block of increments, half of the candidate table (rows 0..31 /
-// 32..63), a row in the publisher's ring.  What it has once: the pass structure, the boundary counter, the history store (30 + 30
+// 32..63), a row in the publisher's ring.  What it has once: the pass structure, the boundary counter, the history hand-off (30 + 30
 // of its lanes), the accept compare -- one ballot whose halves are the two chains' masks -- and the instruction stream: the pass
 // costs what it cost (one DMA instruction more) and resolves five generations of TWO chains.  The LIVE launch therefore holds
 // 2048 chains where it held 1024 (one five-wave workgroup of eight chains per CU), at the same time per launch.
@@ -59,34 +59,196 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     __shared__ __attribute__((aligned(16))) double ctab[PS_CHAINS][64 * CR];       // row l: lane l's candidate (rows 0..31: the first chain's tree, 32..63: the second's)
     __shared__ double pub_rows[LIVE ? PS_CHAINS * PS_PUB * NCH * D : 1];
     __shared__ unsigned int pub_seq[PS_CHAINS], pub_done[PS_CHAINS], pub_exit[PS_CHAINS];
+    // The history of a LIVE launch may go through the publisher wave (HRING).  Why: a store in the chain wave's own queue is
+    // four 16-byte pieces per row and workgroup (a wave's two chains are neighbours), and history stores into one 128-byte column
+    // in eight of the rows' KiBs (address bits 9:7 = 3 on every box measured) are accepted at half the rate of the others when
+    // reads run beside them (scripts/probes/store_classes.hip); the CU's memory pipeline is in order, so the chain waves of the
+    // workgroups that own those columns run their DMAs late, and everyone waits for their rows.  Through the ring a row's columns
+    // of ALL the workgroup's chains leave as ONE contiguous piece (64 bytes for eight chains): a quarter of the requests.
+    // Ring: slot = pass mod PS2_HSLOTS; in it row r (lane r of a chain wave: (generation, element)) of chain kk of the workgroup
+    // at r * (HKK + 1) + kk -- the odd stride keeps both the chain waves' writes (30 rows of one kk) and the publisher's reads
+    // (consecutive kk of consecutive rows) off each other's banks.
+    constexpr int NCHR = NCH;                              // chains of a chain wave
+    constexpr bool HRING = LIVE && (PS2_HRING_TWO != 0);
+    constexpr int HKK = PS_CHAINS * NCHR, HROWS = R * (D + 1), HSL = ((HROWS * (HKK + 1) + 1) / 2) * 2;
+    __shared__ double hist_ring[HRING ? PS2_HSLOTS * HSL : 1];
+    __shared__ unsigned int hist_seq[PS_CHAINS], hist_done[1];
+    // where lane (j, p) of a chain's wave stores element p of generation j's row of the history (p == D: log_obj; chain and
+    // log_obj are one allocation), and by how much that moves per pass
+    const bool hist = P.chain != nullptr;
+    auto hist_offsets = [&](bool hl_, int hj_, int hp_, int64_t c_, unsigned int& off, unsigned int& inc) __attribute__((always_inline)) {
+        if (hl_ && hist && hp_ < D) {
+            off = (unsigned int)((((P.slot_first + hj_) * D + hp_) * P.N + c_) * 8);
+            inc = (unsigned int)((int64_t)R * D * P.N * 8);
+        } else if (hl_ && hist) {
+            off = (unsigned int)((reinterpret_cast<const unsigned char*>(P.logobj) - reinterpret_cast<const unsigned char*>(P.chain)) +
+                                 ((P.slot_first + hj_) * P.N + c_) * 8);
+            inc = (unsigned int)((int64_t)R * P.N * 8);
+        } else { off = 0xffffff00u; inc = 0u; }
+    };
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hist ? reinterpret_cast<unsigned char*>(P.chain) : reinterpret_cast<unsigned char*>(const_cast<double*>(P.Z)),
+                                                                           0, hist ? (int)0xfffff000u : 0, 0x00020000);
+    // (all 64 lanes execute the store -- lanes with nothing to store point out of range)
+    auto hist_store = [&](double v, unsigned int off) __attribute__((always_inline)) {
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
+        const u32x2 vv = {(unsigned int)vb, (unsigned int)(vb >> 32)};
+#ifdef PS2_EXP_NOHIST         // (timing experiment only: every history store out of range, dropped by the descriptor -- no history)
+        off = 0xffffff00u;
+#endif
+        __builtin_amdgcn_raw_buffer_store_b64(vv, hrsrc, (int)off, 0, 0);
+    };
     if constexpr (LIVE) {
-        if (threadIdx.x < PS_CHAINS) { pub_seq[threadIdx.x] = 0u; pub_done[threadIdx.x] = 0u; pub_exit[threadIdx.x] = 0u; }
+        if (threadIdx.x < PS_CHAINS) {
+            pub_seq[threadIdx.x] = 0u; pub_done[threadIdx.x] = 0u; pub_exit[threadIdx.x] = 0u;
+            hist_seq[threadIdx.x] = 0u; hist_done[0] = 0u;
+        }
         __syncthreads();
         if (w == PS_CHAINS) {
             // the publisher wave: demcz_kernels_ps.h (identical protocol; it never leaves before its chain waves)
+#ifdef PS2_PUB_PRIO
+            __builtin_amdgcn_s_setprio(PS2_PUB_PRIO);
+#endif
             const bool pl = lane < PS_CHAINS * NCH * D;
             const int cw = pl ? lane / (NCH * D) : 0, ph = pl ? (lane / D) % NCH : 0, pp = pl ? lane % D : 0;
             const int64_t cl = ((int64_t)bxs * PS_CHAINS + cw) * NCH + ph;
             unsigned int done = 0u;
+            // the history (HRING): lane (row prl of the instruction's RPI rows, chain pk of the workgroup's HKK)
+            constexpr int RPI = 64 / HKK, NI = (HROWS + RPI - 1) / RPI;
+            const int pk = lane % HKK, prl = lane / HKK;
+            const int64_t pc = (int64_t)bxs * HKK + pk;
+            [[maybe_unused]] unsigned int hoffp[NI], hincp[NI], hq = 0u;
+            [[maybe_unused]] int hidx[NI];
+            // chain waves that run at all (the others leave at once and never post)
+            [[maybe_unused]] const int nact = (int)((P.N - (int64_t)bxs * HKK + NCHR - 1) / NCHR);
+            if constexpr (HRING) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int r = i * RPI + prl;
+                    hist_offsets(r < HROWS && pc < P.N, r / (D + 1), r % (D + 1), pc, hoffp[i], hincp[i]);
+                    hidx[i] = ((r < HROWS) ? r : HROWS - 1) * (HKK + 1) + pk;
+                }
+            }
+#ifdef DEMCZ_STAMPS
+            unsigned long long pb_iter = 0, pb_wait = 0, pb_store = 0, pb_sleep = 0, pb_pub = 0;
+            const unsigned long long pb_t0 = __builtin_readcyclecounter();
+#endif
             while (true) {
+#ifdef DEMCZ_STAMPS
+                const unsigned long long pb_a = __builtin_readcyclecounter();
+#endif
                 publisher_wait(P);
+#ifdef DEMCZ_STAMPS
+                pb_wait += __builtin_readcyclecounter() - pb_a; ++pb_iter;
+#endif
+                // one look at what the chain waves have posted: boundary rows (lane -> chain wave cw); history and who has left
+                // (lane & 3; the exit flags FIRST: a wave seen gone has posted all it ever will)
+                [[maybe_unused]] unsigned int hxl = 0u, hsl = 0u;
+                if constexpr (HRING) {
+                    hxl = __hip_atomic_load(&pub_exit[lane & (PS_CHAINS - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    asm volatile("" ::: "memory");
+                    hsl = __hip_atomic_load(&hist_seq[lane & (PS_CHAINS - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
                 const unsigned int seq = __hip_atomic_load(&pub_seq[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const bool ready = pl && seq != done;
-                if (__builtin_amdgcn_ballot_w64(ready) != 0ull) {
+                const bool pany = __builtin_amdgcn_ballot_w64(ready) != 0ull;
+                // history passes that can leave now: a pass leaves when every chain wave still running has posted it (a wave that
+                // gave up -- the launch will be redone -- no longer holds the others' history back: they would wait for ring space
+                // for ever); up to HPR passes a round
+                constexpr int HPR = 2;
+                int hn = 0;
+                if constexpr (HRING) {
+                    if (hist) {
+                        unsigned int hmin = 0xffffffffu;
+#pragma unroll
+                        for (int ww = 0; ww < PS_CHAINS; ++ww) {
+                            const unsigned int hs = (unsigned int)__builtin_amdgcn_readlane((int)hsl, ww);
+                            const bool left = __builtin_amdgcn_readlane((int)hxl, ww) != 0;
+                            if (ww < nact && !(left && hs <= hq)) hmin = (hs < hmin) ? hs : hmin;
+                        }
+                        if (hmin != 0xffffffffu && hmin > hq) hn = (hmin - hq >= (unsigned int)HPR) ? HPR : 1;
+                    }
+                }
+                // all of the round's LDS reads first (the LDS pipeline is busy with the chain waves: a round trip is long), then its
+                // stores -- the boundary rows in front: other workgroups' waves may be waiting for them
+#ifdef DEMCZ_STAMPS
+                const unsigned long long pb_s = __builtin_readcyclecounter();
+#endif
+                double v = 0.0;
+                if (ready) v = pub_rows[((cw * PS_PUB + (int)(done % PS_PUB)) * NCH + ph) * D + pp];
+                [[maybe_unused]] double hvv[HPR][NI];
+                if constexpr (HRING) {
+#pragma unroll
+                    for (int j = 0; j < HPR; ++j) {
+                        if (j < hn) {
+                            const double* slot = hist_ring + (int)((hq + (unsigned int)j) % PS2_HSLOTS) * HSL;
+#pragma unroll
+                            for (int i = 0; i < NI; ++i) hvv[j][i] = slot[hidx[i]];
+                        }
+                    }
+                }
+                if (pany) {
                     if (ready) {
-                        const double v = pub_rows[((cw * PS_PUB + (int)(done % PS_PUB)) * NCH + ph) * D + pp];
                         if (cl < P.N && P.do_append) live_publish(P, (int64_t)done, cl, pp, v);
                         ++done;
                     }
                     asm volatile("" ::: "memory");
                     if (ready && pp == 0 && ph == 0) __hip_atomic_store(&pub_done[cw], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    continue;
                 }
+                const bool hany = hn > 0;
+                if constexpr (HRING) {
+                    if (hany) {
+#pragma unroll
+                        for (int j = 0; j < HPR; ++j) {
+                            if (j < hn) {
+#pragma unroll
+                                for (int i = 0; i < NI; ++i) {
+#ifndef PS2_EXP_PUBSKIP       // (timing experiment: the publisher acknowledges the posts and stores nothing)
+                                    hist_store(hvv[j][i], hoffp[i]);
+#endif
+                                    hoffp[i] += hincp[i];
+                                }
+                            }
+                        }
+                        hq += (unsigned int)hn;
+                        asm volatile("" ::: "memory");
+                        if (lane == 0) __hip_atomic_store(&hist_done[0], hq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+#ifdef DEMCZ_STAMPS
+                if (hany) pb_store += __builtin_readcyclecounter() - pb_s;
+#endif
+                if (pany) continue;
+                if (hany) continue;
                 const bool gone = !pl || (__hip_atomic_load(&pub_exit[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u &&
                                           __hip_atomic_load(&pub_seq[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == done);
-                if (__builtin_amdgcn_ballot_w64(!gone) == 0ull) break;
+                if (__builtin_amdgcn_ballot_w64(!gone) == 0ull) {
+                    // every chain wave has left: whatever history it posted before leaving is in the ring by now
+                    bool hpend = false;
+                    if constexpr (HRING) {
+                        asm volatile("" ::: "memory");
+                        unsigned int hmin = 0xffffffffu;
+#pragma unroll
+                        for (int ww = 0; ww < PS_CHAINS; ++ww) {
+                            const unsigned int hs = __hip_atomic_load(&hist_seq[ww], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (ww < nact && hs > hq) hmin = (hs < hmin) ? hs : hmin;
+                        }
+                        hpend = hist && hmin != 0xffffffffu;
+                    }
+                    if (!hpend) break;
+                    continue;
+                }
+#ifdef DEMCZ_STAMPS
+                ++pb_sleep;
+#endif
                 __builtin_amdgcn_s_sleep(1);
             }
+#ifdef DEMCZ_STAMPS
+            if (P.stamps && lane == 0 && (int)blockIdx.x < 2048) {       // the publisher's own account: second half of the stamp buffer
+                unsigned long long* o = P.stamps + (size_t)(32768 + bxs) * 16;      // (DEMCZ_STAMP_WGS / 2, demcz_capi.hip)
+                o[0] = pb_iter; o[1] = pb_wait; o[2] = pb_store; o[3] = pb_sleep; o[4] = __builtin_readcyclecounter() - pb_t0; o[5] = hq; o[6] = done;
+            }
+#endif
             return;
         }
     }
@@ -192,18 +354,8 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     const bool hl = l5 < R * (D + 1) && act;
     const int hj = hl ? l5 / (D + 1) : 0, hp = hl ? l5 % (D + 1) : 0;
     const unsigned int hmask = (hj + 1 >= 5) ? 0xffffffffu : ((1u << (1u << (hj + 1))) - 1u);     // the state + nodes of generations 1..hj+1
-    const bool hist = P.chain != nullptr;
-    unsigned int h_off, h_inc;
-    if (hl && hist && hp < D) {
-        h_off = (unsigned int)((((P.slot_first + hj) * D + hp) * P.N + c) * 8);
-        h_inc = (unsigned int)((int64_t)R * D * P.N * 8);
-    } else if (hl && hist) {
-        h_off = (unsigned int)((reinterpret_cast<const unsigned char*>(P.logobj) - reinterpret_cast<const unsigned char*>(P.chain)) +
-                               ((P.slot_first + hj) * P.N + c) * 8);
-        h_inc = (unsigned int)((int64_t)R * P.N * 8);
-    } else { h_off = 0xffffff00u; h_inc = 0u; }
-    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hist ? reinterpret_cast<unsigned char*>(P.chain) : const_cast<unsigned char*>(zbase),
-                                                                           0, hist ? (int)0xfffff000u : 0, 0x00020000);
+    [[maybe_unused]] unsigned int h_off, h_inc;            // (!LIVE: the chain wave stores its history itself)
+    hist_offsets(hl, hj, hp, c, h_off, h_inc);
     const double* const tab_h = ct_w + hh * 32 * CR + hp;   // + winner row (of its own chain's tree) * CR
 
     // target constants
@@ -269,13 +421,32 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     double hv = 0.0;
-    // (all 64 lanes execute the store -- lanes with nothing to store point out of range -- so the count of vector-memory
-    //  operations between a DMA and its wait is the same on every path)
+    // !HRING: all 64 lanes execute the store -- lanes with nothing to store point out of range -- so the count of vector-memory
+    // operations between a DMA and its wait is the same on every path.  HRING: the pass's values go into the ring, the chain
+    // wave's memory queue holds its DMAs and nothing else (hd_seen: hist_done as last read, a pass ago).
+    [[maybe_unused]] unsigned int hposted = 0u, hd_seen = 0u;
+#ifdef DEMCZ_STAMPS
+    unsigned long long sa_hfull = 0;       // polls of a full history ring
+#endif
+    [[maybe_unused]] const int hkk = w * NCH + hh, hr = l5; // HRING: its chain among the workgroup's, its row of the pass
     auto store_history = [&](unsigned int off) __attribute__((always_inline)) {
-        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-        const unsigned long long vb = (unsigned long long)__double_as_longlong(hv);
-        const u32x2 vv = {(unsigned int)vb, (unsigned int)(vb >> 32)};
-        __builtin_amdgcn_raw_buffer_store_b64(vv, hrsrc, (int)off, 0, 0);
+        if constexpr (HRING) {
+            if (hist) {
+                while (hposted - hd_seen >= (unsigned int)PS2_HSLOTS) {          // (the publisher is PS2_HSLOTS passes behind: rare)
+                    __builtin_amdgcn_s_sleep(1);
+#ifdef DEMCZ_STAMPS
+                    ++sa_hfull;
+#endif
+                    hd_seen = __hip_atomic_load(&hist_done[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (hr < HROWS) hist_ring[(int)(hposted % PS2_HSLOTS) * HSL + hr * (HKK + 1) + hkk] = hv;
+                ++hposted;
+                asm volatile("" ::: "memory");
+                if (lane == 0) __hip_atomic_store(&hist_seq[w], hposted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        } else {
+            hist_store(hv, off);
+        }
     };
 
     double m[R][D];
@@ -313,8 +484,9 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     [[maybe_unused]] double temp_n = 1.0;
     auto front_reads = [&](int slot, bool counted) __attribute__((always_inline)) {
         const unsigned char* rw = raw_w + slot * (NCH * 1024);
-        // behind this slot's last DMA in program order: AHEAD - 1 whole passes (a store and NCH DMAs each) and this pass's store
-        if (counted) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((1 + NCH) * (PS2_AHEAD - 1) + 1) : "memory");
+        // behind this slot's last DMA in program order: AHEAD - 1 whole passes (NCH DMAs each; !HRING: and a history store) and,
+        // !HRING, this pass's store
+        if (counted) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HRING ? NCH * (PS2_AHEAD - 1) : (1 + NCH) * (PS2_AHEAD - 1) + 1) : "memory");
         za_f = *reinterpret_cast<const double*>(rw + zao);
         zb_f = *reinterpret_cast<const double*>(rw + zao + HW * 16);
         zt_f = *reinterpret_cast<const double*>(rw + zto);
@@ -409,11 +581,13 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         const bool boundary = (--tb == 0);
         [[maybe_unused]] unsigned int pub_seen = 0u;
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (FIRST) {
-            store_history(0xffffff00u);                   // (nothing yet: out of range, but the operation is there to be counted)
-        } else {
-            store_history(h_off);                         // the pass before's
-            h_off += h_inc;
+        if constexpr (!HRING) {
+            if constexpr (FIRST) {
+                store_history(0xffffff00u);               // (nothing yet: out of range, but the operation is there to be counted)
+            } else {
+                store_history(h_off);                     // the pass before's
+                h_off += h_inc;
+            }
         }
         front_reads(SN, true);
         if constexpr (LIVE) {
@@ -431,6 +605,11 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             for (int p = 0; p < D; ++p) cand[p] = cand[p] + mget(j, p);
         PS2_T(0);                      // history store, raw values asked for, candidate adds
         __builtin_amdgcn_sched_barrier(0);
+        // LIVE: the pass before's history values into the publisher's ring -- here, among the pass's other LDS writes, long after
+        // the reads that fetched them (at the head of the pass the wave would wait for those reads, and for these writes)
+#ifndef PS2_EXP_NOPOST         // (timing experiment: no history at all)
+        if constexpr (HRING && !FIRST) store_history(0u);
+#endif
         write_increment();
         const bool bad_n = front_bad();
         double lpp;
@@ -520,6 +699,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             const unsigned int wa = accp1 & hmask;
             const unsigned int wj = 31u - (unsigned int)__builtin_clz(wa);
             hv = tab_h[wj * CR];
+            if constexpr (HRING) hd_seen = __hip_atomic_load(&hist_done[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         {
             const unsigned long long chm = ((path64 & m64 & chg_a) | (path64 & ~m64 & chg_r)) & actm;
@@ -589,8 +769,10 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     if (P.stamps && lane == 0 && wv < 65536) {
         unsigned long long* o = P.stamps + (size_t)wv * 16;
         for (int i = 0; i < 7; ++i) o[i] = sa[i];
-        o[8] = __builtin_readcyclecounter() - sa_start; o[11] = sa_nbad; o[12] = sa_spins; o[14] = (unsigned long long)npass; o[15] = 2;
+        o[8] = __builtin_readcyclecounter() - sa_start; o[7] = sa_hfull; o[11] = sa_nbad; o[12] = sa_spins; o[14] = (unsigned long long)npass; o[15] = 2;
         o[9] = sa_rt0; o[10] = __builtin_amdgcn_s_memrealtime();
+        // where the wave ran: HW_REG_HW_ID (register 4: simd 5:4, cu 11:8, sh 12, se 15:13) and HW_REG_XCC_ID (register 20)
+        o[13] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
     }
 #endif
 #undef PS2_T

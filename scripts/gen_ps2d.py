@@ -33,8 +33,11 @@ sub('''            const bool pl = lane < PS_CHAINS * D;
             const int64_t cl = (int64_t)bxs * PS_CHAINS + cw;''','''            const bool pl = lane < PS_CHAINS * NCH * D;
             const int cw = pl ? lane / (NCH * D) : 0, ph = pl ? (lane / D) % NCH : 0, pp = pl ? lane % D : 0;
             const int64_t cl = ((int64_t)bxs * PS_CHAINS + cw) * NCH + ph;''')
-sub('const double v = pub_rows[(cw * PS_PUB + (int)(done % PS_PUB)) * D + pp];','const double v = pub_rows[((cw * PS_PUB + (int)(done % PS_PUB)) * NCH + ph) * D + pp];')
+sub('if (ready) v = pub_rows[(cw * PS_PUB + (int)(done % PS_PUB)) * D + pp];','if (ready) v = pub_rows[((cw * PS_PUB + (int)(done % PS_PUB)) * NCH + ph) * D + pp];')
 sub('if (ready && pp == 0) __hip_atomic_store(&pub_done[cw], done,','if (ready && pp == 0 && ph == 0) __hip_atomic_store(&pub_done[cw], done,')
+sub('constexpr int NCHR = 1;                                // chains of a chain wave','constexpr int NCHR = NCH;                              // chains of a chain wave')
+sub('constexpr bool HRING = LIVE && (PS2_HRING_ONE != 0);','constexpr bool HRING = LIVE && (PS2_HRING_TWO != 0);')
+sub('const int hkk = w, hr = lane;         // HRING: its chain among the workgroup\'s, its row of the pass','const int hkk = w * NCH + hh, hr = l5; // HRING: its chain among the workgroup\'s, its row of the pass')
 # chain index
 sub('''    const int64_t c = (int64_t)bxs * PS_CHAINS + w;
     if (c >= P.N) {
@@ -172,12 +175,14 @@ sub('''    auto issue = [&](uint64_t pack, int slot) __attribute__((always_inlin
     }''')
 sub('uint64_t pr_f = 0;','uint64_t pr_f[NCH] = {0, 0};')
 sub('''        const unsigned char* rw = raw_w + slot * 1024;
-        // behind this slot's DMA in program order: AHEAD - 1 whole passes (a store and a DMA each) and this pass's store
+        // behind this slot's DMA in program order: AHEAD - 1 whole passes (a DMA each; !HRING: and a history store) and, !HRING,
+        // this pass's store
 #ifndef PS2_EXP_NOWAIT        // (timing experiments only -- results are garbage: scripts/ab_ps2.sh)
-        if (counted) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PS2_AHEAD - 1) : "memory");
+        if (counted) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HRING ? PS2_AHEAD - 1 : 2 * PS2_AHEAD - 1) : "memory");
 #endif''','''        const unsigned char* rw = raw_w + slot * (NCH * 1024);
-        // behind this slot's last DMA in program order: AHEAD - 1 whole passes (a store and NCH DMAs each) and this pass's store
-        if (counted) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((1 + NCH) * (PS2_AHEAD - 1) + 1) : "memory");''')
+        // behind this slot's last DMA in program order: AHEAD - 1 whole passes (NCH DMAs each; !HRING: and a history store) and,
+        // !HRING, this pass's store
+        if (counted) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HRING ? NCH * (PS2_AHEAD - 1) : (1 + NCH) * (PS2_AHEAD - 1) + 1) : "memory");''')
 sub('        pr_f = *reinterpret_cast<const uint64_t*>(rw + ixnext);','''#pragma unroll
         for (int q = 0; q < NCH; ++q) pr_f[q] = *reinterpret_cast<const uint64_t*>(rw + q * 1024 + ixnext);''')
 sub('const uint64_t ix = *reinterpret_cast<const uint64_t*>(raw_w + slot * 1024 + ixown);','const uint64_t ix = *reinterpret_cast<const uint64_t*>(raw_w + slot * (NCH * 1024) + ixown);')
@@ -232,7 +237,7 @@ hdr='''// demcz_kernels_ps2d.h -- window_kernel_ps2 (demcz_kernels_ps2.h) with T
 // shadowed lanes 0..31.  Here they run a second chain: lane l works for chain NCH * wave + (l >> 5), as node l & 31 of THAT
 // chain's tree.  What a wave has once per chain: a KiB of every raw slot and a DMA instruction per pass (a pass's rows, normals,
 // log u and indices are 54 of an instruction's 64 lanes), a block of increments, half of the candidate table (rows 0..31 /
-// 32..63), a row in the publisher's ring.  What it has once: the pass structure, the boundary counter, the history store (30 + 30
+// 32..63), a row in the publisher's ring.  What it has once: the pass structure, the boundary counter, the history hand-off (30 + 30
 // of its lanes), the accept compare -- one ballot whose halves are the two chains' masks -- and the instruction stream: the pass
 // costs what it cost (one DMA instruction more) and resolves five generations of TWO chains.  The LIVE launch therefore holds
 // 2048 chains where it held 1024 (one five-wave workgroup of eight chains per CU), at the same time per launch.
