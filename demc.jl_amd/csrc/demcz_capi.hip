@@ -198,7 +198,7 @@ struct demcz_handle {
     bool has_state = false;
     int64_t launches = 0;
     mutable int64_t kernel_counts[1] = {0};               // demcz_debug_kernel_counts: launches taken by window_kernel_ps2
-    int last_live = 0, last_ps2 = 0, last_temper = 0, last_dual = 0;     // demcz_debug_kernel_name: what the most recent window launch was
+    int last_live = 0, last_ps2 = 0, last_temper = 0, last_dual = 0, last_pw_reg = 0;     // demcz_debug_kernel_name: what the most recent window launch was
     bool external_append = false;
     // host-closure mode
     double* dXprop = nullptr;
@@ -1300,6 +1300,13 @@ static bool pw_matrix_form(const demcz_handle* h)
     return on && atoi(on) != 0 && h->cfg.d == 20 && h->cfg.target_kind == DEMCZ_TARGET_MVNORMAL;
 }
 
+// regular LIVE launches (demcz_kernels_pw.h, REG): K, the distance to the first boundary and the length multiples of five
+static bool pw_regular(const WindowParams& P, bool live)
+{
+    static const bool no_reg = getenv("DEMCZ_NO_PW_REG") != nullptr;
+    return live && !no_reg && P.K % PS_R == 0 && P.to_boundary % PS_R == 0 && P.ngen % PS_R == 0 && P.ngen >= PS_R;
+}
+
 template <int TARGET, int D>
 static void launch_pw(const demcz_handle* h, const WindowParams& P, int64_t blocks, bool live)
 {
@@ -1311,11 +1318,14 @@ static void launch_pw(const demcz_handle* h, const WindowParams& P, int64_t bloc
             return;
         }
     }
+    const bool reg = pw_regular(P, live);
     if (P.temperature) {
-        if (live) hipLaunchKernelGGL((window_kernel_pw<TARGET, D, true, true>), grid, wgl, 0, h->stream, P);
+        if (reg) hipLaunchKernelGGL((window_kernel_pw<TARGET, D, true, true, false, true>), grid, wgl, 0, h->stream, P);
+        else if (live) hipLaunchKernelGGL((window_kernel_pw<TARGET, D, true, true>), grid, wgl, 0, h->stream, P);
         else hipLaunchKernelGGL((window_kernel_pw<TARGET, D, false, true>), grid, wg, 0, h->stream, P);
     } else {
-        if (live) hipLaunchKernelGGL((window_kernel_pw<TARGET, D, true, false>), grid, wgl, 0, h->stream, P);
+        if (reg) hipLaunchKernelGGL((window_kernel_pw<TARGET, D, true, false, false, true>), grid, wgl, 0, h->stream, P);
+        else if (live) hipLaunchKernelGGL((window_kernel_pw<TARGET, D, true, false>), grid, wgl, 0, h->stream, P);
         else hipLaunchKernelGGL((window_kernel_pw<TARGET, D, false, false>), grid, wg, 0, h->stream, P);
     }
 }
@@ -1639,6 +1649,7 @@ static int32_t launch_window(demcz_handle* h, const WindowParams& P, bool live =
         h->last_temper = P.temperature ? 1 : 0;
         h->last_ps2 = (h->lanes == DEMCZ_LAYOUT_SPLIT && h->split_kind == 4 && !h->lr_spec && ps2_applicable(h, P) && (!h->ps_dual || h->dual_now)) ? 1 : 0;
         h->last_dual = h->dual_now ? 1 : 0;
+        h->last_pw_reg = (h->lanes == DEMCZ_LAYOUT_SPLIT && h->split_kind == 4 && P.d > 5 && !pw_matrix_form(h) && pw_regular(P, live)) ? 1 : 0;
     }
     if (h->snap_pending) {
         // the redo snapshot of the state (demcz_run): window_kernel_ps2 writes it as it loads the state -- two 5 us copy launches
@@ -2040,6 +2051,12 @@ static int pw_live_blocks_per_cu()
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, D, true, false>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) a = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, D, true, true>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) b = 0;
     int m = std::min(a, b);
+    {                               // (the regular-launch form)
+        int c = 0, e = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, D, true, false, false, true>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) c = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&e, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, D, true, true, false, true>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) e = 0;
+        m = std::min(m, std::min(c, e));
+    }
     if constexpr (D == 20) {        // (the matrix form of the same launches)
         int c = 0, e = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, D, true, false, true>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) c = 0;
@@ -3739,6 +3756,7 @@ extern "C" int32_t demcz_debug_kernel_name(const demcz_handle* h, char* buf, int
         if (h->lr_spec) snprintf(tmp, sizeof tmp, "window_kernel_lr8s<%d, %s>", d, lv);
         else if (h->split_kind == 4 && d <= 5) snprintf(tmp, sizeof tmp, "%s<%s, %d, %s, %s>", (h->last_ps2 && h->last_dual) ? "window_kernel_ps2d" : h->last_ps2 ? "window_kernel_ps2" : "window_kernel_ps", tg, d, lv, tm);
         else if (h->split_kind == 4 && h->last_live && pw_matrix_form(h)) snprintf(tmp, sizeof tmp, "window_kernel_pw<%s, %d, %s, %s, true>", tg, d, lv, tm);
+        else if (h->split_kind == 4 && h->last_pw_reg) snprintf(tmp, sizeof tmp, "window_kernel_pw<%s, %d, %s, %s, false, true>", tg, d, lv, tm);
         else if (h->split_kind == 4) snprintf(tmp, sizeof tmp, "window_kernel_pw<%s, %d, %s, %s>", tg, d, lv, tm);
         else if (h->split_kind == 3 && h->mlb_qb > 0 && h->split_lanes == 16) snprintf(tmp, sizeof tmp, "window_kernel_mlb<%s, %d, %d, true, %s, %d>", tg, d, h->split_lanes, lv, h->mlb_qb);
         else if (h->split_kind == 3) snprintf(tmp, sizeof tmp, "window_kernel_mlb<%s, %d, %d, true, %s>", tg, d, h->split_lanes, lv);

@@ -36,9 +36,14 @@ namespace demcz {
 // 8 + 18 + 10 matrix instructions (65 clocks each) replace 100 adds behind 50 LDS reads and 210 fmas behind 27 scalar loads, on
 // all 64 lanes instead of 31.  A non-finite increment (0 * inf) would poison candidates that do not take it: such a pass flags
 // the launch, and the library redoes it with the scalar kernels (live_verify) -- the reason this form is LIVE-only.
-template <int TARGET, int D, bool LIVE, bool TEMPER, bool MF = false>
+// REG (round 4; LIVE launches that start right after a boundary, with K and their length multiples of five): every pass is five
+// generations and a boundary falls on the end of every (K/5)-th pass -- the nibble queue of pass lengths, the clamps on the
+// generation indices and the per-pass "how long is the pass after next" arithmetic are constants and a counter
+// (what window_kernel_ps2 is to window_kernel_ps; profiles/r04p_pw_regular.txt).
+template <int TARGET, int D, bool LIVE, bool TEMPER, bool MF = false, bool REG = false>
 __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_kernel_pw(const WindowParams P)
 {
+    static_assert(!REG || (LIVE && PS_R == 5), "regular launches: LIVE, five generations a pass");
     static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "split layout: MvNormal / isotropic targets");
     static_assert(D >= 6 && D <= 24, "d <= 5: window_kernel_ps");
     static_assert(!MF || (LIVE && TARGET == TARGET_MVNORMAL && D > 16 && D <= 20 && PS_R == 5), "matrix form: MvNormal, 16 < d <= 20, LIVE");
@@ -252,13 +257,21 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         ctb = B ? K_s : ctb - R;
         return (unsigned int)(R | (B << 3));
     };
+    if constexpr (!REG) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) segq |= seg_make() << (4 * k);
-    auto qR = [&](int k) __attribute__((always_inline)) -> int { return (int)((segq >> (4 * k)) & 7u); };
+        for (int k = 0; k < 6; ++k) segq |= seg_make() << (4 * k);
+    }
+    auto qR = [&](int k) __attribute__((always_inline)) -> int { if constexpr (REG) return PS_R; else return (int)((segq >> (4 * k)) & 7u); };
+    // (the clamp stays in the regular form: these record buffers are not the arena's zero-filled ones -- a look-ahead past the
+    //  launch's last generation must not turn stale bytes into row indices)
     auto gclamp = [&](int g) __attribute__((always_inline)) { return (g < ngen_s) ? g : ngen_s - 1; };
     int g0 = 0, g3 = qR(0) + qR(1) + qR(2), g5 = g3 + qR(3) + qR(4);
     int npass;
-    {
+    [[maybe_unused]] int tb = P.to_boundary / PS_R;                 // REG: passes up to and including the next boundary pass
+    [[maybe_unused]] const int tbK = P.K / PS_R;
+    if constexpr (REG) {
+        npass = P.ngen / PS_R;
+    } else {
         const int n1 = (P.to_boundary < P.ngen) ? P.to_boundary : P.ngen, rest = P.ngen - n1;
         npass = (n1 + PS_R - 1) / PS_R + (rest / P.K) * ((P.K + PS_R - 1) / PS_R) + (rest % P.K + PS_R - 1) / PS_R;
     }
@@ -444,9 +457,11 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         unsigned long long sa_t = __builtin_readcyclecounter();
 #endif
         const int R = qR(0);
+        bool bnd;                      // a generation divisible by K ends this pass
+        if constexpr (REG) { bnd = (--tb == 0); if (bnd) tb = tbK; } else { bnd = (segq & 8u) != 0u; }
         [[maybe_unused]] unsigned int pub_seen = 0u;
         if constexpr (LIVE) {
-            if (segq & 8u) pub_seen = __hip_atomic_load(&pub_done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (bnd) pub_seen = __hip_atomic_load(&pub_done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         const double logu_c = logu;
         [[maybe_unused]] const double temp_c = temp;
@@ -651,7 +666,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         wave_lds_handoff();
         PW_T(4);                 // history values, winner's row to row 0
         // a generation divisible by K ended the pass: runchain!'s append, demcz.jl:88-91
-        if (segq & 8u) {
+        if (bnd) {
             constexpr int NA = (D + 63) / 64;
 #pragma unroll
             for (int t = 0; t < NA; ++t) {
@@ -688,7 +703,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         g0 += R;
         g3 += qR(3);
         g5 += qR(5);
-        segq = (segq >> 4) | (seg_make() << 20);
+        if constexpr (!REG) segq = (segq >> 4) | (seg_make() << 20);
 #pragma unroll
         for (int t = 0; t < NF; ++t) { ixA[t] = ixB[t]; ixB[t] = *reinterpret_cast<const uint64_t*>(raw_w + slot * SLOTB + ixo + fu[t] * 8); }
         slot = (slot + 1 == PS_SLOTS) ? 0 : slot + 1;

@@ -61,6 +61,40 @@ def test_wave_per_chain_live_long_run_equals_oracle(demc, oracle, d, G):
     _same(a, ref)
 
 
+@pytest.mark.parametrize("d,N,K,temper", [(20, 1024, 10, False), (20, 200, 5, True), (10, 1024, 15, False), (8, 333, 10, True)])
+def test_wave_per_chain_regular_launches_equal_oracle(demc, oracle, d, N, K, temper):
+    """Round 4: LIVE launches that start behind a K boundary, with K and their length multiples of five, take the regular form of
+    window_kernel_pw (REG: every pass five generations, a boundary counter instead of the queue of pass lengths); the others keep
+    the general form.  Both against the oracle, in one run: regular pieces, then a piece that is not a multiple of five, then one
+    that starts inside a K-window."""
+    G, seed = 40 * K + 7, 9100 + d
+    w = demc.workloads.mvnormal_problem(d, N)
+    M0 = w["Zinit"].shape[0]
+    T = None
+    if temper:
+        T = np.array([demc.tempbaseline(g, 100, 3, 1e-2) for g in range(1, G + 1)])
+    e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K + 1), Gcap=G, blockindex=[range(d)], eps_scale=w["eps_scale"], seed=seed,
+                       target=w["target"], lanes_per_chain=SPLIT_WAVE)
+    e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+    names = []
+    g = 1
+    for n in (20 * K, 10 * K, 7, 10 * K):
+        e.run(g, g + n - 1, w["gamma"], None if T is None else T[g - 1:g + n - 1])
+        names.append(e.kernel_name())
+        g += n
+    assert g == G + 1
+    ch, lo = e.get_history(1, G)
+    X, lp, Z, M = e.get_state()
+    live = e.live_status()
+    e.close()
+    assert live == (True, 0), live
+    reg = [n.count(",") == 5 and n.endswith("false, true>") for n in names]       # <TARGET, D, LIVE, TEMPER, MF = false, REG = true>
+    assert reg == [True, True, False, False], names
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed, temperature=T, threads=THREADS)
+    assert np.array_equal(ch, ref["chain"]) and np.array_equal(lo, ref["log_obj"])
+    assert np.array_equal(X, ref["X"]) and np.array_equal(lp, ref["logp"]) and M == ref["M"] and np.array_equal(Z, ref["Z"])
+
+
 def test_c4_shard_deferred_visibility_long_run_equals_oracle(demc, oracle):
     """C4's per-GPU shard with append_lag = 2 (the non-LIVE instantiation of window_kernel_pw, one launch per two K-windows, its
     producer half riding in the same grid) against the oracle-backed emulation of the same visibility rule."""
