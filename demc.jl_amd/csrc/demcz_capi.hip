@@ -2367,6 +2367,9 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     P.Z = h->dZ; P.Zw = h->dZ; P.ZS = h->ZS;
     P.Xcur = h->dX; P.lpcur = h->dlp;
     P.chain = hist ? h->dchain : nullptr; P.logobj = hist ? h->dlogobj : nullptr;
+#ifdef DEMCZ_EXP_NOHIST           // (timing experiment, never the shipped library: no window kernel writes any history --
+    P.chain = nullptr; P.logobj = nullptr;      //  scripts/build_variant.py nohist -DDEMCZ_EXP_NOHIST; profiles/r04o_history_store.txt)
+#endif
     P.N = h->cfg.N; P.chain_id0 = h->cfg.chain_id0; P.d = h->cfg.d;
     P.gamma = gamma; P.seed = h->cfg.seed; P.S = h->S; P.Nblocks = h->cfg.Nblocks;
     P.block_offsets = h->d_block_offsets; P.slot_of = h->d_slot_of; P.eps = h->d_eps; P.slot_role = h->d_slot_role;
