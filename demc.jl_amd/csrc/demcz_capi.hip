@@ -212,6 +212,8 @@ struct demcz_handle {
     double* d_spec_lp = nullptr;
     hipEvent_t spec_ev = nullptr;
     double* pinned_rhat = nullptr;    // demcz_run_checked: pinned host slots the checks' results are copied to
+    unsigned int* pinned_err = nullptr;       // demcz_run_checked: the hand-off's error word, copied behind the call's last launch ...
+    int64_t pinned_err_launches = -1;         // ... valid while no window launch has been made since (h->launches then)
     int64_t pinned_cap = 0;
     bool timing = false;              // demcz_set_kernel_timing: events around every window-kernel launch
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
@@ -600,6 +602,7 @@ static void free_all(demcz_handle* h)
     if (h->d_stage) (void)host_free(h->d_stage);
     for (auto& pr : h->timed) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (h->pinned_rhat) (void)host_free(h->pinned_rhat);
+    if (h->pinned_err) (void)host_free(h->pinned_err);
     if (h->d_safe_X) (void)dev_free(h->cfg.device_id, h->d_safe_X);
     if (h->d_safe_lp) (void)dev_free(h->cfg.device_id, h->d_safe_lp);
     if (h->d_spec_X) (void)dev_free(h->cfg.device_id, h->d_spec_X);
@@ -1870,9 +1873,13 @@ static int32_t live_failed(demcz_handle* h, bool& failed)
         NCCLCHK(h, ncclAllReduce(h->d_live_err, h->d_err_all, 1, ncclUint32, ncclMax, h->comm, h->stream));
         SYNCCHK(h, h->stream);
         HIPCHK(h, hipMemcpy(e, h->d_err_all, sizeof(unsigned int), hipMemcpyDeviceToHost));
+    } else if (h->pinned_err && h->pinned_err_launches == h->launches) {
+        // (copied behind the last window launch, and the stream has been drained since: demcz_run_checked)
+        std::memcpy(e, h->pinned_err, sizeof(e));
     } else {
         HIPCHK(h, hipMemcpy(e, h->d_live_err, sizeof(e), hipMemcpyDeviceToHost));
     }
+    h->pinned_err_launches = -1;
     failed = e[0] != 0u;
     if (!failed && h->peer_mode != 2) h->err_clean = true;
     return DEMCZ_OK;
@@ -3613,7 +3620,9 @@ static int32_t run_checked_body(demcz_handle* h, int64_t g_from, int64_t g_to, d
         if (rc) break;
         if (nxt % every == 0 && nxt - every >= h->g0) {          // demcz.jl:39-41
             double* slot = pinned + (size_t)checks * d;
-            rc = rhat_enqueue(h, nxt - every + 1, nxt, slot, /*side=*/monitor);
+            // (the call's last slab: nothing follows it on the compute stream, so its check goes there -- no hop to the side
+            //  stream, ~10 us of event latency, at the end of every call)
+            rc = rhat_enqueue(h, nxt - every + 1, nxt, slot, /*side=*/monitor && nxt < g_to);
             if (rc) break;
             ++checks;
             if (!monitor) {
@@ -3672,6 +3681,15 @@ static int32_t run_checked_body(demcz_handle* h, int64_t g_from, int64_t g_to, d
             }
         }
         g = nxt + 1;
+    }
+    // the verdict on the call's row hand-offs (demcz_run_checked, below) needs the error word on the host: its copy goes behind
+    // the last launch NOW, so that it travels while the last slab's statistic is still being made -- not as a blocking copy of
+    // its own after everything else (one host round trip less at the end of every call: ~30 us)
+    h->pinned_err_launches = -1;
+    if (rc == DEMCZ_OK && !h->live_log.empty() && h->peer_mode != 2) {
+        if (!h->pinned_err && host_malloc((void**)&h->pinned_err, 4 * sizeof(unsigned int)) != hipSuccess) { h->pinned_err = nullptr; (void)hipGetLastError(); }
+        if (h->pinned_err && hipMemcpyAsync(h->pinned_err, h->d_live_err, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream) == hipSuccess)
+            h->pinned_err_launches = h->launches;
     }
     if (rc == DEMCZ_OK) rc = sync_stream(h, h->stream, "demcz_run_checked");
     if (rc == DEMCZ_OK && h->diag_stream) rc = sync_stream(h, h->diag_stream, "demcz_run_checked");
