@@ -40,6 +40,13 @@ namespace demcz {
 // generations and a boundary falls on the end of every (K/5)-th pass -- the nibble queue of pass lengths, the clamps on the
 // generation indices and the per-pass "how long is the pass after next" arithmetic are constants and a counter
 // (what window_kernel_ps2 is to window_kernel_ps; profiles/r04p_pw_regular.txt).
+// W by lanes (round 4, MvNormal, every scalar form of the kernel): the whitening's 210 fmas used to wait for 27-29 scalar loads of W
+// a pass that ~100 SGPRs cannot prefetch more than a row ahead.  W now sits in 14 register pairs, entry e in lane e % 16 of every
+// 16-lane row, and each fma takes its entry by DPP row_newbcast (v_fmac_f64_dpp; scripts/gen_pw_wdpp.py generates the chains,
+// scripts/probes/dpp_f64 measured them: 1140-1280 clocks per evaluation against 1700 alone, the same doubles).
+#ifndef PW_WDPP
+#define PW_WDPP 1
+#endif
 template <int TARGET, int D, bool LIVE, bool TEMPER, bool MF = false, bool REG = false>
 __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_kernel_pw(const WindowParams P)
 {
@@ -74,6 +81,22 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     __shared__ __attribute__((aligned(16))) double sdelta[PS_CHAINS][(PS_R + 1) * DP];       // row PS_R: negative zeros
     __shared__ __attribute__((aligned(16))) double ctab[PS_CHAINS][32 * CR];                   // row 0: the current state
     __shared__ __attribute__((aligned(16))) double mul[DP];          // mu, one copy per workgroup
+    constexpr bool WDPP = (PW_WDPP != 0) && !MF && TARGET == TARGET_MVNORMAL && (D == 8 || D == 10 || D == 20);
+    constexpr int NWR = (D * (D + 1) / 2 + 15) / 16;                 // register pairs that hold W, sixteen entries each
+    // the pass's increments by lanes, the same way (candidate adds): scripts/gen_pw_wdpp.py, gen_adds
+#ifndef PW_DDPP
+#define PW_DDPP 1
+#endif
+    constexpr bool DDPP = (PW_DDPP != 0) && !MF && PS_R == 5 && (D == 8 || D == 10 || D == 20);
+    // per generation of the pass: positions of a 16-lane row that take it in every row with takers, and the register pairs that
+    // then hold its D increments (the generator's numbers; checked against each other in the generated text)
+    constexpr int DD_KN[5] = {4, 4, 4, 4, 16};
+    constexpr int DD_NQ[5] = {(D + 3) / 4, (D + 3) / 4, (D + 3) / 4, (D + 3) / 4, (D + 15) / 16};
+    constexpr int DD_NQMAX = (D + 3) / 4;
+    __shared__ double Wl[WDPP ? NWR * 16 : 1];                       // W packed lower-triangular, one copy per workgroup
+    if constexpr (WDPP) {
+        for (int e = threadIdx.x; e < NWR * 16; e += blockDim.x) Wl[e] = (e < D * (D + 1) / 2) ? P.tp.Wp[e] : 0.0;
+    }
     __shared__ double pub_rows[LIVE ? PS_CHAINS * PS_PUB * D : 1];
     __shared__ unsigned int pub_seq[PS_CHAINS], pub_done[PS_CHAINS], pub_exit[PS_CHAINS];
     for (int e = threadIdx.x; e < D; e += blockDim.x) mul[e] = P.tp.mu[e];
@@ -142,11 +165,31 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     const int nn = (lane >= 1 && lane < 32) ? lane : 1;
     const int lev = 32 - __builtin_clz((unsigned)nn);
     const double* mrow[PS_R];
+    // DDPP: the lanes whose node takes generation j of the pass (a ballot), and where this lane finds, in the wave's block of
+    // increments, the entry it holds of register pair 0 of generation j: entry m, m = its rank among the positions of a row that
+    // take the generation in every row with takers (pair q: + q * KN entries; lanes at other positions are never read from)
+    [[maybe_unused]] uint64_t tmask[PS_R];
+    [[maybe_unused]] const double* dptr[PS_R];
 #pragma unroll
     for (int j = 1; j <= PS_R; ++j) {
-        const bool take = lane != 0 && ((j == lev) || (j < lev && ((nn >> (lev - 1 - j)) & 1)));
-        mrow[j - 1] = sd_w + (take ? j - 1 : PS_R) * DP;
+        const bool tk = lane != 0 && ((j == lev) || (j < lev && ((nn >> (lev - 1 - j)) & 1)));
+        mrow[j - 1] = sd_w + (tk ? j - 1 : PS_R) * DP;
+        if constexpr (DDPP) {
+            const uint64_t tm = __builtin_amdgcn_ballot_w64(tk);
+            unsigned int common = 0xffffu;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned int rowm = (unsigned int)(tm >> (16 * r)) & 0xffffu;
+                if (rowm) common &= rowm;
+            }
+            const int pos = lane & 15;
+            const int m = ((common >> pos) & 1u) ? __builtin_popcount(common & ((1u << pos) - 1u)) : 0;
+            tmask[j - 1] = tm;
+            dptr[j - 1] = sd_w + (j - 1) * DP + m;
+        }
     }
+    [[maybe_unused]] double one = 1.0;
+    if constexpr (DDPP) asm volatile("" : "+v"(one));       // (in a register: the multiplicand of the adds-as-fmas)
     int anc = nn;
     while (anc > 1 && (anc & 1) == 0) anc >>= 1;
     anc = (anc == 1) ? 0 : (anc >> 1);
@@ -514,6 +557,29 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             if (2 * q + 1 < D) cand[2 * q + 1] = t.y;
             if (2 * q + 1 == D) lp = t.y;
         }
+        if constexpr (DDPP) {
+            // the increments are the same for every node: per generation they sit in a few register pairs by lanes and are added
+            // by the lanes whose path takes the generation, straight out of a taker lane of their row (scripts/gen_pw_wdpp.py,
+            // gen_adds) -- 22 8-byte LDS reads a pass instead of 50 16-byte ones, and no instruction for a generation not taken
+            double Dg[PS_R][DD_NQMAX];
+#pragma unroll
+            for (int u = 0; u < PS_R; ++u)
+#pragma unroll
+                for (int q = 0; q < DD_NQMAX; ++q)
+                    if (q < DD_NQ[u]) Dg[u][q] = dptr[u][q * DD_KN[u]];
+#pragma unroll
+            for (int u = 0; u < PS_R; ++u)
+#pragma unroll
+                for (int q = 0; q < DD_NQMAX; ++q)
+                    if (q < DD_NQ[u]) asm volatile("" : "+v"(Dg[u][q]));
+            if constexpr (D == 20) {
+#include "demcz_pw_ddpp_20.inc"
+            } else if constexpr (D == 10) {
+#include "demcz_pw_ddpp_10.inc"
+            } else {
+#include "demcz_pw_ddpp_8.inc"
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < PS_R; ++j) {
 #pragma unroll
@@ -527,6 +593,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             //  row's worth of pieces across the rows ends the same way: 233 registers / 115 spilled)
 #pragma unroll
             for (int p = 0; p < D; ++p) asm volatile("" : "+v"(cand[p]));
+        }
         }
         }
         PW_T(0);                 // state row + candidate adds straight from LDS
@@ -586,6 +653,14 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         }
         // The log-density: target_logp's operation sequence; mu from the workgroup's LDS copy
         {
+            // W by lanes: the register pairs are asked for here, in front of the reads of mu, and pinned behind the subtraction --
+            // one LDS round trip for all of them (left alone the compiler fetches a block's pairs right in front of the block:
+            // five round trips a pass)
+            [[maybe_unused]] double Wr[WDPP ? NWR : 1];
+            if constexpr (WDPP) {
+#pragma unroll
+                for (int r = 0; r < NWR; ++r) Wr[r] = Wl[r * 16 + (lane & 15)];
+            }
             double (&rr)[D] = cand;           // (the candidate itself is in the table by now)
 #pragma unroll
             for (int q = 0; q < DP / 2; ++q) {
@@ -608,7 +683,19 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             const cptr Wc = (cptr)wa;
             auto wentry = [&](int e) __attribute__((always_inline)) { return Wc[e]; };
             double q = 0.0;
-            if constexpr (TARGET == TARGET_MVNORMAL) {
+            if constexpr (WDPP) {
+                // (round 4: W by lanes -- see the top of the file; the alternatives above are what it replaced)
+#pragma unroll
+                for (int r = 0; r < NWR; ++r) asm volatile("" : "+v"(Wr[r]));
+                if constexpr (D == 20) {
+#include "demcz_pw_wdpp_20.inc"
+                } else if constexpr (D == 10) {
+#include "demcz_pw_wdpp_10.inc"
+                } else {
+#include "demcz_pw_wdpp_8.inc"
+                }
+                lpp = fma(-0.5, q, P.tp.c0);
+            } else if constexpr (TARGET == TARGET_MVNORMAL) {
 #pragma unroll
                 for (int i = 0; i < D; ++i) {
                     double acc = wentry((i * (i + 1)) / 2) * rr[0];

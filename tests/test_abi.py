@@ -60,3 +60,6 @@ def test_two_chain_kernel_is_what_its_generator_makes():
     import sys
     r = subprocess.run([sys.executable, str(ROOT / "scripts" / "gen_ps2d.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, "demcz_kernels_ps2d.h differs from what scripts/gen_ps2d.py generates: " + r.stderr[-500:]
+    # the whitening chains of window_kernel_pw (W by lanes, DPP row_newbcast) are generated text too
+    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "gen_pw_wdpp.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, "demcz_pw_wdpp_*.inc differ from what scripts/gen_pw_wdpp.py generates: " + r.stderr[-500:]
