@@ -339,6 +339,9 @@ constexpr int MLB_REC_WAVES = 4;
 // re-evaluation in the same order (oracle: target_logp; src/demcz.jl:189).  QB = 0: any block structure, full evaluation.
 // GM (QB = 0): the sums are cut at the boundaries of ANY consecutive blocks (TargetParams::gstart), full evaluation, the restarts
 // selected by the group-start mask -- an instantiation of its own, so that runs whose sums are not grouped keep their code.
+#ifndef MLB_DPP
+#define MLB_DPP 1
+#endif
 template <int TARGET, int D, int L, bool REC = false, bool LIVE = false, int QB = 0, bool GM = false>
 __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_mlb(const WindowParams P)
 {
@@ -601,14 +604,20 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
             issue_draws(gi_n, ib_n);                       // the one past the window is unused
             MLB_TICK(1);
 
+            // MDPP (round 4): sixteen lanes per chain = one DPP row: what the chain's lanes hand each other in a block-step -- the moved
+            // block's residuals, the rows' y -- is taken out of the owner lane's register by v_mov_b64_dpp row_newbcast instead of
+            // going through LDS (write, wait, read, twice per block-step): scripts/gen_mlb_dpp.py, profiles/r04s_dpp.txt
+            constexpr bool MDPP = (MLB_DPP != 0) && QB == 5 && D == 20 && L == 16;
             double xp[NP];
+            [[maybe_unused]] double rres[NP];
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const int p = r + L * k;
                 xp[k] = inb[k] ? x[k] + delta[k] : x[k];
-                if (p < D) rvec[gq * DP + p] = xp[k] - muv[k];
+                rres[k] = xp[k] - muv[k];
+                if constexpr (!MDPP) { if (p < D) rvec[gq * DP + p] = rres[k]; }
             }
-            wave_lds_handoff();
+            if constexpr (!MDPP) wave_lds_handoff();
             double lpp;
             [[maybe_unused]] double Pn[NP], Qn[QNB];
             if constexpr (QB > 0) {
@@ -616,8 +625,14 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
                 auto body = [&](auto ibc) __attribute__((always_inline)) {
                     constexpr int IB = decltype(ibc)::value;
                     double rb[QB];
+                    if constexpr (MDPP) {
+#define MLB_DPP_RB
+#include "demcz_mlb_dpp_20_5.inc"
+                    } else {
 #pragma unroll
                     for (int t = 0; t < QB; ++t) rb[t] = rvec[gq * DP + IB * QB + t];
+                    }
+                    [[maybe_unused]] double ynew[NP];
 #pragma unroll
                     for (int k = 0; k < NP; ++k) {
                         const int p = r + L * k;
@@ -634,9 +649,16 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
                             const double pb = (b == IB) ? acc : Pc[k][b];
                             y = (b * QB <= p) ? y + pb : y;
                         }
-                        if (p < D && p >= IB * QB) yvec[gq * DP + p] = y;      // rows above the block keep their y (not read below)
+                        ynew[k] = y;
+                        if constexpr (!MDPP) { if (p < D && p >= IB * QB) yvec[gq * DP + p] = y; }      // rows above the block keep their y (not read below)
                     }
-                    wave_lds_handoff();
+                    [[maybe_unused]] double yy[QNB][QB];
+                    if constexpr (MDPP) {
+#define MLB_DPP_YY
+#include "demcz_mlb_dpp_20_5.inc"
+                    } else {
+                        wave_lds_handoff();
+                    }
                     double q = 0.0;
 #pragma unroll
                     for (int b = 0; b < QNB; ++b) {
@@ -644,8 +666,9 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
                         if (b >= IB) {                     // (literals: resolved when the body is instantiated)
 #pragma unroll
                             for (int t = 0; t < QB; ++t) {
-                                const double yy = yvec[gq * DP + b * QB + t];
-                                qb = (t == 0) ? yy * yy : fma(yy, yy, qb);
+                                double yv;
+                                if constexpr (MDPP) yv = yy[b][t]; else yv = yvec[gq * DP + b * QB + t];
+                                qb = (t == 0) ? yv * yv : fma(yv, yv, qb);
                             }
                         }
                         Qn[b] = qb;

@@ -63,3 +63,5 @@ def test_two_chain_kernel_is_what_its_generator_makes():
     # the whitening chains of window_kernel_pw (W by lanes, DPP row_newbcast) are generated text too
     r = subprocess.run([sys.executable, str(ROOT / "scripts" / "gen_pw_wdpp.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, "demcz_pw_wdpp_*.inc differ from what scripts/gen_pw_wdpp.py generates: " + r.stderr[-500:]
+    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "gen_mlb_dpp.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, "demcz_mlb_dpp_*.inc differ from what scripts/gen_mlb_dpp.py generates: " + r.stderr[-500:]
