@@ -342,6 +342,10 @@ constexpr int MLB_REC_WAVES = 4;
 #ifndef MLB_DPP
 #define MLB_DPP 1
 #endif
+#ifndef MLB_DPP_RECORD          // the record's row indices and log u the same way (every lane fetching the entry it needs itself): built,
+#define MLB_DPP_RECORD 0        // bit-identical, and SLOWER -- 40.5 against 38.3 us per K-window: that hand-off is issued a block-step ahead,
+#endif                          // its LDS latency was already hidden, and the per-lane choice of entry costs more instructions than it saves
+
 template <int TARGET, int D, int L, bool REC = false, bool LIVE = false, int QB = 0, bool GM = false>
 __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_mlb(const WindowParams P)
 {
@@ -458,11 +462,26 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
     //  block-step ahead -- instead of one entry per lane handed round through LDS: 43.2-43.7 us, the extra vector-memory
     //  instructions cost more than the LDS write, three reads and two hand-offs they replace.)
     constexpr int QSB = (QB > 0) ? 2 + (QB + 1) / 2 : 0;
+    // MDPP (round 4): sixteen lanes per chain = one DPP row: what the chain's lanes hand each other in a block-step -- the record's
+    // row indices and log u, the moved block's residuals, the rows' y -- is taken out of the owner lane's register by
+    // v_mov_b64_dpp row_newbcast instead of going through LDS (write, wait, read): scripts/gen_mlb_dpp.py, profiles/r04s_dpp.txt
+    constexpr bool MDPP = (MLB_DPP != 0) && REC && QB == 5 && D == 20 && L == 16;
+    constexpr bool MDPPR = MDPP && (MLB_DPP_RECORD != 0);
     auto load_entry = [&](int gi, int ib) {
         const int b = (QB > 0) ? QB : blen_l[ib];
         const int nn = (b == 1) ? 1 : b;
         const int Sb = 2 + (nn + 1) / 2;
-        const int role = (r < Sb) ? r : Sb - 1;
+        int role = (r < Sb) ? r : Sb - 1;
+        if constexpr (MDPPR) {
+            // every lane fetches the entry IT needs: the owner of a parameter of the moved block the entry with its normal
+            // (entry 1 + slot / 2), the first lane behind the block the row indices (entry 0), the next one log u (entry Sb - 1)
+            role = (r == ((ib * QB + QB + 1) & (L - 1))) ? Sb - 1 : 0;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int p = r + L * k;
+                if (p < D && p >= ib * QB && p < ib * QB + QB) role = 1 + (p - ib * QB) / 2;
+            }
+        }
         const int g = (gi < P.ngen) ? gi : P.ngen - 1;
         const int bo = (QB > 0) ? ib * QSB : boff_l[ib];
         return rec2[((size_t)g * (size_t)P.N + (size_t)c) * (size_t)P.S + (size_t)(bo + role)];
@@ -482,6 +501,31 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
         const int nn = (b == 1) ? 1 : b;
         const int Sb = 2 + (nn + 1) / 2;
         const int role = (r < Sb) ? r : Sb - 1;
+        if constexpr (MDPPR) {
+            const double2 e = e_pre;
+            {   // the entry of the block-step after this one, for the next call
+                const int ib2 = (ib + 1 == NB) ? 0 : ib + 1;
+                const int gi2 = (ib + 1 == NB) ? gi + 1 : gi;
+                e_pre = load_entry(gi2, ib2);
+            }
+            double ex = e.x, ey = e.y, ix, iy, lg;
+#define MLB_DPP_REC
+#include "demcz_mlb_dpp_20_5.inc"
+            logu_next = lg;
+            row1_n = __double_as_longlong(ix);
+            row2_n = __double_as_longlong(iy);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int p = r + L * k;
+                const int pc = (p < D) ? p : 0;
+                const int ts = (p < D && p >= ib * QB && p < ib * QB + QB) ? p - ib * QB : -1;
+                tslot[k] = ts;
+                zt[k] = (ts >= 0 && (ts & 1)) ? ey : ex;          // (its own entry holds its normal; unused where ts < 0)
+                za[k] = (ts >= 0) ? P.Z[row1_n * P.ZS + pc] : 0.0;
+                zb[k] = (ts >= 0) ? P.Z[row2_n * P.ZS + pc] : 0.0;
+            }
+            return;
+        }
         if constexpr (REC) {
             const double2 e = e_pre;
             {   // the entry of the block-step after this one, for the next call
@@ -604,10 +648,6 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
             issue_draws(gi_n, ib_n);                       // the one past the window is unused
             MLB_TICK(1);
 
-            // MDPP (round 4): sixteen lanes per chain = one DPP row: what the chain's lanes hand each other in a block-step -- the moved
-            // block's residuals, the rows' y -- is taken out of the owner lane's register by v_mov_b64_dpp row_newbcast instead of
-            // going through LDS (write, wait, read, twice per block-step): scripts/gen_mlb_dpp.py, profiles/r04s_dpp.txt
-            constexpr bool MDPP = (MLB_DPP != 0) && QB == 5 && D == 20 && L == 16;
             double xp[NP];
             [[maybe_unused]] double rres[NP];
 #pragma unroll

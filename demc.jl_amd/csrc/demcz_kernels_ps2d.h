@@ -291,12 +291,39 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     // node of its chain's tree of outcomes: nn = 0 is the state itself (lanes 0 and 32), 1..31 the nodes
     const int nn = l5;
     const int lev = nn ? 32 - __builtin_clz((unsigned)nn) : 0;
+    // DDPP (round 4; demcz_kernels_pw.h has the long form of this note, scripts/gen_pw_wdpp.py gen_adds the generator): a pass's
+    // increments are the same for every node, and a node that does not take a generation added -0.0, the identity -- so the
+    // increments sit in a few register pairs by lanes, and per generation the lanes whose path takes it add them (EXEC = that
+    // ballot) straight out of a taker lane of their 16-lane row by DPP row_newbcast: 9 8-byte LDS reads a pass instead of 15
+    // 16-byte ones, 18 registers instead of 50.
+    constexpr bool DDPP = (PS2_DDPP != 0);
+    constexpr int DD_KN[5] = {4, 4, 4, 4, 16};
+    constexpr int DD_NQ[5] = {(D + 3) / 4, (D + 3) / 4, (D + 3) / 4, (D + 3) / 4, (D + 15) / 16};
+    constexpr int DD_NQMAX = (D + 3) / 4;
+    [[maybe_unused]] uint64_t tmask[R];
+    [[maybe_unused]] const double* dptr[R];
     const double* mrow[R];                 // rows of sdelta this node adds, in order: an accepted generation on its path or its
 #pragma unroll                             // own -> that generation's increments, anything else -> the row of negative zeros
     for (int j = 1; j <= R; ++j) {
         const bool take = nn != 0 && ((j == lev) || (j < lev && ((nn >> (lev - 1 - j)) & 1)));
         mrow[j - 1] = sd_w + (take ? j - 1 : R) * DP;
+        if constexpr (DDPP) {
+            const uint64_t tm = __builtin_amdgcn_ballot_w64(take);
+            unsigned int common = 0xffffu;
+#pragma unroll
+            for (int rr4 = 0; rr4 < 4; ++rr4) {
+                const unsigned int rowm = (unsigned int)(tm >> (16 * rr4)) & 0xffffu;
+                if (rowm) common &= rowm;
+            }
+            const int pos = lane & 15;
+            int mrank = ((common >> pos) & 1u) ? __builtin_popcount(common & ((1u << pos) - 1u)) : 0;
+            mrank = (mrank < D) ? mrank : 0;               // (positions that hold no entry of this generation: anything in bounds)
+            tmask[j - 1] = tm;
+            dptr[j - 1] = sd_w + (j - 1) * DP + mrank;
+        }
     }
+    [[maybe_unused]] double one = 1.0;
+    if constexpr (DDPP) asm volatile("" : "+v"(one));
     int anc = nn;
     while (anc > 1 && (anc & 1) == 0) anc >>= 1;
     anc = (anc <= 1) ? 0 : (anc >> 1);
@@ -449,8 +476,9 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         }
     };
 
-    double m[R][D];
-    auto mget = [&](int j, int p) __attribute__((always_inline)) -> double { return m[j][p]; };
+    [[maybe_unused]] double m[DDPP ? 1 : R][DDPP ? 1 : D];
+    [[maybe_unused]] double Dg[R][DD_NQMAX];
+    auto mget = [&](int j, int p) __attribute__((always_inline)) -> double { return m[DDPP ? 0 : j][DDPP ? 0 : p]; };
     constexpr int NPIECE = DP / 2;
     double logu = 0.0;
     [[maybe_unused]] double temp = 1.0;
@@ -458,6 +486,13 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     // (Measured and dropped: running the pass on lanes 0..31 only and reading, per node, only the rows it adds -- 22 KB of LDS
     //  traffic per pass down to 8 KB: 103 -> 99.5 us per 1000 generations, for hand-set lane masks the compiler does not know of.)
     auto load_rows = [&]() __attribute__((always_inline)) {
+        if constexpr (DDPP) {
+#pragma unroll
+            for (int u = 0; u < R; ++u)
+#pragma unroll
+                for (int q = 0; q < DD_NQMAX; ++q)
+                    if (q < DD_NQ[u]) Dg[u][q] = dptr[u][q * DD_KN[u]];
+        } else {
 #pragma unroll
         for (int j = 0; j < R; ++j)
 #pragma unroll
@@ -466,6 +501,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
                 m[j][2 * q] = t.x;
                 if (2 * q + 1 < D) m[j][2 * q + 1] = t.y;
             }
+        }
     };
     auto write_increment = [&]() __attribute__((always_inline)) {
         const double diff = za_f - zb_f;
@@ -599,10 +635,22 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         double cand[D];
 #pragma unroll
         for (int p = 0; p < D; ++p) cand[p] = x[p];
+        if constexpr (DDPP) {
+            if constexpr (D == 5) {
+#include "demcz_pw_ddpp_5.inc"
+            } else if constexpr (D == 4) {
+#include "demcz_pw_ddpp_4.inc"
+            } else if constexpr (D == 3) {
+#include "demcz_pw_ddpp_3.inc"
+            } else {
+#include "demcz_pw_ddpp_2.inc"
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < R; ++j)
 #pragma unroll
             for (int p = 0; p < D; ++p) cand[p] = cand[p] + mget(j, p);
+        }
         PS2_T(0);                      // history store, raw values asked for, candidate adds
         __builtin_amdgcn_sched_barrier(0);
         // LIVE: the pass before's history values into the publisher's ring -- here, among the pass's other LDS writes, long after
