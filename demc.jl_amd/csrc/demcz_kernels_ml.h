@@ -465,8 +465,8 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
     // MDPP (round 4): sixteen lanes per chain = one DPP row: what the chain's lanes hand each other in a block-step -- the record's
     // row indices and log u, the moved block's residuals, the rows' y -- is taken out of the owner lane's register by
     // v_mov_b64_dpp row_newbcast instead of going through LDS (write, wait, read): scripts/gen_mlb_dpp.py, profiles/r04s_dpp.txt
-    constexpr bool MDPP = (MLB_DPP != 0) && REC && QB == 5 && D == 20 && L == 16;
-    constexpr bool MDPPR = MDPP && (MLB_DPP_RECORD != 0);
+    constexpr bool MDPP = (MLB_DPP != 0) && QB == 5 && D == 20 && L == 16;
+    constexpr bool MDPPR = MDPP && REC && (MLB_DPP_RECORD != 0);
     auto load_entry = [&](int gi, int ib) {
         const int b = (QB > 0) ? QB : blen_l[ib];
         const int nn = (b == 1) ? 1 : b;
