@@ -60,24 +60,28 @@ def measured_traffic(n_loc, d, K, lanes, gens_per_launch):
     return float(shape["bytes_per_launch_calibrated"]), f"profiles/{prof.get('tag')}_traffic.json"
 
 
-def throughput_point(demc, N, d, K, seed, gens, device_id):
+def throughput_point(demc, N, d, K, seed, gens, device_id, reps=1):
     """One point of the chain-count sweep (not the headline): the same generation loop at N chains,
-    history and appends included, to show where the path leaves the latency regime."""
+    history and appends included, to show where the path leaves the latency regime.  `reps` calls of `gens` generations are
+    timed back to back (small populations: one call of 1000 generations is a quarter host latency)."""
     w = demc.workloads.mvnormal_problem(d, N)
     M0 = w["Zinit"].shape[0]
-    e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (2 * gens // K + 1), Gcap=2 * gens, blockindex=[range(d)],
+    G = (1 + reps) * gens
+    e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K + 1), Gcap=G, blockindex=[range(d)],
                        eps_scale=w["eps_scale"], seed=seed, target=w["target"], device_id=device_id)
     e.set_state(w["Zinit"][-N:], None, w["Zinit"])
     e.run(1, gens, w["gamma"])
     e.synchronize()
     t0 = time.perf_counter()
-    e.run(gens + 1, 2 * gens, w["gamma"])
+    for i in range(reps):
+        e.run((1 + i) * gens + 1, (2 + i) * gens, w["gamma"])
     e.synchronize()
     dt = time.perf_counter() - t0
     lanes = e.info()["lanes_per_chain"]
     e.close()
-    gbs = N * gens / dt * algorithmic_bytes_per_update(d, K) / 1e9
-    return {"chains": N, "lanes_per_chain": lanes, "value": N * gens / dt, "achieved_GBps": gbs, "frac_of_8TBps": gbs / 8000.0}
+    gbs = N * gens * reps / dt * algorithmic_bytes_per_update(d, K) / 1e9
+    return {"chains": N, "lanes_per_chain": lanes, "generations_timed": gens * reps, "value": N * gens * reps / dt, "achieved_GBps": gbs,
+            "frac_of_8TBps": gbs / 8000.0}
 
 
 FP64_MFMA_PEAK_TFLOPS = 78.6    # v_mfma_f64_16x16x4_f64: 2048 flop / 65 clocks x 1024 SIMDs x 2.4 GHz (measured instruction rate,
@@ -631,8 +635,8 @@ def main():
                                        "sampler from `value`'s -- compare its gens_to_rhat_1p05; `--gpus 1 --append-lag E` is its N = 1 point"}
         if world == 1 and not args.no_sweep and (n_loc, d) == (1024, 5):
             try:     # reporting only: throughput regime of the same path
-                out["chain_count_sweep"] = [throughput_point(demc, n, d, K, seed, g, local_rank)
-                                            for n, g in ((2048, 1000), (4096, 1000), (16384, 400), (131072, 200), (1048576, 100))]
+                out["chain_count_sweep"] = [throughput_point(demc, n, d, K, seed, g, local_rank, reps)
+                                            for n, g, reps in ((2048, 1000, 5), (4096, 1000, 5), (16384, 400, 5), (131072, 200, 2), (1048576, 100, 1))]
             except Exception as e:
                 out["chain_count_sweep"] = f"failed: {e}"
         if world == 1 and not args.no_configs:
