@@ -44,6 +44,7 @@ SYMBOLS = [
     "demcz_set_comm_timeout", "demcz_debug_stall_exchange", "demcz_get_kernel_time_series",
     "demcz_history_stream", "demcz_get_history_view", "demcz_detach_history", "demcz_release_host_buffer", "demcz_get_archive_pinned",
     "demcz_debug_kernel_counts", "demcz_pool_trim", "demcz_debug_kernel_name", "demcz_peer_group", "demcz_get_peer_status", "demcz_peer_export", "demcz_peer_attach",
+    "demcz_peer_detach", "demcz_get_peer_ping", "demcz_set_live_rearms", "demcz_get_live_rearms",
 ]
 
 
@@ -144,6 +145,10 @@ def load():
     L.demcz_get_peer_status.argtypes = [C.c_void_p, _ip, _ip]
     L.demcz_peer_export.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.demcz_peer_attach.argtypes = [C.c_void_p, C.c_void_p]
+    L.demcz_peer_detach.argtypes = [C.c_void_p]
+    L.demcz_get_peer_ping.argtypes = [C.c_void_p, _ip, _dp]
+    L.demcz_set_live_rearms.argtypes = [C.c_void_p, C.c_int32]
+    L.demcz_get_live_rearms.argtypes = [C.c_void_p, _ip, _ip]
     L.demcz_debug_kernel_name.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
     L.demcz_get_archive_pinned.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), _lp]
     L.demcz_get_kernel_time_series.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _ip]

@@ -147,7 +147,9 @@ struct demcz_handle;
 // the chains, publishing boundary rows into each other's replicas from inside their launches.  One host thread drives them all.
 struct PeerGroup {
     std::vector<demcz_handle*> members;
-    bool failed = false;       // a hand-off timed out once: calls are logged and executed in lockstep at the next verification
+    bool failed = false;       // a hand-off timed out: calls are logged and executed in lockstep at the next verification ...
+    int32_t rearms_left = 3;   // ... after which the group tries its in-launch hand-off again, this many times in its life
+    bool lockstep_only = false;   // a layout without the hand-off, or streams that cannot run at the same time: never LIVE
     bool busy = false;         // inside group_verify / group_execute
     bool dead = false;         // a member was destroyed: the others only accept demcz_destroy
 };
@@ -208,6 +210,8 @@ struct demcz_handle {
     // split layout: draw records, double-buffered (this launch reads one, its producer half fills the other)
     hipStream_t diag_stream = nullptr;   // demcz_run_checked, monitoring: the checks run here beside the next slab
     hipEvent_t diag_ev = nullptr;
+    hipEvent_t rhat_side_ev = nullptr;   // behind the latest check enqueued on a side stream (they all work in d_scratch) ...
+    bool rhat_side_pending = false;      // ... which a check on the compute stream has to wait for
     double* d_spec_X = nullptr;       // demcz_run_checked with a threshold: state before the slab enqueued ahead of a decision
     double* d_spec_lp = nullptr;
     hipEvent_t spec_ev = nullptr;
@@ -260,6 +264,16 @@ struct demcz_handle {
     int64_t safe_M = 0, safe_M_app = 0, safe_g_done = 0;
     bool replaying = false;
     int32_t live_redos = 0;
+    // Re-arming (round 5): a failed hand-off no longer costs the handle its LIVE launches for good.  live_rollback notes the
+    // generation whose row never arrived; the redo runs one launch per K-window up to and including the demcz_run call that
+    // holds that generation, and the first call that starts behind it goes LIVE again (live_try_rearm) -- at most
+    // `live_rearms_left` times in the handle's life (default 3, DEMCZ_LIVE_REARMS, demcz_set_live_rearms), so that a handle
+    // whose hand-off fails every time (another process's kernels on the GPU, a link that delays rows for good) still ends in
+    // the one-launch-per-K-window mode that cannot fail.
+    int32_t live_rearms_left = 3;
+    int32_t live_rearms = 0;          // times the handle went LIVE again
+    int64_t rearm_from = -1;          // >= 0: a demcz_run call that starts behind this generation re-arms (no_live is set)
+    uint32_t fail_row_hint = 0xffffffffu;   // archive row of the wait that failed (live_failed -> live_rollback), 0xffffffff: unknown
     struct RecDesc { bool valid = false; int64_t g_first = 0, M = 0, rows = 0; int32_t ngen = 0, boff = 0; } rec_desc[2];
     // wave-per-chain split layout: the producer half of a launch is a kernel of its own on a side stream (its own, small
     // register budget: it fills the SIMDs beside the one-wave-per-SIMD consumers instead of sharing their workgroup shape)
@@ -329,6 +343,10 @@ struct demcz_handle {
     unsigned int* d_err_all = nullptr; // mode 2: [0] max over ranks of the LIVE error word, [1] barrier scratch
     bool archive_fine = false;         // dZ is a fine-grained allocation of its own (hipExtMallocWithFlags), not the pool's
     size_t dZ_bytes = 0;
+    size_t mailbox_off = 0;            // archive_fine: byte offset of the 4 KiB mailbox behind the archive (peer_ping)
+    bool peers_closed = false;         // mode 3: demcz_peer_detach has closed the mappings of the peers' archives (no further demcz_run)
+    int32_t ping_ok = -1;              // demcz_comm_init's first-contact check: -1 not made, 0 failed (on some rank), 1 passed on all
+    double ping_wait_us = 0.0;         // ... and how long THIS rank waited for the last peer's token
     int64_t live_share = 0;            // per-mille of the device's LIVE capacity this handle holds (live_claim)
     int64_t comm_timeout_ms = 60000;
     bool comm_dead = false;
@@ -386,6 +404,31 @@ __global__ void rendezvous_kernel(unsigned int* ctr, unsigned int R, unsigned in
     const unsigned long long t0 = wall_clock64();           // 100 MHz
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < R && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(16);
     if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= R) __hip_atomic_fetch_add(met, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// First contact between the replicas of a sharded run (demcz_comm_init): every rank stores a token into slot `rank` of every
+// peer's mailbox -- the same write-through, system-scope 8-byte store live_publish uses for a row, through the same IPC mapping,
+// into the same fine-grained allocation (the mailbox is its last 4 KiB) -- and polls its OWN mailbox, at system scope like
+// live_reload, until all R tokens are there or the time is up.  What the in-launch hand-off rests on -- a store from another
+// GPU's running kernel becoming visible to a polling kernel here -- is thereby checked on the real links before any row
+// depends on it; result[0] = 1 if all tokens arrived, result[1] = 100 MHz ticks this rank waited for the last of them.
+struct PingBoxes { unsigned long long* box[DEMCZ_MAX_PEERS]; };
+__global__ void peer_ping_kernel(unsigned long long* own, PingBoxes peers, int n_peers, int rank, int R, unsigned long long token,
+                                 unsigned long long max_ticks, unsigned int* result)
+{
+    const int lane = (int)threadIdx.x;
+    if (lane < n_peers) __hip_atomic_store(peers.box[lane] + rank, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == 0) __hip_atomic_store(own + rank, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long t0 = wall_clock64();
+    bool ok = lane >= R;
+    while (!ok && wall_clock64() - t0 < max_ticks) {
+        ok = __hip_atomic_load(own + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == token;
+        if (!ok) __builtin_amdgcn_s_sleep(8);
+    }
+    const unsigned long long waited = wall_clock64() - t0;
+    const bool all = __builtin_amdgcn_ballot_w64(ok) == __builtin_amdgcn_ballot_w64(true);
+    unsigned long long wmax = waited;
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(wmax, o, 64); wmax = v > wmax ? v : wmax; }
+    if (lane == 0) { result[0] = all ? 1u : 0u; result[1] = (unsigned int)(wmax > 0xffffffffull ? 0xffffffffull : wmax); }
 }
 __global__ void stall_kernel(int* release, unsigned long long max_ticks)
 {
@@ -510,6 +553,7 @@ static int64_t blockstep_nblk(int b)
 }
 
 constexpr size_t ML_MAX_DYNAMIC_LDS = 160 * 1024;      // LDS per CU on gfx950
+constexpr size_t PEER_MAILBOX_BYTES = 4096;            // behind a fine-grained archive: peer_ping_kernel's tokens
 constexpr size_t REC_PAD = 64;       // doubles behind a record buffer: a consumer's fetches may run past its last row's last generation
 constexpr int PC_CONSUMER_CHAINS = 8;       // chains per consumer workgroup of the replicated split layout: 8 lanes per chain
 static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t nobs, int max_blocklen, int nblocks);
@@ -526,8 +570,25 @@ static void rec_invalidate(demcz_handle* h)
     h->prod_pending[0] = h->prod_pending[1] = false;
     h->rec_desc[0].valid = h->rec_desc[1].valid = false;
 }
+// The archive is about to get SHORTER (a rollback, a new demcz_set_state, a discarded speculative slab): the record buffers may hold
+// row indices drawn against the longer one.  No launch consumes them -- rec_invalidate makes the next launch draw its own -- but
+// the wave-per-chain kernels prefetch a pass or two past a launch's last generation, out of whatever the buffer holds there,
+// and a prefetched index of an unwritten row reads the sentinel.  Zeros ("row 0: always a legal index") again, as at allocation.
+static int32_t rec_scrub(demcz_handle* h)
+{
+    rec_invalidate(h);
+    if (h->lanes != DEMCZ_LAYOUT_SPLIT || h->rec_cap <= 0 || getenv("DEMCZ_NO_SCRUB")) return DEMCZ_OK;
+    for (int b = 0; b < 2; ++b) {
+        if (!h->d_rec[b]) continue;
+        const size_t per = h->rec_in_arena ? (size_t)(h->cfg.d + 2) : (size_t)((h->split_kind == 3) ? 2 * h->S : (int64_t)h->cfg.d + 2);
+        const size_t nd = (size_t)h->rec_cap * per * (size_t)h->cfg.N + REC_PAD;
+        HIPCHK(h, hipMemsetAsync(h->d_rec[b], 0, nd * sizeof(double), h->stream));
+    }
+    return DEMCZ_OK;
+}
 static int32_t flush_exchanges(demcz_handle* h);
 static void peer_detach(demcz_handle* h);
+static void peer_no_dual(demcz_handle* h);
 static int32_t peer_setup_ipc(demcz_handle* h);
 static bool peer_capable(const demcz_handle* h);
 static int32_t check_live_err(demcz_handle* h);
@@ -609,6 +670,7 @@ static void free_all(demcz_handle* h)
     if (h->d_spec_lp) (void)dev_free(h->cfg.device_id, h->d_spec_lp);
     if (h->spec_ev) (void)hipEventDestroy(h->spec_ev);
     if (h->diag_ev) (void)hipEventDestroy(h->diag_ev);
+    if (h->rhat_side_ev) (void)hipEventDestroy(h->rhat_side_ev);
     if (h->diag_stream) stream_release(h->cfg.device_id, h->diag_stream, !h->comm_dead && hipStreamQuery(h->diag_stream) == hipSuccess);
     if (h->stall_flag) (void)dev_free(h->cfg.device_id, h->stall_flag);
     if (h->xdone) (void)host_free(const_cast<long long*>(h->xdone));
@@ -668,6 +730,7 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
     demcz_handle* h = new demcz_handle();
     h->cfg = *cfg;
     h->lanes = 1;
+    if (const char* re = getenv("DEMCZ_LIVE_REARMS")) h->live_rearms_left = std::max(0, atoi(re));
     auto bail = [&](int32_t code) {
         g_create_error = h->err;
         free_all(h);
@@ -966,6 +1029,13 @@ static void peer_detach(demcz_handle* h)
         }
         for (int r = 0; r < DEMCZ_MAX_PEERS; ++r)
             if (h->ipc_mapped[r]) { (void)hipIpcCloseMemHandle(h->ipc_mapped[r]); h->ipc_mapped[r] = nullptr; }
+        // ... and once more behind the closing: an exported allocation is only freed when no importer has it mapped any longer
+        // (freeing it under a peer's mapping is undefined by the IPC contract, whatever current ROCm makes of it)
+        if (met) {
+            met = false;
+            if (ncclAllReduce(h->d_err_all + 1, h->d_err_all + 1, 1, ncclUint32, ncclMax, h->comm, h->stream) == ncclSuccess)
+                met = sync_stream(h, h->stream, "demcz_destroy (peers, mappings closed)") == DEMCZ_OK;
+        }
         if (!met && h->archive_fine) h->dZ = nullptr;       // leaked on purpose (see above)
     }
     h->n_peers = 0;
@@ -1072,10 +1142,11 @@ extern "C" int32_t demcz_set_state(demcz_handle* h, const double* X, const doubl
     h->M = M0;
     h->M_app = M0;
     h->peer_fence = true;
+    if (h->no_live && h->rearm_from >= 0) h->rearm_from = 0;      // (a new run numbers its generations from the start again)
     h->live_log.clear();
     h->snap_pending = false;
     h->acc_log.clear();
-    rec_invalidate(h);
+    { int32_t rcs = rec_scrub(h); if (rcs) return rcs; }
     for (auto& pe : h->pending) if (pe.ev) (void)hipEventDestroy(pe.ev);
     h->pending.clear();
     h->batch_cnt = 0; h->batch_J = -1;
@@ -1849,14 +1920,60 @@ static int32_t live_rollback(demcz_handle* h, std::vector<demcz_handle::RunCall>
     HIPCHK(h, hipMemsetAsync(h->d_live_err, 0, 4 * sizeof(unsigned int), h->stream));
     SYNCCHK(h, h->stream);
     h->peer_fence = true;
+    // Where the redo may go LIVE again: behind the demcz_run call that holds the generation whose row never arrived.  The row
+    // says which boundary it belongs to -- rows [safe_M_app + j * rows, + rows) are boundary j since the verified point, appended
+    // after generation (safe_g_done / K + 1 + j) * K -- and the wave that gave up was working on a generation behind it.  No row
+    // on record (the launch found the word already set; a kernel that does not note it): behind everything enqueued so far.
+    int64_t from = h->g_done;
+    if (h->fail_row_hint != 0xffffffffu && (int64_t)h->fail_row_hint >= h->safe_M_app && (int64_t)h->fail_row_hint < h->M_app) {
+        const int64_t rows = h->cfg.N * ((h->comm || h->peer_mode != 0) ? h->nranks : 1);
+        const int64_t j = ((int64_t)h->fail_row_hint - h->safe_M_app) / rows;
+        from = std::min<int64_t>(from, (h->safe_g_done / h->cfg.K + 1 + j) * (int64_t)h->cfg.K + 1);
+    }
+    h->fail_row_hint = 0xffffffffu;
     h->M = h->safe_M;
     h->M_app = h->safe_M_app;
     h->g_done = h->safe_g_done;
     while (!h->acc_log.empty() && h->acc_log.back().g_last > h->safe_g_done) h->acc_log.pop_back();
-    rec_invalidate(h);
+    { int32_t rcs = rec_scrub(h); if (rcs) return rcs; }
     h->no_live = true;
+    h->rearm_from = -1;
+    if (h->peer_mode != 1 && h->peer_mode != 3 && h->live_rearms_left > 0) {      // (a replica group re-arms as a whole: group_verify)
+        --h->live_rearms_left;
+        h->rearm_from = from;
+    }
+    // (a fault a test injected has fired: the redo's LIVE launches run with the handle's own poll limit)
+    h->live_fault_polls = 0;
     live_release(h);
     ++h->live_redos;
+    return DEMCZ_OK;
+}
+
+// The handle tries LIVE launches again (see demcz_handle::live_rearms_left).  Called at a point where everything enqueued so far
+// ran one launch per K-window -- nothing of it can have failed -- and every rank of a sharded run is at the same call with the
+// same decision to try (it follows from the max-reduced error word and the min-reduced row of live_failed).  Whether a rank CAN
+// -- its share of the device's LIVE budget may have gone to another handle of its process meanwhile -- is agreed by a
+// min-reduction: either all ranks hand rows over inside their launches again or none does (a rank exchanging through
+// ncclAllGather while its peers publish and poll would stall all of them until the communicator's deadline).  The ranks meet
+// once more, stream-ordered, before the first launch that publishes (peer_fence, set by the rollback).
+static int32_t live_try_rearm(demcz_handle* h)
+{
+    h->rearm_from = -1;
+    h->no_live = false;
+    unsigned int ok = live_span(h) > 0 ? 1u : 0u;
+    if (h->peer_mode == 2 && h->comm && h->d_err_all) {
+        HIPCHK(h, hipMemcpyAsync(h->d_err_all + 2, &ok, sizeof(ok), hipMemcpyHostToDevice, h->stream));
+        NCCLCHK(h, ncclAllReduce(h->d_err_all + 2, h->d_err_all + 2, 1, ncclUint32, ncclMin, h->comm, h->stream));
+        SYNCCHK(h, h->stream);
+        HIPCHK(h, hipMemcpy(&ok, h->d_err_all + 2, sizeof(ok), hipMemcpyDeviceToHost));
+    }
+    if (!ok) {
+        h->no_live = true;
+        live_release(h);
+        return DEMCZ_OK;
+    }
+    ++h->live_rearms;
+    if (getenv("DEMCZ_DEBUG_LIVE")) fprintf(stderr, "[demcz] rank %d: LIVE launches re-armed (%d re-arms left)\n", h->rank, (int)h->live_rearms_left);
     return DEMCZ_OK;
 }
 
@@ -1882,6 +1999,30 @@ static int32_t live_failed(demcz_handle* h, bool& failed)
     h->pinned_err_launches = -1;
     failed = e[0] != 0u;
     if (!failed && h->peer_mode != 2) h->err_clean = true;
+    if (failed) {
+        // which row: what live_rollback places the re-arming point by.  Ranks of a communicator need the SAME point: the smallest
+        // row any of them has on record (0xffffffff: none on this rank -- its own waits all succeeded, or the wave that gave up
+        // could not say).  Every rank knows `failed` from the reduction above, so every rank is in this one too.
+        unsigned int row = 0xffffffffu;
+        if (h->peer_mode == 2 && !h->no_live && h->comm) {
+            unsigned int le[4] = {0, 0, 0, 0};
+            HIPCHK(h, hipMemcpy(le, h->d_live_err, sizeof(le), hipMemcpyDeviceToHost));
+            if (le[0] && le[0] == 1u) row = le[2];
+            HIPCHK(h, hipMemcpyAsync(h->d_err_all + 2, &row, sizeof(row), hipMemcpyHostToDevice, h->stream));
+            NCCLCHK(h, ncclAllReduce(h->d_err_all + 2, h->d_err_all + 2, 1, ncclUint32, ncclMin, h->comm, h->stream));
+            SYNCCHK(h, h->stream);
+            HIPCHK(h, hipMemcpy(&row, h->d_err_all + 2, sizeof(row), hipMemcpyDeviceToHost));
+        } else if (e[0] == 1u) {           // (the word a wave's compare-and-swap wrote; a test's pre-set word has no row behind it)
+            row = e[2];
+        }
+        h->fail_row_hint = row;
+        if (getenv("DEMCZ_DEBUG_LIVE")) {
+            unsigned int le[4] = {0, 0, 0, 0};
+            (void)hipMemcpy(le, h->d_live_err, sizeof(le), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[demcz] rank %d: hand-off failed: word %#x, generation %u of its launch, row %u, workgroup %u; verified point: g %lld, M %lld; enqueued: g %lld, M %lld; launches %lld\n",
+                    h->rank, le[0], le[1], le[2], le[3], (long long)h->safe_g_done, (long long)h->safe_M_app, (long long)h->g_done, (long long)h->M_app, (long long)h->launches);
+        }
+    }
     return DEMCZ_OK;
 }
 
@@ -1902,16 +2043,29 @@ static int32_t live_verify(demcz_handle* h)
         return fail(h, DEMCZ_ERR_STATE, "a row another rank should have published never became visible (in-launch hand-off, host-mediated IPC peers): "
                                         "results since the last verified point are void on every rank");
     }
-    std::vector<demcz_handle::RunCall> calls;
+    // The redo: back to the verified point, the logged calls again.  They run one launch per K-window up to the call that holds
+    // the generation whose row never came; a call that starts behind it may go LIVE again (live_try_rearm, in demcz_run) -- its
+    // launches are logged like any others, against the SAME verified point (`replaying`: no new snapshot), and should one of them
+    // fail too the whole list is redone once more.  Bounded: every failure takes one of the handle's re-arms, and without one
+    // left the redo cannot fail.
+    std::vector<demcz_handle::RunCall> calls, dropped;
     rc = live_rollback(h, calls);
     if (rc) return rc;
-    h->replaying = true;
-    for (const auto& c : calls) {
-        rc = demcz_run(h, c.g_from, c.g_to, c.gamma, c.tempered ? c.temperature.data() : nullptr);
-        if (rc) break;
+    for (;;) {
+        h->replaying = true;
+        for (const auto& c : calls) {
+            rc = demcz_run(h, c.g_from, c.g_to, c.gamma, c.tempered ? c.temperature.data() : nullptr);
+            if (rc) break;
+        }
+        h->replaying = false;
+        if (rc) return rc;
+        if (h->live_log.empty()) break;
+        rc = live_failed(h, failed);
+        if (rc) return rc;
+        if (!failed) { h->live_log.clear(); return DEMCZ_OK; }
+        rc = live_rollback(h, dropped);
+        if (rc) return rc;
     }
-    h->replaying = false;
-    if (rc) return rc;
     SYNCCHK(h, h->stream);
     return check_live_err(h);
 }
@@ -2016,6 +2170,13 @@ static int32_t group_verify(demcz_handle* h)
         return rc;
     }
     for (demcz_handle* m : G->members) m->g_done = calls[0].empty() ? m->g_done : calls[0].back().g_to;
+    if (G->failed && !G->lockstep_only && G->rearms_left > 0) {
+        // everything logged has been executed in lockstep, every member is at the same verified point: the group hands its rows
+        // over inside the launches again from the next call on (bounded: see demcz_handle::live_rearms_left)
+        --G->rearms_left;
+        G->failed = false;
+        for (demcz_handle* m : G->members) { m->no_live = false; m->rearm_from = -1; m->live_rearms_left = G->rearms_left; ++m->live_rearms; }
+    }
     return check_live_err(h);
 }
 
@@ -2194,6 +2355,25 @@ static void live_release(demcz_handle* h)
     h->live_claimed = false;
 }
 
+// A handle that becomes a peer gives up the two-chains-to-a-wave form (window_kernel_ps2d).  That form only takes REGULAR
+// launches; its irregular ones (a start or a tail that is not a multiple of five, temperatures outside the arena, a history of
+// 4 GiB or more) run the general kernel with one chain per wave -- twice the waves, which are not all resident, so never LIVE --
+// and a non-LIVE launch appends N rows per boundary at M_append + b * N: it knows nothing of `brows` / `row_off`, publishes
+// nothing to the peers and waits for nothing of theirs, while the host advances M by N * shards (the replicas'
+// archives would silently hold sentinel rows read as data).  With one chain per wave every launch of a peer is either LIVE or --
+// when the shard's chains are more than a LIVE launch holds (N > 1024 per shard at d <= 5) -- the handle runs the exchange path
+// (RCCL all-gather; a replica group: lockstep), which appends all shards' rows itself.  Same results either way.
+static void peer_no_dual(demcz_handle* h)
+{
+    if (!h->ps_dual) return;
+    live_release(h);
+    h->ps_dual = false;
+    h->dual_now = false;
+    h->split_per_wg = PS_CHAINS;
+    h->live_wg_cap = -1;
+    rec_invalidate(h);
+}
+
 // layouts whose LIVE consumers re-read a missing row through live_reload (system scope when there are peers)
 static bool peer_capable(const demcz_handle* h)
 {
@@ -2319,6 +2499,11 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     const bool sharded = (h->comm != nullptr);
     if (h->peer_mode == 1 && (!h->group || h->group->dead))
         return fail(h, DEMCZ_ERR_STATE, "demcz_run: a member of this handle's replica group has been destroyed");
+    if (h->no_live && h->rearm_from >= 0 && g_from > h->rearm_from) {
+        // behind the generation a hand-off failed at: LIVE launches again (the calls up to here ran one launch per K-window)
+        int32_t rcr = live_try_rearm(h);
+        if (rcr) return rcr;
+    }
     // `peer`: the boundary rows of ALL shards reach this replica from inside the launches (live_publish) -- no exchange step
     const bool peer = h->peer_mode != 0 && live_span(h) > 0;
     const bool rccl_exchange = sharded && !peer;
@@ -2335,6 +2520,8 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         if (h->external_append && nb == 1 && (g_to % K) != 0)
             return fail(h, DEMCZ_ERR_STATE, "demcz_run: with external append the K boundary must be the last generation of the call");
     }
+    if (h->peer_mode == 3 && h->peers_closed)
+        return fail(h, DEMCZ_ERR_STATE, "demcz_run: the peers' archives have been closed (demcz_peer_detach): this handle runs no further generations");
     if (h->peer_mode == 3 && !peer)
         return fail(h, DEMCZ_ERR_STATE, "demcz_run: host-mediated IPC peers run with the in-launch hand-off only (it is not available: a timed-out "
                                         "hand-off, an append lag, caller-owned appends, or more chains than a LIVE launch holds)");
@@ -2417,18 +2604,19 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         int32_t rcr = rec_reserve(h, cap);
         if (rcr) return rcr;
     }
-    if (!h->replaying && live_span(h) > 0) {
+    if (live_span(h) > 0) {
         // this call may issue LIVE launches: they are verified at the next synchronising entry point, and redone
         // from here (live_verify) should a row hand-off inside one of them fail
         // bound the redo: verify now (a synchronisation every 256 calls).  Not inside demcz_run_checked: that call rolls back
         // to ITS entry and redoes itself from there (statistics and stop decisions included), so the snapshot must not move
-        // into the middle of it.
-        if (h->live_log.size() >= 256 && !h->in_checked && h->peer_mode != 1) {      // (a replica group verifies as a whole: group_verify)
+        // into the middle of it.  Not inside a redo either (`replaying`): a call of a redo that has re-armed is logged against
+        // the verified point the redo started from -- the snapshot taken there is the one a second failure goes back to.
+        if (h->live_log.size() >= 256 && !h->in_checked && !h->replaying && h->peer_mode != 1) {      // (a replica group verifies as a whole: group_verify)
             int32_t rcv = live_verify(h);
             if (rcv) return rcv;
         }
         if (live_span(h) > 0) {
-            if (h->live_log.empty()) {
+            if (h->live_log.empty() && !h->replaying) {
                 const int64_t N = h->cfg.N;
                 const int d = h->cfg.d;
                 if (!h->d_safe_X) HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->d_safe_X, (size_t)N * d * sizeof(double)));
@@ -2844,6 +3032,22 @@ static int32_t rhat_enqueue(demcz_handle* h, int64_t g_from, int64_t g_to, doubl
         }
         qs = h->diag_stream;
     }
+    // Every check works in the handle's one scratch buffer.  Checks on a side stream follow each other there; a check on the
+    // compute stream (the call's last slab; demcz_rhat) waits for the latest of them.  (Round 5: a 300-slab demcz_run_checked of
+    // four-generation slabs showed the second-to-last check's statistic computed from a scratch the last check was already
+    // writing -- one run in four; with 1000-generation slabs the side check is long done when the last slab ends.)
+    if (qs == h->stream && h->rhat_side_pending) {
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->rhat_side_ev, 0));
+        h->rhat_side_pending = false;
+    }
+    struct SideMark {
+        demcz_handle* h; hipStream_t qs;
+        ~SideMark() {
+            if (qs == h->stream) return;
+            if (!h->rhat_side_ev && hipEventCreateWithFlags(&h->rhat_side_ev, hipEventDisableTiming) != hipSuccess) { h->rhat_side_ev = nullptr; return; }
+            if (hipEventRecord(h->rhat_side_ev, qs) == hipSuccess) h->rhat_side_pending = true;
+        }
+    } side_mark{h, qs};
     int32_t rc = rhat_prepare(h, g_from, g_to, r, true, qs);
     if (rc) return rc;
     const int d = r.d;
@@ -3174,9 +3378,10 @@ extern "C" int32_t demcz_peer_group(demcz_handle** handles, int32_t R)
     }
     PeerGroup* G = new PeerGroup();
     for (int r = 0; r < R; ++r) G->members.push_back(handles[r]);
-    G->failed = !peer_capable(h0) || !concurrent;      // (a layout without the hand-off, or streams that cannot overlap: lockstep from the start)
+    G->rearms_left = h0->live_rearms_left;
     for (int r = 0; r < R; ++r) {
         demcz_handle* m = handles[r];
+        peer_no_dual(m);
         m->group = G;
         m->peer_mode = 1;
         m->nranks = R;
@@ -3185,6 +3390,15 @@ extern "C" int32_t demcz_peer_group(demcz_handle** handles, int32_t R)
         for (int q = 0; q < R; ++q) if (q != r) m->peer_Z[m->n_peers++] = handles[q]->dZ;
         rec_invalidate(m);                  // (draws made against N rows per boundary no longer apply)
     }
+    // Hand-off inside the launches: a layout that has it, streams that can overlap -- and EVERY member able to issue LIVE launches
+    // (its shard within what a launch may hold, its share of the device's LIVE budget granted).  All of them or none: a member
+    // without LIVE launches only logs its calls (demcz_run), and they are executed for the whole group, in lockstep, at the next
+    // verification -- which group_verify does when the group is marked `failed`.
+    bool all_live = peer_capable(h0) && concurrent;
+    for (int r = 0; r < R && all_live; ++r) all_live = live_span(handles[r]) > 0;
+    if (!all_live) for (int r = 0; r < R; ++r) live_release(handles[r]);
+    G->lockstep_only = !all_live;
+    G->failed = G->lockstep_only;
     return DEMCZ_OK;
 }
 
@@ -3209,11 +3423,14 @@ static int32_t archive_make_fine(demcz_handle* h, hipIpcMemHandle_t* mh, bool* o
         return DEMCZ_OK;
     }
     double* fine = nullptr;
-    if (hipExtMallocWithFlags((void**)&fine, h->dZ_bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return DEMCZ_OK; }
+    const size_t box_off = (h->dZ_bytes + 255) & ~(size_t)255;
+    if (hipExtMallocWithFlags((void**)&fine, box_off + PEER_MAILBOX_BYTES, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return DEMCZ_OK; }
     if (hipIpcGetMemHandle(mh, fine) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(fine); return DEMCZ_OK; }
     { int32_t rcq = quiesce_all(h); if (rcq) { (void)hipFree(fine); return rcq; } }
     if (h->prod_stream) (void)hipStreamSynchronize(h->prod_stream);
-    if (hipMemcpyAsync(fine, h->dZ, h->dZ_bytes, hipMemcpyDeviceToDevice, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
+    if (hipMemcpyAsync(fine, h->dZ, h->dZ_bytes, hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
+        hipMemsetAsync(reinterpret_cast<unsigned char*>(fine) + box_off, 0, PEER_MAILBOX_BYTES, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) {
         (void)hipFree(fine);
         return fail(h, DEMCZ_ERR_HIP, "copy into the fine-grained archive failed");
     }
@@ -3227,6 +3444,7 @@ static int32_t archive_make_fine(demcz_handle* h, hipIpcMemHandle_t* mh, bool* o
     g_dev_pool.release(h->dZ, h->cfg.device_id);
     h->dZ = fine;
     h->archive_fine = true;
+    h->mailbox_off = box_off;
     *ok = true;
     return DEMCZ_OK;
 }
@@ -3296,13 +3514,56 @@ static int32_t peer_setup_ipc(demcz_handle* h)
     if (rc == DEMCZ_OK) rc = sync_stream(h, h->stream, "demcz_comm_init (IPC agreement)");
     unsigned int all_ok = 0u;
     if (rc == DEMCZ_OK && hipMemcpy(&all_ok, d_ok, sizeof(all_ok), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(h, DEMCZ_ERR_HIP, "demcz_comm_init: download failed");
-    cleanup();
-    if (rc || !all_ok) {
+    auto close_all = [&]() {
         for (int i = 0; i < DEMCZ_MAX_PEERS; ++i) if (h->ipc_mapped[i]) { (void)hipIpcCloseMemHandle(h->ipc_mapped[i]); h->ipc_mapped[i] = nullptr; }
         h->n_peers = 0;
+    };
+    if (rc || !all_ok) {
+        cleanup();
+        close_all();
         return rc;
     }
+    // Second agreement (round 5), two questions in one reduction:
+    //  * first contact (peer_ping_kernel): does a token stored from every peer's running kernel reach this rank's polling kernel
+    //    through the mappings just opened, within 200 ms?  The hand-off has only ever run between processes on ONE GPU before
+    //    a multi-GPU node sees it; this asks the links themselves, before any row depends on the answer;
+    //  * can THIS rank issue LIVE launches at all -- live_span() depends on the process's LIVE budget on its device (another handle
+    //    of the process may hold it) and on the occupancy query?  A rank that exchanged through ncclAllGather
+    //    while its peers publish and poll would stall all of them until the communicator's deadline.
+    // Either every rank hands its rows over inside the launches, or none does.
     h->peer_mode = 2;
+    peer_no_dual(h);
+    unsigned int* d_res = reinterpret_cast<unsigned int*>(d_rec) + 4;
+    unsigned int agree = 1u;
+    {
+        PingBoxes pb{};
+        for (int i = 0; i < h->n_peers; ++i) pb.box[i] = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(h->peer_Z[i]) + h->mailbox_off);
+        unsigned long long* own = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(h->dZ) + h->mailbox_off);
+        static const unsigned long long ping_ms = getenv("DEMCZ_PING_MS") ? (unsigned long long)atol(getenv("DEMCZ_PING_MS")) : 200ull;
+        hipLaunchKernelGGL(peer_ping_kernel, dim3(1), dim3(64), 0, h->stream, own, pb, h->n_peers, h->rank, R, 0xC0FFEE0000000001ull,
+                           ping_ms * 100000ull, d_res);
+        unsigned int res[2] = {0, 0};
+        if (hipGetLastError() != hipSuccess) rc = fail(h, DEMCZ_ERR_HIP, "demcz_comm_init: ping launch failed");
+        if (rc == DEMCZ_OK) rc = sync_stream(h, h->stream, "demcz_comm_init (first contact)");
+        if (rc == DEMCZ_OK && hipMemcpy(res, d_res, sizeof(res), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(h, DEMCZ_ERR_HIP, "demcz_comm_init: download failed");
+        h->ping_wait_us = (double)res[1] / 100.0;
+        const bool can_live = rc == DEMCZ_OK && live_span(h) > 0;
+        agree = (res[0] && can_live) ? 1u : 0u;
+        if (getenv("DEMCZ_DEBUG_LIVE")) fprintf(stderr, "[demcz] rank %d: first contact %s after %.1f us, LIVE launches %s\n", h->rank, res[0] ? "ok" : "FAILED", h->ping_wait_us, can_live ? "possible" : "not possible");
+    }
+    if (rc == DEMCZ_OK && (hipMemcpyAsync(d_ok, &agree, sizeof(agree), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+                           ncclAllReduce(d_ok, d_ok, 1, ncclUint32, ncclMin, h->comm, h->stream) != ncclSuccess)) rc = fail(h, DEMCZ_ERR_COMM, "demcz_comm_init: reduction failed");
+    if (rc == DEMCZ_OK) rc = sync_stream(h, h->stream, "demcz_comm_init (hand-off agreement)");
+    unsigned int all_agree = 0u;
+    if (rc == DEMCZ_OK && hipMemcpy(&all_agree, d_ok, sizeof(all_agree), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(h, DEMCZ_ERR_HIP, "demcz_comm_init: download failed");
+    cleanup();
+    h->ping_ok = (rc == DEMCZ_OK && all_agree) ? 1 : 0;
+    if (rc || !all_agree) {
+        h->peer_mode = 0;
+        live_release(h);
+        close_all();
+        return rc;
+    }
     h->peer_fence = true;
     // a second communicator and stream for the monitoring R-hat of a finished slab (rhat_enqueue): its two small all-reduces then
     // run beside the next slab's launch instead of holding every rank's compute stream until all ranks have joined
@@ -3344,8 +3605,35 @@ extern "C" int32_t demcz_peer_attach(demcz_handle* h, const void* handles_64B_ea
     std::vector<hipIpcMemHandle_t> hs((size_t)h->nranks);
     std::memcpy(hs.data(), handles_64B_each, sizeof(hipIpcMemHandle_t) * (size_t)h->nranks);
     if (!peers_open(h, hs.data(), h->nranks, h->rank)) return fail(h, DEMCZ_ERR_HIP, "demcz_peer_attach: hipIpcOpenMemHandle refused (peer access between the devices?)");
+    peer_no_dual(h);
     h->peer_mode = 3;
     rec_invalidate(h);
+    return DEMCZ_OK;
+}
+
+// Mode 3, the orderly end: a rank's exported archive may only be freed once no other rank has it mapped.  The host makes the
+// ranks meet after their last synchronising call, every rank calls demcz_peer_detach (its results stay readable, it runs no
+// further generations), the host makes them meet once more, and only then does any rank call demcz_destroy.
+extern "C" int32_t demcz_peer_detach(demcz_handle* h)
+{
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (h->peer_mode != 3) return fail(h, DEMCZ_ERR_STATE, "demcz_peer_detach: host-mediated IPC peers only (demcz_peer_export / demcz_peer_attach)");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    int32_t rc = live_verify(h);
+    if (rc) return rc;
+    for (hipStream_t st : {h->stream, h->prod_stream, h->diag_stream})
+        if (st) HIPCHK(h, hipStreamSynchronize(st));
+    for (int r = 0; r < DEMCZ_MAX_PEERS; ++r)
+        if (h->ipc_mapped[r]) { (void)hipIpcCloseMemHandle(h->ipc_mapped[r]); h->ipc_mapped[r] = nullptr; }
+    h->peers_closed = true;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_get_peer_ping(const demcz_handle* h, int32_t* ok, double* wait_us)
+{
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (ok) *ok = h->ping_ok;
+    if (wait_us) *wait_us = h->ping_wait_us;
     return DEMCZ_OK;
 }
 
@@ -3672,8 +3960,8 @@ static int32_t run_checked_body(demcz_handle* h, int64_t g_from, int64_t g_to, d
                         h->M_app = M_before;
                         h->M = M_before;
                         h->g_done = nxt;
-                        rec_invalidate(h);
-                        if (!h->live_log.empty()) h->live_log.pop_back();     // the discarded slab is not to be redone
+                        if ((rc = rec_scrub(h)) != DEMCZ_OK) break;
+                        if (!h->live_log.empty() && h->live_log.back().g_from == nxt + 1) h->live_log.pop_back();     // the discarded slab is not to be redone
                         while (!h->acc_log.empty() && h->acc_log.back().g_last > nxt) h->acc_log.pop_back();
                     }
                     break;
@@ -3717,24 +4005,34 @@ extern "C" int32_t demcz_run_checked(demcz_handle* h, int64_t g_from, int64_t g_
     // everything before this call is verified first, so that a failed LIVE hand-off inside it rolls back to HERE
     int32_t rc = live_verify(h);
     if (rc) return rc;
-    h->host_paced = (getenv("DEMCZ_NO_HOST_PACING") == nullptr);
-    h->in_checked = true;
-    rc = run_checked_body(h, g_from, g_to, gamma, temperature, every, threshold, g_stop, n_checks, rhat_max, n_max, rhat_last);
-    h->host_paced = false;
-    h->in_checked = false;
-    if (h->live_log.empty()) return rc;
-    // the statistics and the stop decision above may rest on a slab whose row hand-off failed: look, and if so
-    // undo the whole call and make it again with one launch per K-window (the handle stays in that mode)
-    // (a run that failed for another reason on THIS rank only must not leave the others waiting in the reduction below: the
-    //  communicator's deadline covers it)
-    if (rc != DEMCZ_OK && h->peer_mode == 2) return rc;
-    bool failed = false;
-    { int32_t rcf = live_failed(h, failed); if (rcf) return rcf; }
-    if (!failed) { h->live_log.clear(); return rc; }
-    std::vector<demcz_handle::RunCall> dropped;
-    rc = live_rollback(h, dropped);
-    if (rc) return rc;
-    return run_checked_body(h, g_from, g_to, gamma, temperature, every, threshold, g_stop, n_checks, rhat_max, n_max, rhat_last);
+    // (a handle waiting to go LIVE again does so at this call's first slab or -- in a redo -- at a later one, never at a point of
+    //  a fresh call that is not its entry: the snapshot a failure goes back to must be the entry's)
+    if (h->no_live && h->rearm_from >= g_from) h->rearm_from = g_from - 1;
+    const bool pacing = (getenv("DEMCZ_NO_HOST_PACING") == nullptr);
+    for (;;) {
+        h->host_paced = pacing;
+        h->in_checked = true;
+        rc = run_checked_body(h, g_from, g_to, gamma, temperature, every, threshold, g_stop, n_checks, rhat_max, n_max, rhat_last);
+        h->host_paced = false;
+        h->in_checked = false;
+        if (h->live_log.empty()) break;
+        // the statistics and the stop decision above may rest on a slab whose row hand-off failed: look, and if so undo the whole
+        // call and make it again -- one launch per K-window up to the slab that holds the generation whose row never came, LIVE
+        // again behind it while the handle has re-arms left (live_rollback), every slab of the redo logged against THIS call's
+        // entry (`replaying`).  A redo that fails too is redone the same way; without a re-arm left it cannot fail.
+        // (a run that failed for another reason on THIS rank only must not leave the others waiting in the reduction below: the
+        //  communicator's deadline covers it)
+        if (rc != DEMCZ_OK && h->peer_mode == 2) break;
+        bool failed = false;
+        { int32_t rcf = live_failed(h, failed); if (rcf) { rc = rcf; break; } }
+        if (!failed) { h->live_log.clear(); break; }
+        std::vector<demcz_handle::RunCall> dropped;
+        rc = live_rollback(h, dropped);
+        if (rc) break;
+        h->replaying = true;
+    }
+    h->replaying = false;
+    return rc;
 }
 
 // ---- diagnostic entry points (not part of the contract of SURVEY.md 8(b); benchmarks and tests only) ----------
@@ -3742,6 +4040,26 @@ extern "C" int32_t demcz_set_live_spin_limit(demcz_handle* h, int32_t polls)
 {
     if (!h || polls < 0) return DEMCZ_ERR_INVALID_ARGUMENT;
     h->live_spin_limit = (unsigned int)polls;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_set_live_rearms(demcz_handle* h, int32_t n)
+{
+    if (!h || n < 0) return DEMCZ_ERR_INVALID_ARGUMENT;
+    h->live_rearms_left = n;
+    if (h->peer_mode == 1 && h->group) {
+        h->group->rearms_left = n;
+        for (demcz_handle* m : h->group->members) m->live_rearms_left = n;
+    }
+    if (n == 0) h->rearm_from = -1;
+    return DEMCZ_OK;
+}
+
+extern "C" int32_t demcz_get_live_rearms(const demcz_handle* h, int32_t* rearms, int32_t* left)
+{
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (rearms) *rearms = h->live_rearms;
+    if (left) *left = h->live_rearms_left;
     return DEMCZ_OK;
 }
 

@@ -781,7 +781,11 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         }
         PW_T(5);                 // boundary
         if constexpr (LIVE) {
-            if (__builtin_amdgcn_ballot_w64(bad_n) != 0ull) {
+            // (REG: every pass counts as five generations, the one BEHIND the launch's last too -- its slot holds whatever the
+            //  record buffer has past this launch's draws, which after a rollback, a demcz_set_state or a discarded slab are row
+            //  indices of a LONGER archive than there is: never waited for.  Found in round 5 by the re-arming tests: a LIVE launch
+            //  behind a redo polled 2^18 times for a row nobody was going to write.  Without REG that pass has length 0.)
+            if ((!REG || ip + 1 < npass) && __builtin_amdgcn_ballot_w64(bad_n) != 0ull) {
                 if (reread(slot, qR(1), g0 + R)) { leave(); return; }
             }
         }

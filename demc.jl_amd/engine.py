@@ -200,6 +200,17 @@ class HipEngine:
         self._chk(self._L.demcz_get_live_status(self._h, C.byref(on), C.byref(redos)))
         return bool(on.value), int(redos.value)
 
+    def set_live_rearms(self, n: int):
+        """How many more times the handle may go back to LIVE launches after a failed hand-off (default 3; 0: a failure leaves
+        it at one launch per K-window for good, the behaviour of rounds 2-4)."""
+        self._chk(self._L.demcz_set_live_rearms(self._h, C.c_int32(int(n))))
+
+    def live_rearms(self):
+        """Diagnostic: (times the handle went LIVE again after a fall-back, re-arms left)."""
+        a, b = C.c_int32(0), C.c_int32(0)
+        self._chk(self._L.demcz_get_live_rearms(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def kernel_counts(self):
         """Diagnostic: window launches so far by kernel -- {"ps2", "ps_general", "other"} (demcz_debug_kernel_counts)."""
         c = (C.c_int64 * 3)()
@@ -341,8 +352,23 @@ class HipEngine:
         buf = C.create_string_buffer(blob, len(blob))
         self._chk(self._L.demcz_peer_attach(self._h, buf))
 
+    def peer_detach(self):
+        """demcz_peer_detach (host-mediated IPC peers): close this rank's mappings of the other ranks' archives.  Call between
+        two barriers of the host's, after the last run and before any rank closes its engine."""
+        self._chk(self._L.demcz_peer_detach(self._h))
+
+    def peer_ping(self):
+        """(ok, wait_us) of demcz_comm_init's first-contact check: ok = 1 passed on all ranks, 0 failed somewhere (the run
+        exchanges through ncclAllGather), -1 not made; wait_us = how long this rank waited for the last peer's token."""
+        ok, us = C.c_int32(-1), C.c_double(0.0)
+        self._chk(self._L.demcz_get_peer_ping(self._h, C.byref(ok), C.byref(us)))
+        return int(ok.value), float(us.value)
+
     def peer_status(self):
-        """(mode, peers): mode 0 = RCCL exchange or unsharded, 1 = replica group of this process, 2 = IPC peers."""
+        """(mode, peers): mode 0 = RCCL exchange or unsharded, 1 = replica group of this process (demcz_peer_group), 2 = IPC
+        peers set up over the library's communicator (demcz_comm_init), 3 = IPC peers set up by the host carrying the handles
+        (demcz_peer_export / demcz_peer_attach: no automatic redo, the host owes the barriers); peers = replicas this handle
+        publishes into besides its own."""
         m, n = C.c_int32(0), C.c_int32(0)
         self._chk(self._L.demcz_get_peer_status(self._h, C.byref(m), C.byref(n)))
         return int(m.value), int(n.value)

@@ -242,6 +242,18 @@ int32_t demcz_get_peer_status(const demcz_handle* h, int32_t* mode, int32_t* pee
  * no automatic redo in this mode. */
 int32_t demcz_peer_export(demcz_handle* h, int32_t nranks, int32_t rank, void* handle_64B);
 int32_t demcz_peer_attach(demcz_handle* h, const void* handles_64B_each);
+/* The orderly end of that mode: an exported archive may only be freed once no other rank has it mapped.  After the host's
+ * barrier behind the last synchronising call every rank calls demcz_peer_detach (closes its mappings of the others' archives;
+ * results stay readable, demcz_run is refused from then on), the host makes the ranks meet once more, then demcz_destroy.
+ * (With the library's own communicator, demcz_comm_init, demcz_destroy holds both meetings itself.) */
+int32_t demcz_peer_detach(demcz_handle* h);
+/* demcz_comm_init's first-contact check (round 5).  Before the in-launch hand-off is switched on, every rank's kernel stores a
+ * token into every peer's archive allocation -- the store a published row uses, through the IPC mapping a row would travel --
+ * while it polls its own for the peers' tokens (at most 200 ms, DEMCZ_PING_MS); the outcome and "can this rank issue LIVE
+ * launches at all" are min-reduced over the ranks: either every rank hands rows over inside its launches or all of them keep
+ * the ncclAllGather exchange.  *ok = 1 passed on all ranks, 0 failed somewhere (the exchange is in use), -1 not made (unsharded,
+ * DEMCZ_NO_PEER, IPC refused); *wait_us = how long this rank's kernel waited for the last token (start skew + link latency). */
+int32_t demcz_get_peer_ping(const demcz_handle* h, int32_t* ok, double* wait_us);
 
 /* Deadline of every host-side wait of a sharded handle (a stream or event behind an RCCL collective): default 60 000 ms, or
  * the environment variable DEMCZ_COMM_TIMEOUT_MS at demcz_comm_init; 0 = wait for ever.  While it waits the library polls
@@ -331,12 +343,20 @@ int32_t demcz_selftest_draws(int32_t device_id, uint64_t seed, uint64_t chain, u
 
 /* LIVE launches (split layout on one GPU: a launch runs through many K boundaries and its waves hand the appended
  * rows to each other through the archive itself).  A wave that polls `polls` times for a row without seeing it
- * gives up; the library then redoes everything since the last verified point with one launch per K-window and
- * keeps the handle in that mode (results are bit-identical either way).  polls = 0 restores the default (2^18).
+ * gives up; the library then redoes everything since the last verified point with one launch per K-window
+ * (results are bit-identical either way).  polls = 0 restores the default (2^18).
  * demcz_get_live_status: *live_enabled = 1 while the handle issues LIVE launches, *redos = times it had to
- * fall back.  Tests lower the limit to 1 to walk the fall-back path. */
+ * fall back.  Tests lower the limit to 1 to walk the fall-back path.
+ * Re-arming (round 5).  A time-out is not for ever: the redo runs one launch per K-window up to and including the demcz_run
+ * call (inside demcz_run_checked: the slab) that holds the generation whose row never arrived, and the first call behind it
+ * issues LIVE launches again -- in a sharded run on every rank together (the ranks agree on the point through the reduced error
+ * words, and on "can go LIVE again" through one more reduction).  A handle does this at most `n` times in its life (default 3;
+ * DEMCZ_LIVE_REARMS in the environment at demcz_create; demcz_set_live_rearms), after which a failure leaves it at one launch
+ * per K-window, the mode that cannot fail.  demcz_get_live_rearms: *rearms = times it went LIVE again, *left = what remains. */
 int32_t demcz_set_live_spin_limit(demcz_handle* h, int32_t polls);
 int32_t demcz_get_live_status(const demcz_handle* h, int32_t* live_enabled, int32_t* redos);
+int32_t demcz_set_live_rearms(demcz_handle* h, int32_t n);
+int32_t demcz_get_live_rearms(const demcz_handle* h, int32_t* rearms, int32_t* left);
 /* Diagnostic: window launches so far by the kernel that took them (three values): counts[0] window_kernel_ps2 (the regular
  * launches of the wave-per-chain layout), [1] that layout's general kernels (window_kernel_ps / _pw), [2] launches of every
  * other layout.  Tests use it to know which kernel a parity case exercised. */
@@ -347,7 +367,8 @@ int32_t demcz_debug_kernel_name(const demcz_handle* h, char* buf, int32_t cap);
 
 /* Fault injection for the LIVE hand-off: LIVE launches whose first generation is >= g_from use the poll limit `polls` instead
  * of the handle's (demcz_set_live_spin_limit), so that a test can make a hand-off fail LATE in a long call (e.g. in slab 280 of
- * a 300-slab demcz_run_checked).  polls = 0 switches it off.  polls = -1: such a launch finds the error word already set -- as if
+ * a 300-slab demcz_run_checked).  polls = 0 switches it off; a fault that has fired (the redo it caused has rolled back) switches
+ * itself off, so that the redo's own LIVE launches run undisturbed.  polls = -1: such a launch finds the error word already set -- as if
  * a wave had timed out before the others became resident (another process on the GPU) -- so every wave leaves at once; the redo
  * snapshot buffers are filled with NaN patterns beforehand, so a wave that left without writing its row of the snapshot shows. */
 int32_t demcz_debug_set_live_fault(demcz_handle* h, int32_t polls, int64_t g_from);

@@ -41,7 +41,9 @@ def main():
     ch, lo = e.get_history(1, G)
     X, lp, Z, M = e.get_state()
     live, info = e.live_status(), e.info()
-    dist.barrier()                          # nobody frees its archive while another rank may still be publishing into it
+    dist.barrier()                          # nobody closes a mapping while another rank may still be publishing through its own
+    e.peer_detach()                         # this rank's mappings of the other archives are closed ...
+    dist.barrier()                          # ... on every rank, before any rank frees its exported archive (demcz_destroy)
     np.savez(outdir / f"rank{rank}.npz", chain=ch, log_obj=lo, X=X, logp=lp, Z=np.array(Z), M=M, mode=status[0], peers=status[1],
              live=int(live[0]), redos=live[1], launches=info["window_launches"])
     e.close()

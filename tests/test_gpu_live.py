@@ -33,6 +33,7 @@ def test_forced_handoff_timeout_is_redone_bit_exact(demc, oracle, K, layout, d):
     e = _engine(demc, w, N, d, K, G, seed, layout)
     assert e.info()["lanes_per_chain"] == layout
     e.set_live_spin_limit(1)
+    e.set_live_rearms(0)                           # (this case: the fall-back for good; re-arming has its own tests below)
     e.run(1, 50, w["gamma"])
     e.run(51, G, w["gamma"])                       # two calls in the log: both are redone
     e.synchronize()                                # verifies, rolls back, redoes
@@ -56,6 +57,7 @@ def test_forced_handoff_timeout_inside_run_checked(demc, oracle, layout):
     w = demc.workloads.mvnormal_problem(d, N)
     a = _engine(demc, w, N, d, K, G, seed, layout)
     a.set_live_spin_limit(1)
+    a.set_live_rearms(0)
     ga, ta, la = a.run_checked(1, G, w["gamma"], every, 0.0)
     on, redos = a.live_status()
     assert redos == 1 and not on
@@ -218,6 +220,7 @@ def test_partial_timeouts_drain_and_are_redone(demc, oracle, layout, d, polls):
     e = _engine(demc, w, N, d, K, G, seed, layout)
     assert e.info()["lanes_per_chain"] == layout
     e.set_live_spin_limit(polls)
+    e.set_live_rearms(0)
     e.run(1, G, w["gamma"])
     e.synchronize()
     on, redos = e.live_status()
@@ -243,6 +246,7 @@ def test_run_checked_of_more_than_256_slabs_redoes_from_its_entry(demc, oracle, 
         e = _engine(demc, w, N, d, K, G, seed, SPLIT_WAVE)
         if fault:
             e.debug_set_live_fault(1, every * 280)            # poll limit 1 from slab 280 on
+            e.set_live_rearms(0)
         g_stop, trace, last = e.run_checked(1, G, w["gamma"], every, threshold)
         on, redos = e.live_status()
         assert (redos, on) == ((1, False) if fault else (0, True))
@@ -294,6 +298,7 @@ def test_wave_that_finds_the_launch_already_failed_still_writes_its_snapshot_row
         e.run(1, first - 1, w["gamma"])
         e.synchronize()                            # verified: the snapshot of the next call is taken at generation `first`
     e.debug_set_live_fault(-1, first)
+    e.set_live_rearms(0)
     e.run(first, G, w["gamma"])
     assert e.kernel_counts()["ps2"] >= 1, "the faulted launch must be the steady-state kernel's"
     e.synchronize()
@@ -306,3 +311,96 @@ def test_wave_that_finds_the_launch_already_failed_still_writes_its_snapshot_row
     assert np.isfinite(X).all() and np.isfinite(lp).all()
     assert np.array_equal(chain, ref["chain"]) and np.array_equal(lobj, ref["log_obj"])
     assert np.array_equal(X, ref["X"]) and np.array_equal(lp, ref["logp"]) and M == ref["M"] and np.array_equal(Z, ref["Z"])
+
+
+# ---- re-arming (round 5): a time-out is not for ever ------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout,d", [(SPLIT_WAVE, 5), (SPLIT_WAVE, 20), (SPLIT, 5), (SPLIT, 20)])
+def test_run_checked_goes_live_again_behind_the_failed_slab(demc, oracle, layout, d):
+    """A hand-off that times out in slab 3 of a 6-slab demcz_run_checked (fault injection: poll limit 1 for launches that start at
+    generation 2 * every + 1 or later; the fault switches itself off once it has fired).  The call rolls back to its entry and
+    redoes itself: one launch per K-window through slab 3 -- the slab that holds the generation whose row never came -- and LIVE
+    launches again from slab 4 on (demcz_capi.hip: live_rollback / live_try_rearm).  Told apart by the launch count: slabs 1-3 of
+    the redo are `every / K` launches each, slabs 4-6 one each.  Results: those of an undisturbed twin and of the oracle."""
+    N, K, every, seed = 512, 10, 200, 71
+    G = 6 * every
+    w = demc.workloads.mvnormal_problem(d, N)
+    e = _engine(demc, w, N, d, K, G, seed, layout)
+    e.debug_set_live_fault(1, 2 * every + 1)
+    g_stop, trace, last = e.run_checked(1, G, w["gamma"], every, 0.0)
+    on, redos = e.live_status()
+    rearms, left = e.live_rearms()
+    launches = e.info()["window_launches"]
+    assert redos == 1 and rearms == 1 and left == 2 and on, (redos, rearms, left, on)
+    # first attempt: at most 6 + a cold start; the redo: 3 * every / K one-window launches, then 3 (+ cold starts) LIVE ones
+    assert 3 * every // K + 3 <= launches <= 3 * every // K + 6 + 8, launches
+    ch, lo = e.get_history(1, G)
+    X, lp, Z, M = e.get_state()
+    # ... and the handle keeps its LIVE launches afterwards
+    before = e.info()["window_launches"]
+    e.close()
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed)
+    assert g_stop == G and np.array_equal(ch, ref["chain"]) and np.array_equal(lo, ref["log_obj"])
+    assert np.array_equal(X, ref["X"]) and np.array_equal(lp, ref["logp"]) and M == ref["M"] and np.array_equal(Z, ref["Z"])
+    b = _engine(demc, w, N, d, K, G, seed, layout)      # undisturbed twin: the same trace of statistics
+    _, tb, lb = b.run_checked(1, G, w["gamma"], every, 0.0)
+    b.close()
+    assert np.array_equal(trace, tb) and np.array_equal(last, lb)
+
+
+def test_rearm_after_plain_runs_and_its_bound(demc, oracle):
+    """demcz_run calls + a synchronising call.  The poll limit of 1 stays (demcz_set_live_spin_limit), so every LIVE launch with a
+    wait in it fails: the first verification redoes the calls up to the failed one per K-window and re-arms for the one behind it,
+    which fails again, ... until the handle's re-arms (set to 2 here) are used up and it stays at one launch per K-window.  Every
+    intermediate state is the oracle's; redos = 1 + re-arms."""
+    N, d, K, seed = 512, 5, 2, 17
+    w = demc.workloads.mvnormal_problem(d, N)
+    G = 240
+    e = _engine(demc, w, N, d, K, G, seed, SPLIT_WAVE)
+    e.set_live_spin_limit(1)
+    e.set_live_rearms(2)
+    for a in range(1, G, 40):
+        e.run(a, a + 39, w["gamma"])
+    e.synchronize()
+    on, redos = e.live_status()
+    rearms, left = e.live_rearms()
+    assert (redos, rearms, left, on) == (3, 2, 0, False), (redos, rearms, left, on)
+    ch, lo = e.get_history(1, G)
+    X, lp, Z, M = e.get_state()
+    e.close()
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed)
+    assert np.array_equal(ch, ref["chain"]) and np.array_equal(lo, ref["log_obj"])
+    assert np.array_equal(X, ref["X"]) and np.array_equal(lp, ref["logp"]) and M == ref["M"] and np.array_equal(Z, ref["Z"])
+
+
+def test_rearm_on_the_next_call_and_after_set_state(demc, oracle):
+    """A failure in the LAST call made: nothing of the redo lies behind it, so the handle re-arms at the next call -- and a
+    demcz_set_state in between (a new run, generations numbered from 1 again) does not lose the pending re-arm."""
+    N, d, K, G, seed = 512, 5, 10, 400, 23
+    w = demc.workloads.mvnormal_problem(d, N)
+    e = _engine(demc, w, N, d, K, 2 * G, seed, SPLIT_WAVE)
+    e.debug_set_live_fault(1, 1)
+    e.run(1, G, w["gamma"])
+    e.synchronize()
+    assert e.live_status() == (False, 1) and e.live_rearms() == (0, 2)
+    n0 = e.info()["window_launches"]
+    e.run(G + 1, 2 * G, w["gamma"])
+    e.synchronize()
+    assert e.live_status() == (True, 1) and e.live_rearms() == (1, 2)
+    assert e.info()["window_launches"] - n0 <= 4
+    ch, _ = e.get_history(1, 2 * G)
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, 2 * G, None, w["eps_scale"], w["gamma"], seed)
+    assert np.array_equal(ch, ref["chain"])
+    # the same through set_state
+    e.debug_set_live_fault(1, 1)
+    e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+    e.run(1, G, w["gamma"])
+    e.synchronize()
+    assert e.live_status() == (False, 2) and e.live_rearms() == (1, 1)
+    e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+    n0 = e.info()["window_launches"]
+    e.run(1, G, w["gamma"])
+    e.synchronize()
+    assert e.live_status() == (True, 2) and e.live_rearms() == (2, 1) and e.info()["window_launches"] - n0 <= 4
+    ch2, _ = e.get_history(1, G)
+    e.close()
+    assert np.array_equal(ch2, ref["chain"][:, :, :G])

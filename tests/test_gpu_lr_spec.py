@@ -72,6 +72,7 @@ def test_forced_handoff_timeout_is_redone_bit_exact(demc, oracle, K):
     w = demc.workloads.linreg_problem(d, N, nobs=70)
     e = _engine(demc, w, N, d, K, G, seed)
     e.set_live_spin_limit(1)
+    e.set_live_rearms(0)                  # (the fall-back for good; re-arming: tests/test_gpu_live.py)
     e.run(1, 50, gamma)
     e.run(51, G, gamma)
     e.synchronize()

@@ -21,6 +21,25 @@ os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 BLOCKS_D20 = [list(range(0, 5)), list(range(5, 10)), list(range(10, 15)), list(range(15, 20))]
 
 
+def _communicate_all(procs, timeout):
+    """communicate() with every child; whatever happens (a rank that hangs, an exception here) no child outlives the test: a
+    rank left polling on the GPU would hold it for the rest of the session."""
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except Exception:
+                pass
+    return outs
+
+
 def _group(demc, w, R, n_loc, d, K, G, seed, blocks=None, lanes=0, group=True):
     N = R * n_loc
     M0 = w["Zinit"].shape[0]
@@ -95,6 +114,7 @@ def test_replica_group_forced_timeout_is_redone_in_lockstep(demc, oracle, R, d):
     w = demc.workloads.mvnormal_problem(d, N)
     es = _group(demc, w, R, N // R, d, K, G1 + G2, seed)
     es[R - 1].set_live_spin_limit(1)
+    es[0].set_live_rearms(0)                         # (of the whole group; re-arming: test_replica_group_goes_live_again)
     _run(es, [50, 70], w["gamma"])
     es[0].synchronize()                              # verifies the GROUP: rollback and lockstep redo of both calls
     assert all(e.live_status()[1] == 1 and not e.live_status()[0] for e in es), [e.live_status() for e in es]
@@ -255,7 +275,7 @@ def test_two_processes_on_one_gpu_hand_rows_over_through_ipc(demc, oracle, tmp_p
     case = str(Path(__file__).resolve().parent / "peer_ipc_case.py")
     procs = [subprocess.Popen([sys.executable, case, str(r), str(world), str(port), str(tmp_path), str(d), pieces],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
-    outs = [p.communicate(timeout=300) for p in procs]
+    outs = _communicate_all(procs, 300)
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, (p.returncode, so[-1500:], se[-3000:])
     N, K, seed = 1024, 10, 2024 + d
@@ -270,3 +290,98 @@ def test_two_processes_on_one_gpu_hand_rows_over_through_ipc(demc, oracle, tmp_p
     assert np.array_equal(np.concatenate([r["chain"] for r in rs], axis=0), ref["chain"])
     assert np.array_equal(np.concatenate([r["log_obj"] for r in rs], axis=0), ref["log_obj"])
     assert np.array_equal(np.concatenate([r["X"] for r in rs], axis=0), ref["X"])
+
+
+def test_replica_group_goes_live_again(demc, oracle):
+    """A forced time-out on one member (fault injection, fires once): the group rolls back, executes what was logged in lockstep --
+    and from the next call on its members publish into each other's replicas from inside their launches again (round 5)."""
+    R, N, d, K, G1, G2, seed = 2, 512, 5, 10, 300, 300, 5
+    w = demc.workloads.mvnormal_problem(d, N)
+    es = _group(demc, w, R, N // R, d, K, G1 + G2, seed)
+    es[1].debug_set_live_fault(1, 1)
+    _run(es, [G1], w["gamma"])
+    es[0].synchronize()
+    assert all(e.live_status()[1] == 1 for e in es) and all(e.live_rearms() == (1, 2) for e in es), [e.live_rearms() for e in es]
+    n0 = [e.info()["window_launches"] for e in es]
+    for e in es:
+        e.run(G1 + 1, G1 + G2, w["gamma"])
+    for e in es:
+        e.synchronize()
+    assert all(e.live_status() == (True, 1) for e in es), [e.live_status() for e in es]
+    assert all(e.info()["window_launches"] - n <= 4 for e, n in zip(es, n0)), "LIVE launches again: a handful per call"
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G1 + G2, None, w["eps_scale"], w["gamma"], seed)
+    _check(es, G1 + G2, ref)
+    for e in es:
+        e.close()
+
+
+def test_rearm_with_the_ipc_set_up_of_a_one_rank_communicator(demc, oracle, monkeypatch):
+    """The sharded handle's path (peer mode 2): error words max-reduced, the failed row min-reduced, the redo through
+    ncclAllGather up to the failed slab, the ranks' agreement to go LIVE again (a min-reduction), the stream-ordered meeting
+    before the first publishing launch -- on a communicator of one rank.  6-slab demcz_run_checked, fault in slab 3."""
+    monkeypatch.setenv("DEMCZ_PEER_SELF", "1")
+    N, d, K, every, seed = 512, 5, 10, 200, 29
+    G = 6 * every
+    w = demc.workloads.mvnormal_problem(d, N)
+    M0 = w["Zinit"].shape[0]
+    e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K + 1), Gcap=G, blockindex=[range(d)], eps_scale=w["eps_scale"],
+                       seed=seed, target=w["target"])
+    e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+    e.comm_init(e.comm_unique_id(), 1, 0)
+    assert e.peer_status() == (2, 0) and e.peer_ping()[0] == 1
+    e.debug_set_live_fault(1, 2 * every + 1)
+    g_stop, trace, _ = e.run_checked(1, G, w["gamma"], every, 0.0)
+    assert e.live_status() == (True, 1) and e.live_rearms() == (1, 2)
+    launches = e.info()["window_launches"]
+    assert 3 * every // K + 3 <= launches <= 3 * every // K + 14, launches
+    ch, lo = e.get_history(1, G)
+    _, _, Z, M = e.get_state()
+    e.close()
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed)
+    assert np.array_equal(ch, ref["chain"]) and np.array_equal(lo, ref["log_obj"]) and np.array_equal(Z, ref["Z"]) and M == ref["M"]
+
+
+def test_a_two_chain_handle_that_becomes_a_peer_runs_one_chain_per_wave(demc, oracle):
+    """1024 < N <= 2048 chains per shard at d <= 5 selects two chains to a wave (window_kernel_ps2d), whose
+    irregular launches cannot hand rows over; as a peer such a handle must not mix the two.  Two members of 1100 chains, calls
+    that are not multiples of five: every replica must hold the oracle's archive (no sentinel row read as data, none missing)."""
+    R, n_loc, d, K, seed = 2, 1100, 5, 10, 3
+    N = R * n_loc
+    pieces = [103, 7, 190]
+    G = sum(pieces)
+    w = demc.workloads.mvnormal_problem(d, N)
+    es = _group(demc, w, R, n_loc, d, K, G, seed)
+    _run(es, pieces, w["gamma"])
+    for e in es:
+        e.synchronize()
+    assert all("ps2d" not in e.kernel_name() for e in es), [e.kernel_name() for e in es]
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed, threads=THREADS)
+    _check(es, G, ref)
+    for e in es:
+        e.close()
+
+
+@pytest.mark.parametrize("d,G", [(5, 1000), (20, 400)])
+def test_eight_replicas_concurrently_on_one_gpu(demc, oracle, tmp_path, d, G):
+    """C4's fan-out -- eight replicas, seven peer stores per published element, eight launches polling each other -- as far as one
+    GPU can show it: a replica group of R = 8 x 128 chains.  HIP multiplexes a process's streams over four hardware queues by
+    default, on which eight launches that wait for each other cannot all run; GPU_MAX_HW_QUEUES = 8, set before the process's
+    first GPU call, lifts that -- hence a fresh child process (tests/peer_group_r8_case.py).  Bit-equal to the oracle's unsharded
+    run, LIVE launches on every member (no lockstep fall-back)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    case = str(Path(__file__).resolve().parent / "peer_group_r8_case.py")
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    p = subprocess.Popen([sys.executable, case, str(tmp_path), str(d), str(G)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    (so, se), = _communicate_all([p], 300)
+    assert p.returncode == 0, (p.returncode, so[-1500:], se[-3000:])
+    r = np.load(tmp_path / "r8.npz")
+    N, K, seed = 1024, 10, 808 + d
+    w = demc.workloads.mvnormal_problem(d, N)
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed, threads=THREADS)
+    assert list(r["live"]) == [1] * 8 and list(r["redos"]) == [0] * 8, (r["live"], r["redos"])
+    assert max(r["launches"]) <= 6, "LIVE launches through the boundaries on every member"
+    assert np.array_equal(r["chain"], ref["chain"]) and np.array_equal(r["log_obj"], ref["log_obj"])
+    assert np.array_equal(r["X"], ref["X"]) and all(int(m) == ref["M"] for m in r["M"])
+    assert np.array_equal(r["Z0"], ref["Z"]) and np.array_equal(r["Z7"], ref["Z"])
