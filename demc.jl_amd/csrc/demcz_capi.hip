@@ -2575,6 +2575,8 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
     P.rec_in = nullptr; P.rec_out = nullptr; P.next_g_first = 0; P.next_M = 0; P.next_ngen = 0; P.consumer_blocks = 0;
     P.next_rows = 0; P.next_boff = 0; P.rec_stride = 0;
     P.rec_fields = (h->lanes == DEMCZ_LAYOUT_SPLIT && h->split_kind == 2) ? h->cfg.d + 2 : 0;    // lane-per-parameter consumers: record-major
+    P.z_bytes = (uint32_t)std::min<size_t>(h->dZ_bytes, 0xffffffffull);
+    P.hist_bytes = (hist && h->hist_joint) ? (uint32_t)std::min<double>((double)h->cfg.N * (h->cfg.d + 1) * (double)h->cfg.Gcap * 8.0, 4294967295.0) : 0u;
     P.brows = h->cfg.N * (peer ? shards : 1);
     P.row_off = peer ? (int64_t)h->rank * h->cfg.N : 0;
     P.n_peers = peer ? h->n_peers : 0;

@@ -118,6 +118,13 @@ struct WindowParams {
     int64_t row_off;
     int32_t n_peers;
     double* peer_Z[DEMCZ_MAX_PEERS];
+    // What the kernels' raw-buffer descriptors clip at (round 5: every descriptor is sized to its allocation, so that an offset
+    // gone wrong is dropped by the hardware instead of written / read somewhere inside the 4 GB a descriptor could span):
+    // z_bytes = bytes addressable from Z -- the archive, or with the arena of the wave-per-chain layout the archive, both record
+    // buffers and the temperatures behind it; hist_bytes = chain ‖ log_obj as ONE allocation from `chain` (0: two allocations or
+    // none).  Both saturate at 0xffffffff; kernels that address through them are only launched when everything lies below that.
+    uint32_t z_bytes;
+    uint32_t hist_bytes;
 #ifdef DEMCZ_STAMPS
     unsigned long long* stamps;   // diagnostic build only (scripts/stamps.py): 16 values per workgroup (8 stamps, 8 sums)
 #endif

@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(LIVE ? 64 * PC8_LIVE_WAVES : 64) window_kernel
     constexpr int ROUNDS = (CH + L - 1) / L;
     constexpr int HW = (D + 1) / 2;                       // 16-byte pieces of a row
     static_assert(2 * HW <= ZSC, "a row's last 16-byte piece stays inside the row");
-    const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.Z), 0, 0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.Z), 0, (int)P.z_bytes, 0x00020000);      // (the archive's own size: a wrong row index reads zeros, not a neighbour)
     // The prefetch reads every row through the ordinary cached path, also in a LIVE launch.  A row this launch appends
     // is published by write-through (sc1) stores, so memory always holds its final doubles or the sentinel; what an
     // ordinary load can add to that is a STALE copy from this XCD's L2 / the CU's L1 -- which, each double of a row being

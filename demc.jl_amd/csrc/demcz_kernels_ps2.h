@@ -77,6 +77,31 @@ __device__ __forceinline__ void ps2_dma16(const void* sbase, unsigned voff, unsi
     asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" PS2_DMA_POLICY
                  :: "v"(voff), "s"(sbase), "{m0}"(lds_dst) : "memory");
 }
+// The same transfer through a buffer descriptor (round 5, the default: PS2_DMA_BUFFER).  A global load checks nothing: its address
+// is base + a 32-bit offset made from a row index that itself came out of an LDS slot a pass ago -- one mis-counted s_waitcnt and
+// the index is whatever the slot held before, the address anywhere in the 4 GB behind the arena: a memory-access fault, as seen
+// once in round 4 with an experimental form of this kernel whose vector-memory count per pass was off.  With
+// num_records = the arena's size the hardware returns zeros for anything beyond it: a wrong index can give a wrong result -- which
+// the parity tests see -- but never touches memory that is not the handle's.
+typedef unsigned int ps2_rsrc_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ps2_rsrc_t ps2_make_rsrc(const void* base, unsigned int bytes)
+{
+    const unsigned long long b = (unsigned long long)reinterpret_cast<uintptr_t>(base);
+    ps2_rsrc_t r;
+    r.x = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)b);
+    r.y = (unsigned int)__builtin_amdgcn_readfirstlane((int)((unsigned int)(b >> 32) & 0xffffu));      // stride 0: a raw buffer
+    r.z = (unsigned int)__builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ void ps2_dma16b(ps2_rsrc_t rsrc, unsigned voff, unsigned lds_dst)
+{
+    asm volatile("s_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" PS2_DMA_POLICY
+                 :: "v"(voff), "s"(rsrc), "{m0}"(lds_dst) : "memory");
+}
+#ifndef PS2_DMA_BUFFER
+#define PS2_DMA_BUFFER 1
+#endif
 
 template <int TARGET, int D, bool LIVE, bool TEMPER>
 __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_kernel_ps2(const WindowParams P)
@@ -145,8 +170,10 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             inc = (unsigned int)((int64_t)R * P.N * 8);
         } else { off = 0xffffff00u; inc = 0u; }
     };
+    // (num_records = the history's own size, P.hist_bytes < 0xfff00000 -- ps2_applicable: a store whose offset is wrong is dropped,
+    //  not written into whatever lies within 4 GB of the history; "nothing to store" = 0xffffff00 lies above any such size)
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hist ? reinterpret_cast<unsigned char*>(P.chain) : reinterpret_cast<unsigned char*>(const_cast<double*>(P.Z)),
-                                                                           0, hist ? (int)0xfffff000u : 0, 0x00020000);
+                                                                           0, hist ? (int)P.hist_bytes : 0, 0x00020000);
     // (all 64 lanes execute the store -- lanes with nothing to store point out of range)
     auto hist_store = [&](double v, unsigned int off) __attribute__((always_inline)) {
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -413,6 +440,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     // which half of the packed index pair a row lane takes (v_perm byte selectors; 0x0c = the constant 0x00)
     const unsigned int selv = !rowl ? 0x0c0c0c0cu : (rwhich ? 0x07060504u : 0x03020100u);
     const unsigned char* const zbase = reinterpret_cast<const unsigned char*>(P.Z);
+    [[maybe_unused]] const ps2_rsrc_t zrsrc = ps2_make_rsrc(zbase, P.z_bytes);      // the arena: archive + both record buffers + temperatures
     unsigned int dma_off, dma_inc;
     {
         const unsigned int rec_off = (unsigned int)(reinterpret_cast<const unsigned char*>(P.rec_in) - zbase);
@@ -479,7 +507,11 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         const unsigned int off = (sel << ZSH) + dma_off;
         dma_off += dma_inc;
 #ifndef PS2_EXP_NODMA
+#if PS2_DMA_BUFFER
+        ps2_dma16b(zrsrc, off, raw_lds + (unsigned)slot * 1024u);
+#else
         ps2_dma16(zbase, off, raw_lds + (unsigned)slot * 1024u);
+#endif
 #else
         asm volatile("" :: "v"(off));
 #endif

@@ -86,8 +86,10 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             inc = (unsigned int)((int64_t)R * P.N * 8);
         } else { off = 0xffffff00u; inc = 0u; }
     };
+    // (num_records = the history's own size, P.hist_bytes < 0xfff00000 -- ps2_applicable: a store whose offset is wrong is dropped,
+    //  not written into whatever lies within 4 GB of the history; "nothing to store" = 0xffffff00 lies above any such size)
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hist ? reinterpret_cast<unsigned char*>(P.chain) : reinterpret_cast<unsigned char*>(const_cast<double*>(P.Z)),
-                                                                           0, hist ? (int)0xfffff000u : 0, 0x00020000);
+                                                                           0, hist ? (int)P.hist_bytes : 0, 0x00020000);
     // (all 64 lanes execute the store -- lanes with nothing to store point out of range)
     auto hist_store = [&](double v, unsigned int off) __attribute__((always_inline)) {
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -358,6 +360,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     // which half of the packed index pair a row lane takes (v_perm byte selectors; 0x0c = the constant 0x00)
     const unsigned int selv = !rowl ? 0x0c0c0c0cu : (rwhich ? 0x07060504u : 0x03020100u);
     const unsigned char* const zbase = reinterpret_cast<const unsigned char*>(P.Z);
+    [[maybe_unused]] const ps2_rsrc_t zrsrc = ps2_make_rsrc(zbase, P.z_bytes);      // the arena: archive + both record buffers + temperatures
     // (every one of a pass's NCH DMA instructions uses all 64 lanes in these roles, for the wave's k-th chain)
     int64_t ck[NCH];
 #pragma unroll
@@ -437,7 +440,11 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             const unsigned int sel = __builtin_amdgcn_perm((unsigned int)(pack[q] >> 32), (unsigned int)pack[q], selv);
             const unsigned int off = (sel << ZSH) + dma_off[q];
             dma_off[q] += dma_inc;
+#if PS2_DMA_BUFFER
+            ps2_dma16b(zrsrc, off, raw_lds + (unsigned)(slot * NCH + q) * 1024u);
+#else
             ps2_dma16(zbase, off, raw_lds + (unsigned)(slot * NCH + q) * 1024u);
+#endif
         }
     };
 #pragma unroll

@@ -152,7 +152,11 @@ sub('''    auto issue = [&](uint64_t pack, int slot) __attribute__((always_inlin
         const unsigned int off = (sel << ZSH) + dma_off;
         dma_off += dma_inc;
 #ifndef PS2_EXP_NODMA
+#if PS2_DMA_BUFFER
+        ps2_dma16b(zrsrc, off, raw_lds + (unsigned)slot * 1024u);
+#else
         ps2_dma16(zbase, off, raw_lds + (unsigned)slot * 1024u);
+#endif
 #else
         asm volatile("" :: "v"(off));
 #endif
@@ -165,7 +169,11 @@ sub('''    auto issue = [&](uint64_t pack, int slot) __attribute__((always_inlin
             const unsigned int sel = __builtin_amdgcn_perm((unsigned int)(pack[q] >> 32), (unsigned int)pack[q], selv);
             const unsigned int off = (sel << ZSH) + dma_off[q];
             dma_off[q] += dma_inc;
+#if PS2_DMA_BUFFER
+            ps2_dma16b(zrsrc, off, raw_lds + (unsigned)(slot * NCH + q) * 1024u);
+#else
             ps2_dma16(zbase, off, raw_lds + (unsigned)(slot * NCH + q) * 1024u);
+#endif
         }
     };
 #pragma unroll
