@@ -10,7 +10,7 @@
 #include "demcz_kernels_ps.h"
 #include "demcz_kernels_ps2.h"
 #include "demcz_kernels_ps2d.h"
-#include "demcz_kernels_pw.h"
+#include "demcz_pw_dispatch.h"
 
 #include <rccl/rccl.h>
 
@@ -812,7 +812,9 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
                           : (kind == 3) ? h->wpw * (64 / Lsplit) : 1;
         const bool split_ok = kind != 0;
         // one wave per chain (demcz_kernels_ps.h): where the replicated consumer is built and a pass's draws fit one DMA
-        const bool ps_ok = (kind == 1 || kind == 2) && h->full_block && ps_available(cfg->target_kind, d);
+        // (round 5: wherever the archive's rows are reachable by 32-bit offsets -- no longer only where another split consumer is
+        //  built for the dimension too)
+        const bool ps_ok = idx32 && h->full_block && ps_available(cfg->target_kind, d);
         const int per_wg_default = h->split_per_wg;
         h->split_kind = 0;
         if (cfg->lanes_per_chain == DEMCZ_LAYOUT_SPLIT_WAVE || (cfg->lanes_per_chain == 0 && ps_ok && cfg->N <= PS_MAX_N && cfg->K >= 2 && !getenv("DEMCZ_NO_PS"))) {
@@ -842,11 +844,13 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
                     h->live_wg_cap = -1;
                 }
             }
-            if (!h->ps_dual && cfg->lanes_per_chain == 0 && !single_fits) {
+            if (!h->ps_dual && cfg->lanes_per_chain == 0 && !single_fits && kind != 0) {
                 h->split_kind = kind;
                 h->split_per_wg = per_wg_default;
                 h->live_wg_cap = -1;
             }
+            // (kind == 0 -- a dimension with no other split consumer -- and more chains than a LIVE launch holds, up to PS_MAX_N:
+            //  one wave per chain all the same, one launch per K-window; the alternative is the one-lane kernel's 16-32 waves)
         } else if (cfg->lanes_per_chain == DEMCZ_LAYOUT_SPLIT) {
             if (!split_ok) {
                 h->err = "demcz_create: the split layout is not built for this target / d / block structure";
@@ -1279,7 +1283,7 @@ static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t n
         lr16_dynamic_lds<10>(nobs) <= ML_MAX_DYNAMIC_LDS)
         return 16;      // design + y resident in LDS
     if (target_kind == DEMCZ_TARGET_MVNORMAL) {
-        if (d == 2 || d == 3 || d == 4 || d == 5 || d == 8 || d == 10) return 8;
+        if (d >= 2 && d <= 10) return 8;
         if (d == 20) return 16;
     }
     if (target_kind == DEMCZ_TARGET_ISO_QUAD && d == 10) return 8;
@@ -1306,7 +1310,7 @@ static bool pc_available(int target_kind, int d, bool full_block)
     if (target_kind == DEMCZ_TARGET_ISO_QUAD) return d == 10;
     // (d = 20: the replicated 210-coefficient whitening does not fit registers -- 63 us per window against
     //  16.7 for the 16-lanes-per-chain kernel, which stays the choice there)
-    return target_kind == DEMCZ_TARGET_MVNORMAL && (d == 2 || d == 3 || d == 4 || d == 5 || d == 8 || d == 10);
+    return target_kind == DEMCZ_TARGET_MVNORMAL && d >= 2 && d <= 10;
 }
 
 // the split form of the 16-lane layout (window_kernel_ml<.., REC>): where the replicated consumer does not fit
@@ -1318,7 +1322,12 @@ static bool split_ml_available(int target_kind, int d, bool full_block, int64_t 
 }
 
 // one wave per chain: window_kernel_ps (d <= 5: a pass's draws are one DMA) / window_kernel_pw (C4's d = 20)
-static bool ps_available(int target_kind, int d) { return target_kind == DEMCZ_TARGET_MVNORMAL && ((d >= 2 && d <= 5) || d == 8 || d == 10 || d == 20); }
+// (round 5: every dimension; the isotropic quadratic from d = 6 on -- window_kernel_pw evaluates both targets)
+static bool ps_available(int target_kind, int d)
+{
+    if (target_kind == DEMCZ_TARGET_MVNORMAL) return d >= 2 && d <= PW_D_MAX;
+    return target_kind == DEMCZ_TARGET_ISO_QUAD && d >= PW_D_MIN && d <= PW_D_MAX;
+}
 
 static int pc_roles(int d) { return ((d == 1) ? 1 : (d + 1) / 2) + 2; }
 // doubles of draw record per (generation, chain), and producer lanes per (generation, chain)
@@ -1381,27 +1390,14 @@ static bool pw_regular(const WindowParams& P, bool live)
     return live && !no_reg && P.K % PS_R == 0 && P.to_boundary % PS_R == 0 && P.ngen % PS_R == 0 && P.ngen >= PS_R;
 }
 
-template <int TARGET, int D>
-static void launch_pw(const demcz_handle* h, const WindowParams& P, int64_t blocks, bool live)
+// window_kernel_pw (d = 6..32, MvNormal / isotropic quadratic): instantiated in translation units of its own, demcz_pw_dispatch.h
+static int32_t launch_pw(demcz_handle* h, const WindowParams& P, int64_t blocks, bool live)
 {
-    const dim3 grid((unsigned)blocks), wg(64 * PS_CHAINS), wgl(64 * (PS_CHAINS + 1));
-    if constexpr (D == 20 && TARGET == TARGET_MVNORMAL) {
-        if (live && pw_matrix_form(h)) {
-            if (P.temperature) hipLaunchKernelGGL((window_kernel_pw<TARGET, D, true, true, true>), grid, wgl, 0, h->stream, P);
-            else hipLaunchKernelGGL((window_kernel_pw<TARGET, D, true, false, true>), grid, wgl, 0, h->stream, P);
-            return;
-        }
-    }
-    const bool reg = pw_regular(P, live);
-    if (P.temperature) {
-        if (reg) hipLaunchKernelGGL((window_kernel_pw<TARGET, D, true, true, false, true>), grid, wgl, 0, h->stream, P);
-        else if (live) hipLaunchKernelGGL((window_kernel_pw<TARGET, D, true, true>), grid, wgl, 0, h->stream, P);
-        else hipLaunchKernelGGL((window_kernel_pw<TARGET, D, false, true>), grid, wg, 0, h->stream, P);
-    } else {
-        if (reg) hipLaunchKernelGGL((window_kernel_pw<TARGET, D, true, false, false, true>), grid, wgl, 0, h->stream, P);
-        else if (live) hipLaunchKernelGGL((window_kernel_pw<TARGET, D, true, false>), grid, wgl, 0, h->stream, P);
-        else hipLaunchKernelGGL((window_kernel_pw<TARGET, D, false, false>), grid, wg, 0, h->stream, P);
-    }
+    const int target = (h->cfg.target_kind == DEMCZ_TARGET_ISO_QUAD) ? TARGET_ISO_QUAD : TARGET_MVNORMAL;
+    const int form = (live && pw_matrix_form(h)) ? PW_FORM_MATRIX : pw_regular(P, live) ? PW_FORM_REGULAR : PW_FORM_GENERAL;
+    if (pw_launch(target, P.d, live, P.temperature != nullptr, form, (unsigned)blocks, h->stream, P) != 0)
+        return fail(h, DEMCZ_ERR_STATE, "split layout: dimension / target not built for the wave-per-chain consumer");
+    return DEMCZ_OK;
 }
 
 template <int TARGET, int D>
@@ -1476,15 +1472,23 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
             // (regression target: what a consumer workgroup leaves of its CU's LDS holds ONE 8 KB producer workgroup)
             // (two chains to a wave: one 40 KB consumer workgroup per CU at 2048 chains leaves room for three 32 KB producer
             //  workgroups, and the producer has twice the draws to make per launch: 131 against 144 us per launch, profiles/r04j_dual.txt)
-            const size_t dyn = (ps != h->stream) ? (h->lr_spec ? (size_t)8192 : (h->ps_dual && !getenv("DEMCZ_PRODUCE_LDS")) ? (size_t)32768 : throttle_env) : 0;
+            // (wave-per-chain consumers at d > 20 take 70-110 KB of a CU's LDS themselves: the producers' allocation is what is left)
+            size_t big_d = throttle_env;
+            if (h->split_kind == 4 && P.d > 20) {
+                const size_t clds = (size_t)pw_query(h->cfg.target_kind == DEMCZ_TARGET_ISO_QUAD ? TARGET_ISO_QUAD : TARGET_MVNORMAL, P.d, PW_QUERY_LIVE_LDS_BYTES);
+                const size_t room = (clds + 4096 < ML_MAX_DYNAMIC_LDS) ? ML_MAX_DYNAMIC_LDS - clds - 4096 : 8192;
+                big_d = std::max<size_t>(8192, std::min<size_t>(throttle_env, room));
+            }
+            const size_t dyn = (ps != h->stream) ? (h->lr_spec ? (size_t)8192 : (h->ps_dual && !getenv("DEMCZ_PRODUCE_LDS")) ? (size_t)32768 : big_d) : 0;
             switch (P.d) {
-            case 2: hipLaunchKernelGGL((produce_kernel<2>), pg, pw, dyn, ps, P); break;
-            case 3: hipLaunchKernelGGL((produce_kernel<3>), pg, pw, dyn, ps, P); break;
-            case 4: hipLaunchKernelGGL((produce_kernel<4>), pg, pw, dyn, ps, P); break;
-            case 5: hipLaunchKernelGGL((produce_kernel<5>), pg, pw, dyn, ps, P); break;
-            case 8: hipLaunchKernelGGL((produce_kernel<8>), pg, pw, dyn, ps, P); break;
-            case 10: hipLaunchKernelGGL((produce_kernel<10>), pg, pw, dyn, ps, P); break;
-            case 20: hipLaunchKernelGGL((produce_kernel<20>), pg, pw, dyn, ps, P); break;
+#define DEMCZ_PRODUCE_CASE(DD) case DD: hipLaunchKernelGGL((produce_kernel<DD>), pg, pw, dyn, ps, P); break;
+            DEMCZ_PRODUCE_CASE(2) DEMCZ_PRODUCE_CASE(3) DEMCZ_PRODUCE_CASE(4) DEMCZ_PRODUCE_CASE(5) DEMCZ_PRODUCE_CASE(6) DEMCZ_PRODUCE_CASE(7)
+            DEMCZ_PRODUCE_CASE(8) DEMCZ_PRODUCE_CASE(9) DEMCZ_PRODUCE_CASE(10) DEMCZ_PRODUCE_CASE(11) DEMCZ_PRODUCE_CASE(12) DEMCZ_PRODUCE_CASE(13)
+            DEMCZ_PRODUCE_CASE(14) DEMCZ_PRODUCE_CASE(15) DEMCZ_PRODUCE_CASE(16) DEMCZ_PRODUCE_CASE(17) DEMCZ_PRODUCE_CASE(18) DEMCZ_PRODUCE_CASE(19)
+            DEMCZ_PRODUCE_CASE(20) DEMCZ_PRODUCE_CASE(21) DEMCZ_PRODUCE_CASE(22) DEMCZ_PRODUCE_CASE(23) DEMCZ_PRODUCE_CASE(24) DEMCZ_PRODUCE_CASE(25)
+            DEMCZ_PRODUCE_CASE(26) DEMCZ_PRODUCE_CASE(27) DEMCZ_PRODUCE_CASE(28) DEMCZ_PRODUCE_CASE(29) DEMCZ_PRODUCE_CASE(30) DEMCZ_PRODUCE_CASE(31)
+            DEMCZ_PRODUCE_CASE(32)
+#undef DEMCZ_PRODUCE_CASE
             default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
             }
             HIPCHK(h, hipGetLastError());
@@ -1521,10 +1525,7 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
             case 3: launch_ps<TARGET_MVNORMAL, 3>(h, P, grid, live); break;
             case 4: launch_ps<TARGET_MVNORMAL, 4>(h, P, grid, live); break;
             case 5: launch_ps<TARGET_MVNORMAL, 5>(h, P, grid, live); break;
-            case 8: launch_pw<TARGET_MVNORMAL, 8>(h, P, grid, live); break;
-            case 10: launch_pw<TARGET_MVNORMAL, 10>(h, P, grid, live); break;
-            case 20: launch_pw<TARGET_MVNORMAL, 20>(h, P, grid, live); break;
-            default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
+            default: { int32_t rcw = launch_pw(h, P, grid, live); if (rcw) return rcw; } break;
             }
         }
     } else if (h->split_kind == 3) {
@@ -1573,7 +1574,10 @@ static int32_t launch_window_pc(demcz_handle* h, const WindowParams& P, bool liv
         case 3: launch_pc<TARGET_MVNORMAL, 3>(h, P, blocks, live); break;
         case 4: launch_pc<TARGET_MVNORMAL, 4>(h, P, blocks, live); break;
         case 5: launch_pc<TARGET_MVNORMAL, 5>(h, P, blocks, live); break;
+        case 6: launch_pc<TARGET_MVNORMAL, 6>(h, P, blocks, live); break;
+        case 7: launch_pc<TARGET_MVNORMAL, 7>(h, P, blocks, live); break;
         case 8: launch_pc<TARGET_MVNORMAL, 8>(h, P, blocks, live); break;
+        case 9: launch_pc<TARGET_MVNORMAL, 9>(h, P, blocks, live); break;
         case 10: launch_pc<TARGET_MVNORMAL, 10>(h, P, blocks, live); break;
         default: return fail(h, DEMCZ_ERR_STATE, "split layout: dimension not built");
         }
@@ -1694,7 +1698,10 @@ static bool try_launch_ml(const demcz_handle* h, const WindowParams& P)
         case 3: launch_window_ml<TARGET_MVNORMAL, 3, 8>(h, P); return true;
         case 4: launch_window_ml<TARGET_MVNORMAL, 4, 8>(h, P); return true;
         case 5: launch_window_ml<TARGET_MVNORMAL, 5, 8>(h, P); return true;
+        case 6: launch_window_ml<TARGET_MVNORMAL, 6, 8>(h, P); return true;
+        case 7: launch_window_ml<TARGET_MVNORMAL, 7, 8>(h, P); return true;
         case 8: launch_window_ml<TARGET_MVNORMAL, 8, 8>(h, P); return true;
+        case 9: launch_window_ml<TARGET_MVNORMAL, 9, 8>(h, P); return true;
         case 10: launch_window_ml<TARGET_MVNORMAL, 10, 8>(h, P); return true;
         case 20: launch_window_ml<TARGET_MVNORMAL, 20, 16>(h, P); return true;
         }
@@ -2213,28 +2220,6 @@ static int ps_live_blocks_per_cu()
 }
 
 template <int D>
-static int pw_live_blocks_per_cu()
-{
-    int a = 0, b = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, D, true, false>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) a = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, D, true, true>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) b = 0;
-    int m = std::min(a, b);
-    {                               // (the regular-launch form)
-        int c = 0, e = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, D, true, false, false, true>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) c = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&e, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, D, true, true, false, true>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) e = 0;
-        m = std::min(m, std::min(c, e));
-    }
-    if constexpr (D == 20) {        // (the matrix form of the same launches)
-        int c = 0, e = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, D, true, false, true>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) c = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&e, reinterpret_cast<const void*>(&window_kernel_pw<TARGET_MVNORMAL, D, true, true, true>), 64 * (PS_CHAINS + 1), 0) != hipSuccess) e = 0;
-        m = std::min(m, std::min(c, e));
-    }
-    return m;
-}
-
-template <int D>
 static int ps2d_live_blocks_per_cu()
 {
     int a = 0, b = 0;
@@ -2261,11 +2246,13 @@ static int64_t live_wg_capacity(demcz_handle* h)
         case 3: per_cu = std::min(ps_live_blocks_per_cu<3>(), ps2_live_blocks_per_cu<3>()); break;
         case 4: per_cu = std::min(ps_live_blocks_per_cu<4>(), ps2_live_blocks_per_cu<4>()); break;
         case 5: per_cu = std::min(ps_live_blocks_per_cu<5>(), ps2_live_blocks_per_cu<5>()); break;
-        case 8: per_cu = pw_live_blocks_per_cu<8>(); break;
-        case 10: per_cu = pw_live_blocks_per_cu<10>(); break;
-        case 20: per_cu = pw_live_blocks_per_cu<20>(); break;
-        default: per_cu = 0;
+        default: per_cu = pw_query(h->cfg.target_kind == DEMCZ_TARGET_ISO_QUAD ? TARGET_ISO_QUAD : TARGET_MVNORMAL, h->cfg.d, PW_QUERY_LIVE_BLOCKS_PER_CU);
         }
+        // window_kernel_pw at d > 20: ONE workgroup per CU (its registers, from d = 23 on its LDS too: 86-111 KB).  A launch of
+        // 1024 chains is then a workgroup on every CU, and what else runs on the chip beside it (producer workgroups, the R-hat
+        // kernels: finite, they wait for nothing) can delay a consumer workgroup's start but not prevent it -- the same argument
+        // as for the regression kernel's full-LDS workgroups below.  No halving there (undone by the doubling).
+        if (h->cfg.d > 20 && per_cu == 1) per_cu = 2;
     } else if (h->split_kind == 3) {
         const void* f = nullptr;
         switch (h->cfg.d) {
@@ -2302,7 +2289,10 @@ static int64_t live_wg_capacity(demcz_handle* h)
         case 3: per_cu = pc_live_blocks_per_cu<TARGET_MVNORMAL, 3>(); break;
         case 4: per_cu = pc_live_blocks_per_cu<TARGET_MVNORMAL, 4>(); break;
         case 5: per_cu = pc_live_blocks_per_cu<TARGET_MVNORMAL, 5>(); break;
+        case 6: per_cu = pc_live_blocks_per_cu<TARGET_MVNORMAL, 6>(); break;
+        case 7: per_cu = pc_live_blocks_per_cu<TARGET_MVNORMAL, 7>(); break;
         case 8: per_cu = pc_live_blocks_per_cu<TARGET_MVNORMAL, 8>(); break;
+        case 9: per_cu = pc_live_blocks_per_cu<TARGET_MVNORMAL, 9>(); break;
         case 10: per_cu = pc_live_blocks_per_cu<TARGET_MVNORMAL, 10>(); break;
         default: per_cu = 0;
         }

@@ -583,6 +583,9 @@ __global__ void logp_kernel(TargetParams tp, int d, const double* X, int64_t ldX
     out[c] = target_logp<TARGET, 0>(tp, d, [&](int j) { return X[c + ldX * j]; });
 }
 
+// ---- the small non-template kernels (archive bookkeeping, R-hat, diagnostics): defined in ONE translation unit, demcz_capi.hip;
+// the units that only instantiate window kernels (demcz_pw_inst_<g>.hip) define DEMCZ_NO_AUX_KERNELS ----
+#ifndef DEMCZ_NO_AUX_KERNELS
 // The part of the archive no row has been appended to yet holds `v` (LIVE launches of the split layout,
 // demcz_kernels_pc.h, recognise an unpublished row by it; nothing below row M ever leaves the device).
 __global__ void fill_u64_kernel(unsigned long long* p, size_t n, unsigned long long v)
@@ -973,5 +976,6 @@ __global__ void selftest_draws_kernel(uint64_t seed, uint64_t chain, uint64_t bl
     normals[2 * i + 1] = z1;
     logu[i] = dm_log(u_open(r1));
 }
+#endif  // DEMCZ_NO_AUX_KERNELS
 
 }  // namespace demcz

@@ -47,12 +47,19 @@ namespace demcz {
 #ifndef PW_WDPP
 #define PW_WDPP 1
 #endif
+// Round 5: every dimension from 6 to 32, MvNormal and the isotropic quadratic (the reference's own scripts run at d = 10, 26, 30:
+// test/test_anneal.jl:7-10, test/example_linreg.jl:9, test/test_anneal_parallel.jl:16) -- the generated DPP texts exist for
+// every one of them (scripts/gen_pw_wdpp.py), the kernel's tables were always written for a general D.  What grows with D: a
+// slot is NDMA = 2..5 KiB (a workgroup's LDS: 40 KB at d = 8, 70 KB at d = 20, 110 KB at d = 32 -- from d = 23 on ONE workgroup
+// fits a CU), a node's candidate is D registers and W ceil(D (D + 1) / 32) more: beyond d = 20 the kernel is compiled for two
+// waves per SIMD (256 registers) instead of three -- it never has more than two there.
+constexpr int pw_min_waves(int D) { return (D <= 20) ? 3 : 2; }
 template <int TARGET, int D, bool LIVE, bool TEMPER, bool MF = false, bool REG = false>
-__global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_kernel_pw(const WindowParams P)
+__global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), pw_min_waves(D)) window_kernel_pw(const WindowParams P)
 {
     static_assert(!REG || (LIVE && PS_R == 5), "regular launches: LIVE, five generations a pass");
     static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "split layout: MvNormal / isotropic targets");
-    static_assert(D >= 6 && D <= 24, "d <= 5: window_kernel_ps");
+    static_assert(D >= 6 && D <= 32, "d <= 5: window_kernel_ps");
     static_assert(!MF || (LIVE && TARGET == TARGET_MVNORMAL && D > 16 && D <= 20 && PS_R == 5), "matrix form: MvNormal, 16 < d <= 20, LIVE");
     constexpr int HW = (D + 1) / 2;                        // 16-byte pieces of an archive row
     constexpr int ZSC = ((D + 7) / 8) * 8;                 // archive row stride in doubles (demcz_create: ZS)
@@ -81,13 +88,13 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     __shared__ __attribute__((aligned(16))) double sdelta[PS_CHAINS][(PS_R + 1) * DP];       // row PS_R: negative zeros
     __shared__ __attribute__((aligned(16))) double ctab[PS_CHAINS][32 * CR];                   // row 0: the current state
     __shared__ __attribute__((aligned(16))) double mul[DP];          // mu, one copy per workgroup
-    constexpr bool WDPP = (PW_WDPP != 0) && !MF && TARGET == TARGET_MVNORMAL && (D == 8 || D == 10 || D == 20);
+    constexpr bool WDPP = (PW_WDPP != 0) && !MF && TARGET == TARGET_MVNORMAL;
     constexpr int NWR = (D * (D + 1) / 2 + 15) / 16;                 // register pairs that hold W, sixteen entries each
     // the pass's increments by lanes, the same way (candidate adds): scripts/gen_pw_wdpp.py, gen_adds
 #ifndef PW_DDPP
 #define PW_DDPP 1
 #endif
-    constexpr bool DDPP = (PW_DDPP != 0) && !MF && PS_R == 5 && (D == 8 || D == 10 || D == 20);
+    constexpr bool DDPP = (PW_DDPP != 0) && !MF && PS_R == 5;
     // per generation of the pass: positions of a 16-lane row that take it in every row with takers, and the register pairs that
     // then hold its D increments (the generator's numbers; checked against each other in the generated text)
     constexpr int DD_KN[5] = {4, 4, 4, 4, 16};
@@ -572,13 +579,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
 #pragma unroll
                 for (int q = 0; q < DD_NQMAX; ++q)
                     if (q < DD_NQ[u]) asm volatile("" : "+v"(Dg[u][q]));
-            if constexpr (D == 20) {
-#include "demcz_pw_ddpp_20.inc"
-            } else if constexpr (D == 10) {
-#include "demcz_pw_ddpp_10.inc"
-            } else {
-#include "demcz_pw_ddpp_8.inc"
-            }
+#include "demcz_pw_ddpp_sel.inc"
         } else {
 #pragma unroll
         for (int j = 0; j < PS_R; ++j) {
@@ -687,13 +688,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
                 // (round 4: W by lanes -- see the top of the file; the alternatives above are what it replaced)
 #pragma unroll
                 for (int r = 0; r < NWR; ++r) asm volatile("" : "+v"(Wr[r]));
-                if constexpr (D == 20) {
-#include "demcz_pw_wdpp_20.inc"
-                } else if constexpr (D == 10) {
-#include "demcz_pw_wdpp_10.inc"
-                } else {
-#include "demcz_pw_wdpp_8.inc"
-                }
+#include "demcz_pw_wdpp_sel.inc"
                 lpp = fma(-0.5, q, P.tp.c0);
             } else if constexpr (TARGET == TARGET_MVNORMAL) {
 #pragma unroll

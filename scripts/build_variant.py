@@ -11,7 +11,5 @@ from demc_jl_amd import _lib
 name, extra = sys.argv[1], sys.argv[2:]
 out = ROOT / "build_ab" / f"{name}.so"
 out.parent.mkdir(exist_ok=True)
-cmd = _lib.build_command(out)
-cmd[1:1] = extra
-subprocess.run(cmd, check=True)
+_lib.build_lib(out, extra=extra)
 print(out)

@@ -25,11 +25,16 @@ SPLIT, SPLIT_WAVE = 100, 164       # DEMCZ_LAYOUT_SPLIT, DEMCZ_LAYOUT_SPLIT_WAVE
 
 
 def auto_split_layout(d, N, K=10):
-    """What lanes_per_chain = 0 selects where a split layout is built (MvNormal, full block): one wave per chain for the
-    smallest populations of d in 2..5, 8, 10, 20 (as many chains as a LIVE launch of it holds: 1024 on MI355X; 2048 at d <= 5
-    with K a multiple of five, where a wave runs two chains), the replicated / cooperating consumers otherwise."""
-    if (2 <= d <= 5 or d in (8, 10, 20)) and N <= 1024:
+    """What lanes_per_chain = 0 selects for MvNormal with one full block: one wave per chain for the smallest populations of every
+    d in 2..32 (as many chains as a LIVE launch of it holds: 1024 on MI355X; 2048 at d <= 5 with K a multiple of five, where a
+    wave runs two chains), the replicated / cooperating consumers otherwise where they are built (d <= 10, d = 20)."""
+    if 2 <= d <= 32 and N <= 1024:
         return SPLIT_WAVE
     if 2 <= d <= 5 and N <= 2048 and K % 5 == 0:
         return SPLIT_WAVE
     return SPLIT
+
+
+def split_built(d):
+    """MvNormal, one full block: dimensions with the eight-lane replicated (d <= 10) or sixteen-lane cooperating (d = 20) consumers."""
+    return 2 <= d <= 10 or d == 20

@@ -61,6 +61,25 @@ def test_wave_per_chain_live_long_run_equals_oracle(demc, oracle, d, G):
     _same(a, ref)
 
 
+@pytest.mark.parametrize("kind,d", [("mvn", 6), ("mvn", 7), ("mvn", 12), ("mvn", 16), ("mvn", 22), ("mvn", 23), ("mvn", 26), ("mvn", 30), ("mvn", 32),
+                                    ("iso", 10), ("iso", 30)])
+def test_wave_per_chain_every_dimension_live_equals_oracle(demc, oracle, kind, d):
+    """Round 5: window_kernel_pw is no longer built for d = 8 / 10 / 20 only.  The reference's own scripts run at d = 10 (iso-quad,
+    test/test_anneal.jl:7-10), 26 (test/example_linreg.jl:9) and 30 (test/test_anneal_parallel.jl:16); README.md:16 says "10-20
+    dimensions".  N = 1024 chains, K = 10, the library's choice of layout: one wave per chain, LIVE launches (from d = 21 on one
+    workgroup per CU), regular and irregular pieces; the isotropic quadratic tempered (the annealer's use of it)."""
+    N, K, seed = 1024, 10, 5200 + d
+    G = 600 if d <= 16 else 400
+    w = demc.workloads.mvnormal_problem(d, N) if kind == "mvn" else demc.workloads.iso_quad_problem(d, N)
+    T = None if kind == "mvn" else np.array([demc.tempbaseline(g, G, 3, 1e-3) for g in range(1, G + 1)])
+    gamma = w["gamma"]
+    a = _hip(demc, w, N, d, K, G, [range(d)], seed, gamma, temperature=T, pieces=[G // 2, 3, G - G // 2 - 3])
+    assert a["lanes"] == SPLIT_WAVE and a["live"] == (True, 0), (a["lanes"], a["live"])
+    assert a["launches"] <= 12, a["launches"]
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], gamma, seed, temperature=T, threads=THREADS)
+    _same(a, ref)
+
+
 @pytest.mark.parametrize("d,N,K,temper", [(20, 1024, 10, False), (20, 200, 5, True), (10, 1024, 15, False), (8, 333, 10, True)])
 def test_wave_per_chain_regular_launches_equal_oracle(demc, oracle, d, N, K, temper):
     """Round 4: LIVE launches that start behind a K boundary, with K and their length multiples of five, take the regular form of

@@ -24,24 +24,26 @@ def test_selftest_draws_bit_exact(demc, oracle):
 
 @pytest.mark.parametrize("lanes", [1, 0, "ml", SPLIT, SPLIT_WAVE])
 @pytest.mark.parametrize("N,d,G", [(4, 5, 200), (100, 5, 57), (1024, 5, 40), (64, 3, 30), (65, 8, 25), (32, 7, 25),
-                                   (13, 2, 31), (77, 4, 33), (50, 10, 27), (41, 20, 23)])
+                                   (13, 2, 31), (77, 4, 33), (50, 10, 27), (41, 20, 23),
+                                   # round 5: no whitelist of dimensions for the wave-per-chain consumer (d = 2..32)
+                                   (45, 6, 33), (40, 9, 27), (37, 12, 26), (70, 16, 24), (33, 21, 22), (36, 23, 22), (29, 26, 21), (64, 30, 23),
+                                   (21, 32, 22)])
 def test_mvnormal_full_block_bit_exact(demc, oracle, N, d, G, lanes):
-    """Every layout: one lane per chain fused (lanes=1), the library's choice (lanes=0: a
-    producer/consumer split for the dimensions it is built for), eight / sixteen lanes per chain, and both
-    consumers of the split asked for by name (eight replicated lanes per chain; one wave per chain)."""
+    """Every layout: one lane per chain fused (lanes=1), the library's choice (lanes=0: one wave per chain at every d in 2..32
+    for populations this small), eight / sixteen lanes per chain and the split's replicated / cooperating consumers where they
+    are built (d <= 10, d = 20), one wave per chain asked for by name."""
+    from helpers import split_built
+    if lanes in ("ml", SPLIT) and not split_built(d):
+        pytest.skip("eight- / sixteen-lane kernels: d <= 10 and d = 20")
     if lanes == "ml":
-        if d == 7:
-            pytest.skip("no multi-lane build for d=7")
         lanes = 16 if d == 20 else 8
-    if (lanes == SPLIT and d == 7) or (lanes == SPLIT_WAVE and not (2 <= d <= 5 or d in (8, 10, 20))):
-        pytest.skip("split layout not built for this d")
     w = demc.workloads.mvnormal_problem(d, N)
     seed = 99 + N
     mc, Z, runner = demc.demcz_sample(w["target"], w["Zinit"], N, w["K"], G, 1, [range(d)], w["eps_scale"], w["gamma"],
                                       verbose=False, seed=seed, lanes_per_chain=lanes, return_runner=True)
     used = runner.engines[0].info()["lanes_per_chain"]
     runner.close()
-    assert used == (1 if d == 7 else (auto_split_layout(d, N) if lanes == 0 else lanes))
+    assert used == (auto_split_layout(d, N) if lanes == 0 else lanes)
     ref = oracle_sample(oracle, w["target"], w["Zinit"], N, w["K"], G, None, w["eps_scale"], w["gamma"], seed)
     assert np.array_equal(mc.chain, ref["chain"])
     assert np.array_equal(mc.log_obj, ref["log_obj"])
@@ -79,7 +81,7 @@ def test_mvnormal_blocks_and_generic_d_bit_exact(demc, oracle, N, d, G, blocks, 
 
 
 @pytest.mark.parametrize("lanes", [1, 0])
-@pytest.mark.parametrize("kind,d,N,G", [("iso", 10, 50, 60), ("iso", 7, 20, 30), ("linreg", 10, 64, 40), ("linreg", 26, 10, 20),
+@pytest.mark.parametrize("kind,d,N,G", [("iso", 10, 50, 60), ("iso", 7, 20, 30), ("iso", 30, 40, 25), ("linreg", 10, 64, 40), ("linreg", 26, 10, 20),
                                         ("linreg", 4, 10, 20), ("linreg", 10, 37, 33), ("linreg", 10, 5, 12)])
 def test_anneal_targets_bit_exact(demc, oracle, kind, d, N, G, lanes):
     """Tempered accept (demcz_anneal.jl:172-178) on the isotropic quadratic and the regression SSE."""
