@@ -156,6 +156,26 @@ def config_rows(demc, seed, device_id):
     return out
 
 
+def d_sweep_rows(demc, seed, device_id, gens=1000):
+    """`configs.d_sweep` (round 5): C2's population (N = 1024, K = 10, one full block) across dimensions, so that the line shows
+    the fast path is not a whitelist of shapes -- the dimensions rounds 2-4 built (5, 8, 10, 20) next to the ones in between and
+    beyond, which the reference's own scripts use (README.md:16 "10-20 dimensions"; test/example_linreg.jl:9: 26;
+    test/test_anneal_parallel.jl:16: 30) -- and the isotropic quadratic of test/test_anneal.jl:7-10 at d = 10 / 30, tempered.
+    Every row: kernel name, events-based launch time, HBM roofline fraction, like the BASELINE configs above."""
+    rows = []
+    try:
+        for d in (5, 6, 7, 8, 10, 12, 16, 20, 26, 30):
+            w = demc.workloads.mvnormal_problem(d, 1024)
+            rows.append(config_row(demc, f"MvNormal d={d}, N=1024", w, 1024, d, 10, [range(d)], seed, device_id, gens=gens))
+        for d in (10, 30):
+            w = demc.workloads.iso_quad_problem(d, 1024)
+            rows.append(config_row(demc, f"isotropic quadratic d={d}, N=1024, tempered T0=3 -> TN=1e-3", w, 1024, d, 10, [range(d)], seed,
+                                   device_id, gens=gens, anneal=True))
+    except Exception as e:          # reporting only
+        rows.append({"error": f"{type(e).__name__}: {e}"[:300]})
+    return rows
+
+
 def cpu_c1(K=10, seed=31953150):
     """BASELINE config C1 as the reference runs it (test/example_normpdf.jl:20-30 plumbing): MvNormal d=5, N=4 chains, 10 000
     generations, ONE core, chains updated in the reference's order (chain ic+1 sees chain ic's fresh archive row inside a
@@ -641,6 +661,7 @@ def main():
                 out["chain_count_sweep"] = f"failed: {e}"
         if world == 1 and not args.no_configs:
             out["configs"] = config_rows(demc, seed, local_rank)
+            out["configs"]["d_sweep"] = d_sweep_rows(demc, seed, local_rank)
         if not args.no_cpu_baseline and world == 1:      # (the contract: rank 0 at N = 1 only)
             try:
                 out["cpu_baseline"] = cpu_baseline(demc.workloads.mvnormal_problem(d, n_loc), n_loc, d, K, seed, 8.0e7, w["Zinit"].shape[0] + N * (G // K))
