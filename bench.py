@@ -176,6 +176,66 @@ def d_sweep_rows(demc, seed, device_id, gens=1000):
     return rows
 
 
+def closure_row(demc, seed, device_id, gens=300):
+    """`configs.closure` (round 5): the reference's defining feature is an ARBITRARY log-density (`logobj`, src/demcz.jl:189,
+    README.md:14).  Behind this ABI that is the host-closure mode: per block-step the device draws and forms the N proposals
+    (demcz_propose), the host evaluates its closure on them, the device takes the N Metropolis decisions (demcz_accept_commit).
+    C2's shape (MvNormal d = 5, N = 1024, K = 10) with a vectorised NumPy closure, two ways:
+      copies     rounds 1-4: propose kernel -> D2H copy -> stream sync | closure | H2D copy -> accept kernel -> stream sync
+      pipelined  round 5 (demcz_closure_buffers): the kernels write / read pinned host memory directly, the host spins on a flag
+                 the propose kernel's last workgroup raises, the commit is only enqueued
+    Per block-step: microseconds inside each of the three calls and inside the closure (host clock), and updates/s."""
+    N, d, K = 1024, 5, 10
+    w = demc.workloads.mvnormal_problem(d, N)
+    M0 = w["Zinit"].shape[0]
+    spec = w["target"].spec()
+    mu, c0 = np.asarray(w["mu"], dtype=np.float64), float(spec["c0"])
+    Wl = np.asarray(spec["W"], dtype=np.float64).reshape(d, d, order="F")
+
+    def closure(X):                       # log N(x; mu, Sigma) for the rows of X, W = chol(Sigma)^-1 (lower)
+        Y = (X - mu) @ Wl.T
+        return c0 - 0.5 * np.einsum("ij,ij->i", Y, Y)
+
+    out = {"workload": f"host-closure mode, C2's shape: MvNormal d={d}, N={N}, K={K}, vectorised NumPy closure", "generations_timed": gens}
+    try:
+        for mode in ("copies", "pipelined"):
+            e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (2 * gens // K + 2), Gcap=2 * gens, blockindex=[range(d)],
+                               eps_scale=w["eps_scale"], seed=seed, target=closure, device_id=device_id)
+            try:
+                X0 = np.asfortranarray(w["Zinit"][-N:])
+                e.set_state(X0, closure(X0), w["Zinit"])
+                bufs = e.closure_buffers() if mode == "pipelined" else None
+                t_prop = t_clo = t_acc = t_end = 0.0
+                t_all = 0.0
+                for g in range(1, 2 * gens + 1):
+                    timed = g > gens
+                    a = time.perf_counter()
+                    Xp = e.propose(g, 0, w["gamma"])
+                    b = time.perf_counter()
+                    if bufs is not None:
+                        bufs[1][:] = closure(Xp)
+                        c = time.perf_counter()
+                        e.accept_commit(None)
+                    else:
+                        lp = closure(Xp)
+                        c = time.perf_counter()
+                        e.accept_commit(lp)
+                    dd = time.perf_counter()
+                    e.end_generation(g)
+                    f = time.perf_counter()
+                    if timed:
+                        t_prop += b - a; t_clo += c - b; t_acc += dd - c; t_end += f - dd; t_all += f - a
+                e.synchronize()
+                out[mode] = {"value": N * gens / t_all, "unit": "chain-updates/s", "us_per_block_step": t_all / gens * 1e6,
+                             "us_propose_call": t_prop / gens * 1e6, "us_closure": t_clo / gens * 1e6,
+                             "us_accept_commit_call": t_acc / gens * 1e6, "us_end_generation_call": t_end / gens * 1e6}
+            finally:
+                e.close()
+    except Exception as ex:          # reporting only
+        out["error"] = f"{type(ex).__name__}: {ex}"[:300]
+    return out
+
+
 def cpu_c1(K=10, seed=31953150):
     """BASELINE config C1 as the reference runs it (test/example_normpdf.jl:20-30 plumbing): MvNormal d=5, N=4 chains, 10 000
     generations, ONE core, chains updated in the reference's order (chain ic+1 sees chain ic's fresh archive row inside a
@@ -662,6 +722,7 @@ def main():
         if world == 1 and not args.no_configs:
             out["configs"] = config_rows(demc, seed, local_rank)
             out["configs"]["d_sweep"] = d_sweep_rows(demc, seed, local_rank)
+            out["configs"]["closure"] = closure_row(demc, seed, local_rank)
         if not args.no_cpu_baseline and world == 1:      # (the contract: rank 0 at N = 1 only)
             try:
                 out["cpu_baseline"] = cpu_baseline(demc.workloads.mvnormal_problem(d, n_loc), n_loc, d, K, seed, 8.0e7, w["Zinit"].shape[0] + N * (G // K))

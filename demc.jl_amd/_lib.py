@@ -45,6 +45,7 @@ SYMBOLS = [
     "demcz_history_stream", "demcz_get_history_view", "demcz_detach_history", "demcz_release_host_buffer", "demcz_get_archive_pinned",
     "demcz_debug_kernel_counts", "demcz_pool_trim", "demcz_debug_kernel_name", "demcz_peer_group", "demcz_get_peer_status", "demcz_peer_export", "demcz_peer_attach",
     "demcz_peer_detach", "demcz_get_peer_ping", "demcz_set_live_rearms", "demcz_get_live_rearms",
+    "demcz_closure_buffers",
 ]
 
 
@@ -148,6 +149,7 @@ def load():
     L.demcz_propose.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_double, _dp]
     L.demcz_accept_commit.argtypes = [C.c_void_p, _dp, _dp]
     L.demcz_end_generation.argtypes = [C.c_void_p, C.c_int64]
+    L.demcz_closure_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.demcz_comm_unique_id.argtypes = [C.c_void_p]
     L.demcz_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     L.demcz_export_current_device.argtypes = [C.c_void_p, C.c_void_p]

@@ -207,6 +207,16 @@ struct demcz_handle {
     double* dlogu = nullptr;
     bool proposal_pending = false;
     bool gen_open = false;
+    // host-closure mode, pipelined (round 5: demcz_closure_buffers).  Proposals and their log-densities live in pinned host memory
+    // the kernels address directly: propose_kernel writes the N x d proposals there (and the device copy the commit needs), the
+    // last workgroup to finish raises a flag word in the same memory, the host spins on the flag -- no D2H copy, no stream
+    // synchronisation; accept_commit_kernel reads the N log-densities straight from host memory and is only ENQUEUED: the next
+    // demcz_propose goes into the stream behind it while it runs.
+    double* hc_X = nullptr;           // pinned, mapped: N x d (ld N)
+    double* hc_lp = nullptr;          // pinned, mapped: N
+    volatile unsigned int* hc_flag = nullptr;   // pinned, mapped: [0] = sequence number of the last proposal that is complete in hc_X
+    unsigned int* hc_count = nullptr; // device: workgroups of the current propose launch that have finished
+    unsigned int hc_seq = 0;
     // split layout: draw records, double-buffered (this launch reads one, its producer half fills the other)
     hipStream_t diag_stream = nullptr;   // demcz_run_checked, monitoring: the checks run here beside the next slab
     hipEvent_t diag_ev = nullptr;
@@ -673,6 +683,10 @@ static void free_all(demcz_handle* h)
     if (h->rhat_side_ev) (void)hipEventDestroy(h->rhat_side_ev);
     if (h->diag_stream) stream_release(h->cfg.device_id, h->diag_stream, !h->comm_dead && hipStreamQuery(h->diag_stream) == hipSuccess);
     if (h->stall_flag) (void)dev_free(h->cfg.device_id, h->stall_flag);
+    if (h->hc_X) (void)hipHostFree(h->hc_X);
+    if (h->hc_lp) (void)hipHostFree(h->hc_lp);
+    if (h->hc_flag) (void)hipHostFree(const_cast<unsigned int*>(h->hc_flag));
+    if (h->hc_count) (void)dev_free(h->cfg.device_id, h->hc_count);
     if (h->xdone) (void)host_free(const_cast<long long*>(h->xdone));
     if (!h->comm_dead) {                 // (a dead handle's communicators were aborted, which frees them)
         if (h->comm_side) (void)ncclCommDestroy(h->comm_side);
@@ -3143,11 +3157,27 @@ extern "C" int32_t demcz_mean_cov(demcz_handle* h, int64_t g_from, int64_t g_to,
 
 // ---- host-closure mode -------------------------------------------------------------------------
 namespace demcz {
-__global__ void propose_kernel(const WindowParams P, int ib, uint64_t blk0, double* Xprop, double* logu)
+// (host_X / done_count / host_flag: the pipelined closure mode, demcz_closure_buffers -- the proposals also go to pinned host memory,
+//  and the last workgroup to finish publishes `seq` in the flag word the host is spinning on)
+__device__ __forceinline__ void propose_done(unsigned int* done_count, unsigned int* host_flag, unsigned int seq)
+{
+    if (!host_flag) return;
+    __threadfence_system();                       // this thread's stores to host memory, before the workgroup reports
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int prev = __hip_atomic_fetch_add(done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1) {
+            __hip_atomic_store(done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (ready for the next launch)
+            __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+__global__ void propose_kernel(const WindowParams P, int ib, uint64_t blk0, double* Xprop, double* logu, double* host_X,
+                               unsigned int* done_count, unsigned int* host_flag, unsigned int seq)
 {
     extern __shared__ double lds[];
     const int64_t c = (int64_t)blockIdx.x * WINDOW_BS + threadIdx.x;
-    if (c >= P.N) return;
+    if (c >= P.N) { propose_done(done_count, host_flag, seq); return; }
     const int tid = threadIdx.x;
     const int d = P.d;
     rng_state st;
@@ -3181,9 +3211,11 @@ __global__ void propose_kernel(const WindowParams P, int ib, uint64_t blk0, doub
             xv = xv + delta;
         }
         Xprop[c + P.N * p] = xv;
+        if (host_X) host_X[c + P.N * p] = xv;
     }
     rng_next(st, r1, r2);
     logu[c] = dm_log(u_open(r1));
+    propose_done(done_count, host_flag, seq);
 }
 
 __global__ void accept_commit_kernel(int64_t N, int d, double* Xcur, double* lpcur, const double* Xprop,
@@ -3217,7 +3249,7 @@ __global__ void end_generation_kernel(int64_t N, int d, const double* Xcur, cons
 
 extern "C" int32_t demcz_propose(demcz_handle* h, int64_t g, int32_t ib, double gamma, double* Xprop)
 {
-    if (!h || !Xprop) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (!h) return DEMCZ_ERR_INVALID_ARGUMENT;
     if (h->cfg.target_kind != DEMCZ_TARGET_HOST_CALLBACK) return fail(h, DEMCZ_ERR_STATE, "demcz_propose: handle was not created with DEMCZ_TARGET_HOST_CALLBACK");
     if (!h->has_state) return fail(h, DEMCZ_ERR_STATE, "demcz_propose: call demcz_set_state first");
     if (g < 1 || ib < 0 || ib >= h->cfg.Nblocks) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_propose: bad generation or block");
@@ -3232,21 +3264,87 @@ extern "C" int32_t demcz_propose(demcz_handle* h, int64_t g, int32_t ib, double 
     P.Z = h->dZ; P.ZS = h->ZS; P.M = h->M; P.Xcur = h->dX; P.N = N; P.chain_id0 = h->cfg.chain_id0; P.d = d;
     P.gamma = gamma; P.seed = h->cfg.seed; P.block_offsets = h->d_block_offsets; P.slot_of = h->d_slot_of; P.eps = h->d_eps;
     const uint64_t blk0 = (uint64_t)(g + h->rng_offset - 1) * (uint64_t)h->S + (uint64_t)off;
-    hipLaunchKernelGGL(propose_kernel, dim3((unsigned)((N + WINDOW_BS - 1) / WINDOW_BS)), dim3(WINDOW_BS),
-                       (size_t)(d + 1) * WINDOW_BS * sizeof(double), h->stream, P, (int)ib, blk0, h->dXprop, h->dlogu);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(Xprop, h->dXprop, (size_t)N * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    SYNCCHK(h, h->stream);
+    if (h->hc_X) {
+        // pipelined: the kernel writes the proposals into pinned host memory itself and raises the flag; the host spins on it
+        const unsigned int seq = ++h->hc_seq;
+        double* hX = nullptr; unsigned int* hF = nullptr;
+        HIPCHK(h, hipHostGetDevicePointer((void**)&hX, h->hc_X, 0));
+        HIPCHK(h, hipHostGetDevicePointer((void**)&hF, const_cast<unsigned int*>(h->hc_flag), 0));
+        hipLaunchKernelGGL(propose_kernel, dim3((unsigned)((N + WINDOW_BS - 1) / WINDOW_BS)), dim3(WINDOW_BS),
+                           (size_t)(d + 1) * WINDOW_BS * sizeof(double), h->stream, P, (int)ib, blk0, h->dXprop, h->dlogu, hX, h->hc_count, hF, seq);
+        HIPCHK(h, hipGetLastError());
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned long long polls = 0; __atomic_load_n(const_cast<unsigned int*>(h->hc_flag), __ATOMIC_ACQUIRE) != seq; ++polls) {
+            if ((polls & 0xffffull) == 0xffffull) {       // (now and then: did the launch fail?  is a sharded peer stalling the stream?)
+                const hipError_t qe = hipStreamQuery(h->stream);
+                if (qe != hipSuccess && qe != hipErrorNotReady) return fail(h, DEMCZ_ERR_HIP, std::string("demcz_propose: ") + hipGetErrorString(qe));
+                if (qe == hipSuccess && __atomic_load_n(const_cast<unsigned int*>(h->hc_flag), __ATOMIC_ACQUIRE) != seq)
+                    return fail(h, DEMCZ_ERR_HIP, "demcz_propose: the propose kernel finished without raising its flag");
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) return fail(h, DEMCZ_ERR_HIP, "demcz_propose: no proposal within 60 s");
+            }
+        }
+        if (Xprop && Xprop != h->hc_X) std::memcpy(Xprop, h->hc_X, (size_t)N * d * sizeof(double));
+    } else {
+        if (!Xprop) return fail(h, DEMCZ_ERR_INVALID_ARGUMENT, "demcz_propose: Xprop is required (or call demcz_closure_buffers first)");
+        hipLaunchKernelGGL(propose_kernel, dim3((unsigned)((N + WINDOW_BS - 1) / WINDOW_BS)), dim3(WINDOW_BS),
+                           (size_t)(d + 1) * WINDOW_BS * sizeof(double), h->stream, P, (int)ib, blk0, h->dXprop, h->dlogu,
+                           (double*)nullptr, (unsigned int*)nullptr, (unsigned int*)nullptr, 0u);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(Xprop, h->dXprop, (size_t)N * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        SYNCCHK(h, h->stream);
+    }
     h->proposal_pending = true;
+    return DEMCZ_OK;
+}
+
+// Pinned host buffers for the closure mode: *Xprop (N x d column-major, ld N) receives every proposal of demcz_propose, *logp (N) is
+// where the caller leaves the closure's values for demcz_accept_commit -- the kernels read and write them in place (see
+// demcz_handle::hc_X).  The buffers belong to the handle and live as long as it does.
+extern "C" int32_t demcz_closure_buffers(demcz_handle* h, double** Xprop, double** logp)
+{
+    if (!h || !Xprop || !logp) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (h->cfg.target_kind != DEMCZ_TARGET_HOST_CALLBACK) return fail(h, DEMCZ_ERR_STATE, "demcz_closure_buffers: handle was not created with DEMCZ_TARGET_HOST_CALLBACK");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    if (!h->hc_X) {
+        const size_t N = (size_t)h->cfg.N, d = (size_t)h->cfg.d;
+        double* x = nullptr; double* l = nullptr; unsigned int* f = nullptr;
+        if (hipHostMalloc((void**)&x, N * d * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+            hipHostMalloc((void**)&l, N * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+            hipHostMalloc((void**)&f, 64, hipHostMallocMapped) != hipSuccess) {
+            (void)hipGetLastError();
+            if (x) (void)hipHostFree(x);
+            if (l) (void)hipHostFree(l);
+            if (f) (void)hipHostFree(f);
+            return fail(h, DEMCZ_ERR_HIP, "demcz_closure_buffers: pinned allocation failed");
+        }
+        std::memset(x, 0, N * d * sizeof(double)); std::memset(l, 0, N * sizeof(double)); std::memset(f, 0, 64);
+        HIPCHK(h, dev_malloc(h->cfg.device_id, (void**)&h->hc_count, sizeof(unsigned int)));
+        HIPCHK(h, hipMemsetAsync(h->hc_count, 0, sizeof(unsigned int), h->stream));
+        h->hc_X = x; h->hc_lp = l; h->hc_flag = f;
+    }
+    *Xprop = h->hc_X;
+    *logp = h->hc_lp;
     return DEMCZ_OK;
 }
 
 extern "C" int32_t demcz_accept_commit(demcz_handle* h, const double* logp_prop, const double* temperature)
 {
-    if (!h || !logp_prop) return DEMCZ_ERR_INVALID_ARGUMENT;
+    if (!h || (!logp_prop && !h->hc_lp)) return DEMCZ_ERR_INVALID_ARGUMENT;
     if (!h->proposal_pending) return fail(h, DEMCZ_ERR_STATE, "demcz_accept_commit: no pending proposal");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     const int64_t N = h->cfg.N;
+    if (h->hc_lp) {
+        // pipelined: the kernel reads the log-densities from pinned host memory; nothing is waited for -- the next demcz_propose is
+        // enqueued behind this kernel, and the caller does not write the buffer again before that proposal has come back
+        if (logp_prop && logp_prop != h->hc_lp) std::memcpy(h->hc_lp, logp_prop, (size_t)N * sizeof(double));
+        double* lpd = nullptr;
+        HIPCHK(h, hipHostGetDevicePointer((void**)&lpd, h->hc_lp, 0));
+        hipLaunchKernelGGL(accept_commit_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, N, h->cfg.d, h->dX,
+                           h->dlp, h->dXprop, (const double*)lpd, h->dlogu, temperature ? 1 : 0, temperature ? *temperature : 1.0);
+        HIPCHK(h, hipGetLastError());
+        h->proposal_pending = false;
+        return DEMCZ_OK;
+    }
     int32_t rc = ensure_scratch(h, N);
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_scratch, logp_prop, (size_t)N * sizeof(double), hipMemcpyHostToDevice, h->stream));

@@ -304,15 +304,37 @@ class HipEngine:
         return mean, cov
 
     # -- host-closure mode ----------------------------------------------------------------------
+    def closure_buffers(self):
+        """demcz_closure_buffers: (Xprop, logp) NumPy views of the handle's pinned host buffers -- N x d column-major and N.
+        After this call propose() returns a view of Xprop (no copy, no stream synchronisation) and accept_commit() with no
+        argument commits whatever has been written into logp."""
+        if getattr(self, "_hc", None) is None:
+            px, pl = C.c_void_p(), C.c_void_p()
+            self._chk(self._L.demcz_closure_buffers(self._h, C.byref(px), C.byref(pl)))
+            bx = (C.c_double * (self.N * self.d)).from_address(px.value)
+            bl = (C.c_double * self.N).from_address(pl.value)
+            self._hc = (np.ctypeslib.as_array(bx).reshape((self.N, self.d), order="F"), np.ctypeslib.as_array(bl))
+        return self._hc
+
     def propose(self, g, ib, gamma):
+        if getattr(self, "_hc", None) is not None:
+            self._chk(self._L.demcz_propose(self._h, int(g), int(ib), float(gamma), None))
+            return self._hc[0]
         Xp = np.empty((self.N, self.d), order="F")
         self._chk(self._L.demcz_propose(self._h, int(g), int(ib), float(gamma), _lib.ptr(Xp)))
         return Xp
 
-    def accept_commit(self, logp_prop, temperature=None):
-        lp = _lib.f64(logp_prop)
+    def accept_commit(self, logp_prop=None, temperature=None):
         t = C.byref(C.c_double(float(temperature))) if temperature is not None else None
-        self._chk(self._L.demcz_accept_commit(self._h, _lib.ptr(lp), C.cast(t, _lib._dp) if t is not None else None))
+        tp = C.cast(t, _lib._dp) if t is not None else None
+        hc = getattr(self, "_hc", None)
+        if logp_prop is None or (hc is not None and logp_prop is hc[1]):
+            if hc is None:
+                raise ValueError("accept_commit() without values needs closure_buffers() first")
+            self._chk(self._L.demcz_accept_commit(self._h, None, tp))
+            return
+        lp = _lib.f64(logp_prop)
+        self._chk(self._L.demcz_accept_commit(self._h, _lib.ptr(lp), tp))
 
     def end_generation(self, g):
         self._chk(self._L.demcz_end_generation(self._h, int(g)))

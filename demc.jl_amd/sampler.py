@@ -51,6 +51,11 @@ class MC:
     # checkpoint, which keeps only the last generation, records the true count here so that `prevrun=` resumes the
     # streams where they stopped instead of replaying them.
     rng_generations: Optional[int] = None
+    # Philox blocks one generation of the run that made this result consumed per chain (it follows from its blocks: a block-step
+    # of b parameters takes 1 + ceil(b / 2) + 1, or 3 for b = 1).  A `prevrun` resumed with OTHER blocks starts its streams at the
+    # first generation boundary of the new size behind everything the previous run drew -- never inside it.  None: unknown (a
+    # result made by hand, an old checkpoint): taken to be the new run's own.
+    rng_blocks_per_generation: Optional[int] = None
 
     @property
     def generations_drawn(self):
@@ -385,10 +390,24 @@ def make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp,
     return _Runner(engines, sh, K, N, d, append_lag=append_lag)
 
 
-def _generations_drawn(prevrun):
-    """Generations the chains' random streams have consumed by the end of `prevrun` (see MC.rng_generations)."""
+def blocks_per_generation(blockindex):
+    """Philox blocks a chain consumes per generation: per block-step 1 (row indices) + ceil(nn / 2) (normal
+    pairs; nn = b, or 1 for b = 1: demcz.jl:183-186) + 1 (the accept uniform)."""
+    return sum(1 + ((1 if len(b) == 1 else len(b)) + 1) // 2 + 1 for b in blockindex)
+
+
+def _generations_drawn(prevrun, blockindex=None):
+    """Where a run that resumes `prevrun` starts its chains' random streams, in generations of ITS OWN size: the generations
+    `prevrun` consumed (MC.rng_generations) -- scaled up to the next whole generation when the previous run's generations were
+    of another size (other blocks), so that no draw is ever used twice."""
     n = getattr(prevrun, "rng_generations", None)
-    return int(prevrun.chain.shape[2]) if n is None else int(n)
+    n = int(prevrun.chain.shape[2]) if n is None else int(n)
+    s_prev = getattr(prevrun, "rng_blocks_per_generation", None)
+    if blockindex is not None and s_prev:
+        s_new = blocks_per_generation([list(b) for b in blockindex])
+        if s_new != int(s_prev):
+            n = -(-n * int(s_prev) // s_new)
+    return n
 
 
 def initial_state(logobj, Zmat, N, Ngeneration, K, prevrun, init):
@@ -408,7 +427,8 @@ def initial_state(logobj, Zmat, N, Ngeneration, K, prevrun, init):
             raise ValueError("init must be 'last_rows' or 'reference_zeros'")
         logp = None
         if not is_device_target(logobj):
-            logp = np.array([float(logobj(X[i, :].copy())) for i in range(N)])      # demcz.jl:17
+            logp = (np.asarray(logobj(X), dtype=np.float64).reshape(-1) if getattr(logobj, "batched", False)
+                    else np.array([float(logobj(X[i, :].copy())) for i in range(N)]))      # demcz.jl:17
         return X, logp
     X = np.array(prevrun.chain[:, :, -1], dtype=np.float64, order="F")             # demcz.jl:20
     logp = np.array(prevrun.log_objcurrent, dtype=np.float64).reshape(-1)          # demcz.jl:21
@@ -421,12 +441,27 @@ def _run_generations(runner, logobj, g_from, g_to, gamma, Nblocks, temperature=N
         runner.run(g_from, g_to, gamma, temperature)
         return
     eng = runner.engines[0]
+    # The proposals arrive in, and the closure's values leave from, pinned host buffers the kernels address directly (round 5:
+    # demcz_closure_buffers) -- no copies, no stream synchronisation per block-step.  The reference's closure takes ONE parameter
+    # vector (demcz.jl:189); a closure that declares `batched = True` is handed the whole N x d matrix of a block-step's
+    # proposals and returns N values -- one call into NumPy instead of N.
+    bufs = eng.closure_buffers() if hasattr(eng, "closure_buffers") else None
+    batched = bool(getattr(logobj, "batched", False))
     for g in range(g_from, g_to + 1):
         T = None if temperature is None else float(temperature[g - g_from])
         for ib in range(Nblocks):
             Xp = eng.propose(g, ib, gamma)
-            lp = np.array([float(logobj(Xp[i, :].copy())) for i in range(Xp.shape[0])])   # demcz.jl:189
-            eng.accept_commit(lp, T)
+            if bufs is not None:
+                if batched:
+                    bufs[1][:] = logobj(Xp)
+                else:
+                    for i in range(Xp.shape[0]):
+                        bufs[1][i] = float(logobj(Xp[i, :].copy()))                       # demcz.jl:189
+                eng.accept_commit(None, T)
+            else:
+                lp = (np.asarray(logobj(Xp), dtype=np.float64) if batched
+                      else np.array([float(logobj(Xp[i, :].copy())) for i in range(Xp.shape[0])]))
+                eng.accept_commit(lp, T)
         eng.end_generation(g)
 
 
@@ -447,7 +482,7 @@ def _warn_live_redos(runner):
             return
 
 
-def _finish(runner, prevrun, G, padded_Z, Mcap, rng_offset=0):
+def _finish(runner, prevrun, G, padded_Z, Mcap, rng_offset=0, blockindex=None):
     _warn_live_redos(runner)
     X, lp, Z, M = runner.state()               # (first: it only needs the compute stream; the history copies are still leaving)
     chain, lobj = runner.history(1, G, take=True)
@@ -458,7 +493,8 @@ def _finish(runner, prevrun, G, padded_Z, Mcap, rng_offset=0):
     if prevrun is not None:                                                          # demcz.jl:58-59
         chain = np.asfortranarray(np.concatenate([prevrun.chain, chain], axis=2))
         lobj = np.asfortranarray(np.concatenate([prevrun.log_obj, lobj], axis=1))
-    return MC(chain, lobj, X, lp, rng_generations=int(rng_offset) + int(G)), Z
+    spg = blocks_per_generation([list(b) for b in blockindex]) if blockindex is not None else None
+    return MC(chain, lobj, X, lp, rng_generations=int(rng_offset) + int(G), rng_blocks_per_generation=spg), Z
 
 
 def print_status(runner, ig, printlast=500):
@@ -508,7 +544,7 @@ def demcz_sample(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
     autostop = _sym(autostop)
     X, logp = initial_state(logobj, Zmat, N, Ngeneration, K, prevrun, init)
     if rng_offset is None:       # a resumed run continues the chains' random streams where prevrun stopped
-        rng_offset = 0 if prevrun is None else _generations_drawn(prevrun)
+        rng_offset = 0 if prevrun is None else _generations_drawn(prevrun, blockindex)
     runner = make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp, seed=seed,
                           sharding=sharding, device_id=device_id, engine_factory=engine_factory,
                           lanes_per_chain=lanes_per_chain, stream=stream, rng_offset=rng_offset, append_lag=append_lag)
@@ -528,7 +564,7 @@ def demcz_sample(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
                                     np.max(runner.rhat(ig - autostop_every + 1, ig)) < autostop_Rhat):
                 if runner.accept_ratio_mean(ig - autostop_every + 1, ig) < 0.1:       # demcz.jl:42,44-46
                     print("Warning: accept ratio below 10% on average")
-                res = _finish(runner, prevrun, ig, padded_Z, Mcap, rng_offset)                  # demcz.jl:47-52
+                res = _finish(runner, prevrun, ig, padded_Z, Mcap, rng_offset, blockindex)                  # demcz.jl:47-52
                 return (res + (runner,)) if return_runner else res
         while ig < Ngeneration:                                                     # demcz.jl:30
             stops = [Ngeneration]
@@ -547,9 +583,9 @@ def demcz_sample(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
                     # demcz.jl:42,44-46 (intent: per-chain ratio over log_obj[:, window])
                     if runner.accept_ratio_mean(ig - autostop_every + 1, ig) < 0.1:
                         print("Warning: accept ratio below 10% on average")
-                    res = _finish(runner, prevrun, ig, padded_Z, Mcap, rng_offset)              # demcz.jl:47-52
+                    res = _finish(runner, prevrun, ig, padded_Z, Mcap, rng_offset, blockindex)              # demcz.jl:47-52
                     return (res + (runner,)) if return_runner else res
-        res = _finish(runner, prevrun, Ngeneration, padded_Z, Mcap, rng_offset)                 # demcz.jl:58-62
+        res = _finish(runner, prevrun, Ngeneration, padded_Z, Mcap, rng_offset, blockindex)                 # demcz.jl:58-62
         return (res + (runner,)) if return_runner else res
     finally:
         if not return_runner:
@@ -584,7 +620,7 @@ def demcz_anneal(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
         eps_scale = 1e-4 * np.ones(d)
     X, logp = initial_state(logobj, Zmat, N, Ngeneration, K, prevrun, init)
     if rng_offset is None:
-        rng_offset = 0 if prevrun is None else _generations_drawn(prevrun)
+        rng_offset = 0 if prevrun is None else _generations_drawn(prevrun, blockindex)
     runner = make_runner(logobj, Zmat, N, K, Ngeneration, blockindex, eps_scale, X, logp, seed=seed,
                           sharding=sharding, device_id=device_id, engine_factory=engine_factory,
                           lanes_per_chain=lanes_per_chain, stream=stream, rng_offset=rng_offset, append_lag=append_lag)
@@ -622,6 +658,6 @@ def demcz_anneal(logobj, Zmat, N=4, K=10, Ngeneration=5000, Nblocks=1, blockinde
                     γ = max(adapt["minγ"], γ * 0.5)
                 elif accept_ratio > 0.5:
                     γ = min(adapt["maxγ"], γ * 1.5)
-        return _finish(runner, prevrun, Ngeneration, padded_Z, Mcap, rng_offset)                # demcz_anneal.jl:60-64
+        return _finish(runner, prevrun, Ngeneration, padded_Z, Mcap, rng_offset, blockindex)                # demcz_anneal.jl:60-64
     finally:
         runner.close()

@@ -91,7 +91,8 @@ def save_checkpoint(path, mc: MC, Z, generations_done=None, seed=_NO_SEED, opts=
     if generations_done is None:
         generations_done = mc.generations_drawn
     np.savez_compressed(path, Xcurrent=mc.Xcurrent, log_objcurrent=mc.log_objcurrent, last_chain=mc.chain[:, :, -1:],
-                        last_log_obj=mc.log_obj[:, -1:], Z=Z, generations_done=int(generations_done), seed=int(seed))
+                        last_log_obj=mc.log_obj[:, -1:], Z=Z, generations_done=int(generations_done), seed=int(seed),
+                        blocks_per_generation=int(getattr(mc, "rng_blocks_per_generation", None) or 0))
 
 
 def load_checkpoint(path):
@@ -100,5 +101,6 @@ def load_checkpoint(path):
     ``generations_done`` (MC.rng_generations), so the resumed run draws what an uninterrupted one would."""
     f = np.load(path)
     prev = MC(np.asfortranarray(f["last_chain"]), np.asfortranarray(f["last_log_obj"]), np.asfortranarray(f["Xcurrent"]),
-              np.array(f["log_objcurrent"]), rng_generations=int(f["generations_done"]))
+              np.array(f["log_objcurrent"]), rng_generations=int(f["generations_done"]),
+              rng_blocks_per_generation=(int(f["blocks_per_generation"]) or None) if "blocks_per_generation" in f else None)
     return prev, np.asfortranarray(f["Z"]), int(f["generations_done"]), int(f["seed"])

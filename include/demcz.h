@@ -94,7 +94,8 @@ typedef struct demcz_config {
                                      lanes run the chains, and on one GPU a launch runs through many
                                      K boundaries (small N); DEMCZ_LAYOUT_SPLIT_WAVE = the same with
                                      one wavefront per chain that resolves five generations per pass
-                                     (smallest N; MvNormal, d = 2..5, 8, 10, 20).  Results are bit-identical. */
+                                     (smallest N; MvNormal at every d in 2..32, the isotropic quadratic
+                                     at d in 6..32).  Results are bit-identical. */
     int32_t reserved0;
 } demcz_config;
 
@@ -207,6 +208,14 @@ int32_t demcz_mean_cov(demcz_handle* h, int64_t g_from, int64_t g_to, double* me
  * closure; demcz_accept_commit applies demcz.jl:190-194 (tempered if temperature != NULL).
  * demcz_end_generation performs runchain!'s bookkeeping demcz.jl:84-91. */
 int32_t demcz_propose(demcz_handle* h, int64_t g, int32_t ib, double gamma, double* Xprop);
+/* The same round trip without its two copies and its two stream synchronisations (round 5).  demcz_closure_buffers hands out pinned
+ * host buffers of the handle -- *Xprop: N x d (ld N), *logp: N -- that the kernels address directly: demcz_propose(h, g, ib, gamma,
+ * NULL) returns as soon as the propose kernel has written the proposals INTO *Xprop (its last workgroup raises a flag word the host
+ * spins on: no copy, no hipStreamSynchronize); the caller evaluates its closure on *Xprop, leaves the values in *logp and calls
+ * demcz_accept_commit(h, NULL, temperature), which only ENQUEUES the commit (the kernel reads *logp from host memory) -- the next
+ * demcz_propose goes into the stream behind it.  Do not write *logp between demcz_accept_commit and the return of the next
+ * demcz_propose.  Own pointers may still be passed to either call: they are copied from / into the pinned buffers. */
+int32_t demcz_closure_buffers(demcz_handle* h, double** Xprop, double** logp);
 int32_t demcz_accept_commit(demcz_handle* h, const double* logp_prop, const double* temperature);
 int32_t demcz_end_generation(demcz_handle* h, int64_t g);
 

@@ -271,6 +271,38 @@ def test_bench_under_torchrun_single_rank(tmp_path):
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
 
 
+@pytest.mark.parametrize("first,second", [(None, "4x5"), ("4x5", None), (None, "10-3-7")])
+def test_prevrun_carried_into_a_run_with_other_blocks_equals_oracle(demc, oracle, first, second):
+    """demcz.jl:18-22: a `prevrun` hands X AND log_objcurrent to the next run.  The MvNormal sums are cut at the run's block
+    boundaries, so log-densities made under Nblocks = 1 are not, to the last bit, what a run with four
+    blocks would compute at the same points (tests/test_oracle_targets.py: within 8 ulp) -- and the next run must still start
+    from the CARRIED values, as the reference does, not from its own re-evaluation: its first accept tests compare a grouped
+    proposal with an ungrouped current value.  The block-update kernel with the incremental quadratic form (window_kernel_mlb,
+    QB = 5) keeps per-chain partial sums: they must come from X while log p comes from the caller.  HIP path = oracle doing the
+    same, bit for bit, in both directions and for unequal blocks (the full-evaluation form)."""
+    d, N, K, G1, G2, seed = 20, 256, 10, 60, 70, 77
+    layouts = {None: None, "4x5": [list(range(0, 5)), list(range(5, 10)), list(range(10, 15)), list(range(15, 20))],
+               "10-3-7": [list(range(0, 10)), list(range(10, 13)), list(range(13, 20))]}
+    b1, b2 = layouts[first], layouts[second]
+    w = demc.workloads.mvnormal_problem(d, N)
+    bl = lambda b: b or [range(d)]
+    from demc_jl_amd.sampler import blocks_per_generation
+    S1, S2 = blocks_per_generation(bl(b1)), blocks_per_generation(bl(b2))
+    assert S1 != S2       # (generations of different size: the resumed streams start behind everything run 1 drew, never inside it)
+    mc1, Z1 = demc.demcz_sample(w["target"], w["Zinit"], N, K, G1, len(bl(b1)), bl(b1), w["eps_scale"], w["gamma"], verbose=False, seed=seed)
+    mc2, Z2 = demc.demcz_sample(w["target"], Z1, N, K, G2, len(bl(b2)), bl(b2), w["eps_scale"], w["gamma"], verbose=False, seed=seed,
+                                prevrun=mc1)
+    r1 = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G1, b1, w["eps_scale"], w["gamma"], seed)
+    assert np.array_equal(mc1.chain, r1["chain"]) and np.array_equal(mc1.log_objcurrent, r1["logp"]) and np.array_equal(Z1, r1["Z"])
+    # the second run: state and log-densities carried (NOT recomputed under the new blocks), streams advanced by G1 generations
+    r2 = oracle_sample(oracle, w["target"], r1["Z"], N, K, G2, b2, w["eps_scale"], w["gamma"], seed, X0=r1["X"], lp0=r1["logp"],
+                       rng_offset=-(-G1 * S1 // S2))
+    assert np.array_equal(mc2.chain[:, :, G1:], r2["chain"]), "the resumed run differs from the oracle's"
+    assert np.array_equal(mc2.log_obj[:, G1:], r2["log_obj"]) and np.array_equal(Z2, r2["Z"])
+    own = oracle.logp(r2["prob"], r1["X"])
+    assert not np.array_equal(own, r1["logp"]), "the case must exercise carried values that differ from the run's own evaluation"
+
+
 def test_utils_mirror_reference_postprocessing(demc, oracle, tmp_path):
     """The post-processing of test/example_normpdf.jl:35-51 with the reference's function names,
     reduced on the GPU from host arrays; plus resume (prevrun) and the checkpoint file."""
@@ -684,6 +716,67 @@ def test_host_closure_path_equals_oracle(demc, oracle, tempered):
     ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, blocks, w["eps_scale"], w["gamma"], seed, temperature=T)
     assert np.array_equal(mc.chain, ref["chain"]) and np.array_equal(mc.log_obj, ref["log_obj"])
     assert np.array_equal(mc.Xcurrent, ref["X"]) and np.array_equal(Z, ref["Z"])
+
+
+@pytest.mark.parametrize("mode", ["copies", "pinned", "pinned-own-pointers"])
+def test_host_closure_round_trips_equal_oracle(demc, oracle, mode):
+    """The three ways through demcz_propose / demcz_accept_commit: the copying calls of rounds 1-4, the pinned buffers the kernels
+    address directly (round 5: demcz_closure_buffers -- no copies, the host spins on the propose kernel's flag, the commit is only
+    enqueued), and the pinned buffers with the caller's own arrays passed all the same.  A batched closure (one call per
+    block-step), tempered, blocks of unequal length; against the oracle, bit for bit."""
+    d, N, G, K, seed = 6, 300, 40, 5, 11
+    w = demc.workloads.mvnormal_problem(d, N)
+    blocks = [[0, 1], [2], [5, 3, 4]]
+    prob = oracle.Problem(N, d, K, 10, w["eps_scale"], 0, blocks=blocks, target=w["target"].spec())
+    closure = lambda X: oracle.logp(prob, np.asarray(X))
+    T = _temps_with_zeros(G)
+    M0 = w["Zinit"].shape[0]
+    e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K + 1), Gcap=G, blockindex=blocks, eps_scale=w["eps_scale"], seed=seed,
+                       target=closure)
+    X0 = np.asfortranarray(w["Zinit"][-N:])
+    e.set_state(X0, closure(X0), w["Zinit"])
+    if mode != "copies":
+        bx, bl = e.closure_buffers()
+    for g in range(1, G + 1):
+        for ib in range(len(blocks)):
+            if mode == "pinned":
+                Xp = e.propose(g, ib, w["gamma"])
+                assert Xp is bx
+                bl[:] = closure(Xp)
+                e.accept_commit(None, float(T[g - 1]))
+            elif mode == "copies":
+                Xp = e.propose(g, ib, w["gamma"])
+                e.accept_commit(closure(Xp), float(T[g - 1]))
+            else:
+                own = np.empty((N, d), order="F")
+                e._chk(e._L.demcz_propose(e._h, g, ib, float(w["gamma"]), own.ctypes.data_as(demc._lib._dp)))
+                assert np.array_equal(own, bx)
+                e.accept_commit(closure(own).copy(), float(T[g - 1]))
+        e.end_generation(g)
+    ch, lo = e.get_history(1, G)
+    X, lp, Z, M = e.get_state()
+    e.close()
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, blocks, w["eps_scale"], w["gamma"], seed, temperature=T)
+    assert np.array_equal(ch, ref["chain"]) and np.array_equal(lo, ref["log_obj"])
+    assert np.array_equal(X, ref["X"]) and np.array_equal(lp, ref["logp"]) and np.array_equal(Z, ref["Z"])
+
+
+def test_batched_closure_through_the_sampler_surface(demc, oracle):
+    """demcz_sample with a closure that declares `batched = True`: one call per block-step with the N x d proposals."""
+    d, N, G, K, seed = 5, 128, 30, 10, 3
+    w = demc.workloads.mvnormal_problem(d, N)
+    prob = oracle.Problem(N, d, K, 10, w["eps_scale"], 0, target=w["target"].spec())
+    calls = []
+
+    def closure(X):
+        X = np.asarray(X)
+        calls.append(X.shape)
+        return oracle.logp(prob, X if X.ndim == 2 else X[None, :])
+    closure.batched = True
+    mc, Z = demc.demcz_sample(closure, w["Zinit"], N, K, G, 1, [range(d)], w["eps_scale"], w["gamma"], verbose=False, seed=seed)
+    assert calls.count((N, d)) >= G
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed)
+    assert np.array_equal(mc.chain, ref["chain"]) and np.array_equal(Z, ref["Z"])
 
 
 def test_streamed_history_equals_copied_history(demc, oracle):

@@ -91,3 +91,33 @@ def test_mvnormal_sums_stay_in_one_group_otherwise(oracle, demc, blocks):
     a = oracle.logp(oracle.Problem(8, d, 10, 100, w["eps_scale"], 1, blocks=blocks, target=w["target"].spec()), X)
     b = oracle.logp(oracle.Problem(8, d, 10, 100, w["eps_scale"], 1, target=w["target"].spec()), X)
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("d,blocks", [(6, [[0], [1, 2], [5, 3, 4]]), (6, [[0, 1, 2], [3, 4, 5]]),
+                                      (20, [list(range(0, 5)), list(range(5, 10)), list(range(10, 15)), list(range(15, 20))]),
+                                      (20, [list(range(0, 10)), list(range(10, 13)), list(range(13, 20))])])
+def test_grouped_mvnormal_order_stays_within_ulps_of_the_ungrouped_one(oracle, d, blocks):
+    """when a run's blocks are consecutive index ranges, the MvNormal quadratic form is summed group by group
+    (oracle/demcz_oracle.c: mvn_groups), so the same point x gets different LAST BITS under Nblocks = 1 and Nblocks = 4 -- the
+    reference has no canonical order for a sum of d products (Distributions / PDMats: not under /root/reference).  How far apart:
+    at most 8 units in the last place of the larger operand of the final fma, max(|c0|, q/2) -- measured 6 over 3 x 10^5 points
+    from 0.01 to 10 standard scales away from the mean (relative to log p itself the figure is unbounded where c0 and q/2 cancel).
+    What that means for a caller: a `prevrun` / a host closure built for other blocks carries log-densities that differ from this
+    run's own evaluation in the 15th-16th significant digit -- the size of the accept test's own rounding, not of anything a
+    Metropolis decision turns on -- and tests/test_gpu_parity.py checks that the HIP path and the oracle treat such carried values
+    identically."""
+    import demc_jl_amd as demc
+    w = demc.workloads.mvnormal_problem(d, 64)
+    one = oracle.Problem(64, d, 10, 100, w["eps_scale"], 1, target=w["target"].spec())
+    grp = oracle.Problem(64, d, 10, 100, w["eps_scale"], 1, blocks=blocks, target=w["target"].spec())
+    c0 = float(oracle.logp(one, w["mu"][None, :])[0])
+    rng = np.random.default_rng(5)
+    worst, differing = 0.0, 0
+    for scale in (0.01, 0.03, 0.1, 0.3, 1.0, 10.0):
+        X = w["mu"] + scale * rng.standard_normal((50000, d))
+        a, b = oracle.logp(one, X), oracle.logp(grp, X)
+        mag = np.maximum(abs(c0), np.abs(c0 - a))
+        worst = max(worst, float((np.abs(a - b) / np.spacing(mag)).max()))
+        differing += int(np.count_nonzero(a != b))
+    assert differing > 0, "the two orders are different arithmetic: some points must differ in their last bits"
+    assert worst <= 8.0, worst
