@@ -596,21 +596,28 @@ def main():
                 if res["gens_to_rhat"] is None and mx < thr:
                     res["gens_to_rhat"] = gchk
 
-        def fence(drain_library=True):
+        stamps = {}
+
+        def fence(drain_library=True, name=None):
             if drain_library:
                 runner.synchronize()
             torch.cuda.synchronize()          # (the whole device: the library's streams included)
+            if name:
+                stamps[name + "_arrive"] = time.perf_counter()      # (CLOCK_MONOTONIC: one clock for all processes of the node)
             if dist is not None:
                 dist.barrier()
                 torch.cuda.synchronize()
+            if name:
+                stamps[name + "_leave"] = time.perf_counter()
 
         note(advance(1, W * every, False), 1)
         eng.set_kernel_timing(True)
-        fence()
+        fence(name="pre")
         # the timed region holds the S steps and nothing else: one library call that returns when its last slab's statistic is on
         # the host, and the fence.  Reading the events out, bookkeeping in Python: after it.
         t0 = time.perf_counter()
         trace = advance(W * every + 1, G, True)
+        stamps["timed_done"] = time.perf_counter()
         fence(drain_library=False)            # (demcz_run_checked returned with the last slab's statistic on the host)
         dt = time.perf_counter() - t0
         note(trace, W * every + 1)
@@ -634,6 +641,14 @@ def main():
         res["peer"] = eng.peer_status()
         res["kernel"] = eng.kernel_name()
         res["kernel_counts"] = eng.kernel_counts()
+        # what a SCALE line needs to explain itself (round 5): per rank, did the in-launch hand-off hold (redos), did the handle go
+        # LIVE again (re-arms), what demcz_comm_init's first-contact check saw, when the rank reached the rendezvous in front of
+        # the timed region and how long its own timed call took
+        res["rank_diag"] = {"rank": rank, "live_launches": bool(res["live_on"]), "live_redos": int(res["live_redos"]),
+                            "live_rearms": list(eng.live_rearms()) if hasattr(eng, "live_rearms") else None,
+                            "peer_status": list(res["peer"]), "peer_ping": list(eng.peer_ping()) if hasattr(eng, "peer_ping") else None,
+                            "window_launches_timed": int(launches), "rendezvous_arrive_s": stamps.get("pre_arrive"),
+                            "rendezvous_leave_s": stamps.get("pre_leave"), "own_timed_call_ms": (stamps["timed_done"] - t0) * 1e3}
         runner.close()        # (frees the device's LIVE slot for the next measurement / the sweep's handles)
         return res
 
@@ -652,6 +667,19 @@ def main():
             print(json.dumps({"error": "DEMCZ_ERR_COMM", "rank": rank, "detail": str(e)}), file=sys.stderr, flush=True)
             os._exit(3)
         raise
+    rank_rows, skew = [m["rank_diag"]], None
+    if dist is not None:
+        rank_rows = [None] * world
+        dist.all_gather_object(rank_rows, m["rank_diag"])
+        arr = [r["rendezvous_arrive_s"] for r in rank_rows if r and r.get("rendezvous_arrive_s") is not None]
+        lea = [r["rendezvous_leave_s"] for r in rank_rows if r and r.get("rendezvous_leave_s") is not None]
+        if arr and lea:
+            skew = {"arrival_spread_us": (max(arr) - min(arr)) * 1e6, "release_spread_us": (max(lea) - min(lea)) * 1e6,
+                    "what": "spread over the ranks of when each reached / left the barrier in front of the timed region (host clock, one node): "
+                            "what the ranks' first launches start apart by -- the in-launch hand-off tolerates ~0.1-0.3 s (its poll limit)"}
+        for r in rank_rows:
+            if r:
+                r.pop("rendezvous_arrive_s", None); r.pop("rendezvous_leave_s", None)
     dt, ev_ms, launches, lanes = m["dt"], m["ev_ms"], m["launches"], m["lanes"]
     gens_to_rhat, rhat_trace, acc, live_on, live_redos = m["gens_to_rhat"], m["rhat_trace"], m["acc"], m["live_on"], m["live_redos"]
     lag_value = 0 if both else lag
@@ -692,6 +720,8 @@ def main():
                                     f"pointers ({m['peer'][1]} peers); no collective per K-window" if m["peer"][0] == 2 and live_on else
                                     "ncclAllGather + scatter per K-window" + (" (the in-launch hand-off timed out and the run was redone)" if m["peer"][0] == 2 else "")),
                        "exchange_note": exchange_note,
+                       "ranks": rank_rows if world > 1 else None, "rendezvous_skew": skew,
+                       "live_rearms": m["rank_diag"]["live_rearms"],
                        "parallelism": f"chains sharded x{world}, Z replicated" if world > 1 else "single GPU"},
             "gens_to_rhat_1p05": gens_to_rhat, "rhat_trace": rhat_trace[-12:], "accept_ratio_mean": acc,
             "value_window_kernels_only": N * gens / (ev_ms / 1e3) if ev_ms > 0 else None,

@@ -595,7 +595,7 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
     unsigned int cnt_total = 0, cnt_first = 0;             // accept mask by ballot (WindowParams::acc_out)
     const unsigned long long speak64 = __builtin_amdgcn_ballot_w64(r == 0);
 #ifdef DEMCZ_STAMPS
-    unsigned long long sb[6] = {0, 0, 0, 0, 0, 0}, sb_t = __builtin_readcyclecounter(), sb_waits = 0;
+    unsigned long long sb[7] = {0, 0, 0, 0, 0, 0, 0}, sb_t = __builtin_readcyclecounter(), sb_waits = 0, sb_polls = 0;
 #define MLB_TICK(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); sb[i] += t_ - sb_t; sb_t = t_; } while (0)
 #else
 #define MLB_TICK(i) do { } while (0)
@@ -614,9 +614,15 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
                 int spins = 0;
                 MLB_TICK(4);
 #ifdef DEMCZ_STAMPS
-                if (__builtin_amdgcn_ballot_w64(bad) != 0ull) ++sb_waits;
+                // (the poll loop is timed only when it is entered: a stamp costs 100-200 clocks, more than an average step waits)
+                const bool sb_any = __builtin_amdgcn_ballot_w64(bad) != 0ull;
+                unsigned long long sb_w0 = 0;
+                if (sb_any) { ++sb_waits; sb_w0 = __builtin_readcyclecounter(); }
 #endif
                 while (__builtin_amdgcn_ballot_w64(bad) != 0ull) {       // wave-uniform
+#ifdef DEMCZ_STAMPS
+                    ++sb_polls;
+#endif
                     if (live_poll_abandon(P, spins, bad, (unsigned)(is_sentinel(za[0]) ? row1_c : row2_c), gi)) return;
                     __builtin_amdgcn_s_sleep(1);
                     bad = false;
@@ -629,6 +635,9 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
                         bad |= is_sentinel(za[k]) | is_sentinel(zb[k]);
                     }
                 }
+#ifdef DEMCZ_STAMPS
+                if (sb_any) sb[6] += __builtin_readcyclecounter() - sb_w0;
+#endif
             }
             double delta[NP];
             bool inb[NP];
@@ -841,6 +850,9 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
                 }
             }
             ++nb;
+#ifdef DEMCZ_EXP_DRAIN_PUBLISH     // (diagnosis, scripts/mlb_stamps.py: how long the boundary's write-through stores take to be acknowledged)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         }
         MLB_TICK(3);
     }
@@ -855,6 +867,7 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
     if (P.stamps && lane == 0 && vb < 65536) {     // [wait+poll+increments, next draws, dependent part, history, -, between]
         unsigned long long* o = P.stamps + (size_t)vb * 16;
         for (int i = 0; i < 6; ++i) o[8 + i] = sb[i];
+        o[6] = sb[6]; o[7] = sb_polls;
         o[14] = (unsigned long long)P.ngen * (unsigned long long)NB;
         o[15] = sb_waits;
     }

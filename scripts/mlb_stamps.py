@@ -3,12 +3,13 @@
 import ctypes as C, os, subprocess, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
-so = ROOT / "build_ab" / "stamps.so"
+so = ROOT / "build_ab" / (os.environ.get("DEMCZ_STAMPS_LIB", "stamps") + ".so")      # (DEMCZ_STAMPS_LIB=stamps_nohist: an experiment build)
+os.environ["DEMCZ_LIB"] = str(so)          # (before anything imports demc_jl_amd: _lib reads it at import)
 if not so.exists():
     so.parent.mkdir(exist_ok=True)
-    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-pass-failed",
-                    "-DDEMCZ_STAMPS", "-o", str(so), str(ROOT / "demc.jl_amd" / "csrc" / "demcz_capi.hip"), "-lrccl"], check=True)
-os.environ["DEMCZ_LIB"] = str(so)
+    sys.path.insert(0, str(ROOT))
+    from demc_jl_amd import _lib as _build
+    _build.build_lib(so, extra=["-DDEMCZ_STAMPS"])          # (every translation unit, in parallel: demc.jl_amd/_lib.py)
 sys.path.insert(0, str(ROOT))
 import numpy as np
 import demc_jl_amd as demc
@@ -36,16 +37,21 @@ for i in (4, 0, 1, 2, 3, 5):
     v = s[:, 8 + i] / ns
     print(f"  {v.mean():8.0f} {v.max():8.0f}   {names[i]}")
 print(f"  {(s[:, 8:14].sum(axis=1) / ns).mean():8.0f} ticks per block-step in all")
+print(f"  {(s[:, 6] / ns).mean():8.0f} {(s[:, 6] / ns).max():8.0f}   of which INSIDE the poll loop (round 5: timed only in the steps that enter it -- a stamp costs 100-200 clocks, "
+      "which round 4's figure for the waits, this segment's total divided by the share of steps with a wait, attributed to them)")
 wt = s[:, 15]
 if wt.sum() > 0:
-    print(f"  block-steps in which a wave found a row missing: {100 * wt.sum() / ns.sum():.1f} %, {s[:, 8].sum() / wt.sum():.0f} ticks per such step (mean); per wave min / max share {100 * (wt / ns).min():.1f} / {100 * (wt / ns).max():.1f} %")
+    print(f"  block-steps in which a wave found a row missing: {100 * wt.sum() / ns.sum():.2f} %, {s[:, 6].sum() / wt.sum():.0f} ticks in the poll loop per such step (mean), "
+          f"{s[:, 7].sum() / wt.sum():.1f} polls each; per wave min / max share {100 * (wt / ns).min():.1f} / {100 * (wt / ns).max():.1f} %")
+    pw = s[:, 6] / np.maximum(wt, 1)
+    print(f"  poll-loop ticks per wait, per wave: median {np.median(pw[wt > 0]):.0f}  95 % {np.percentile(pw[wt > 0], 95):.0f}  max {pw.max():.0f}")
 e.close()
 # per-wave speed without the waits: is somebody slower than the rest all the time?
-work = (s[:, 8:14].sum(axis=1) - s[:, 8]) / ns
+work = (s[:, 8:14].sum(axis=1) - s[:, 6]) / ns
 order = np.argsort(work)
 print(f"  ticks per block-step without the waits, per wave: min {work.min():.0f}  5 % {np.percentile(work, 5):.0f}  median {np.median(work):.0f}  95 % {np.percentile(work, 95):.0f}  max {work.max():.0f}")
 print("  slowest waves (workgroup index: ticks):", ", ".join(f"{int(i)}: {work[i]:.0f}" for i in order[-8:]))
 print("  by workgroup index mod 8 (XCD), mean:", " ".join(f"{work[k::8].mean():.0f}" for k in range(8)))
-print("  waits per wave by workgroup index mod 8, mean ticks per step:", " ".join(f"{(s[k::8, 8] / ns[k::8]).mean():.0f}" for k in range(8)))
+print("  poll-loop ticks per wave by workgroup index mod 8, mean per step:", " ".join(f"{(s[k::8, 6] / ns[k::8]).mean():.0f}" for k in range(8)))
 print("  by workgroup index, buckets of 64, mean:", " ".join(f"{work[k:k + 64].mean():.0f}" for k in range(0, len(work), 64)))
 print("  workgroups slower than 1.1 x median:", int((work > 1.1 * np.median(work)).sum()), "of", len(work), "; indices", np.nonzero(work > 1.1 * np.median(work))[0][:40].tolist())

@@ -8,11 +8,12 @@ import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 so = ROOT / "build_ab" / "stamps.so"
+os.environ["DEMCZ_LIB"] = str(so)          # (before anything imports demc_jl_amd: _lib reads it at import)
 if not so.exists():
     so.parent.mkdir(exist_ok=True)
-    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-pass-failed",
-                    "-DDEMCZ_STAMPS", "-o", str(so), str(ROOT / "demc.jl_amd" / "csrc" / "demcz_capi.hip"), "-lrccl"], check=True)
-os.environ["DEMCZ_LIB"] = str(so)
+    sys.path.insert(0, str(ROOT))
+    from demc_jl_amd import _lib as _build
+    _build.build_lib(so, extra=["-DDEMCZ_STAMPS"])          # (every translation unit, in parallel: demc.jl_amd/_lib.py)
 sys.path.insert(0, str(ROOT))
 import numpy as np
 import demc_jl_amd as demc
