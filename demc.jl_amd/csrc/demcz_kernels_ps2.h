@@ -102,6 +102,21 @@ __device__ __forceinline__ void ps2_dma16b(ps2_rsrc_t rsrc, unsigned voff, unsig
 #ifndef PS2_DMA_BUFFER
 #define PS2_DMA_BUFFER 1
 #endif
+// The publisher wave's idle sleep (round 5).  It shares a SIMD with a chain wave and, with nothing to publish, used to look at the
+// hand-off words every ~150 clocks (s_sleep 1): ~13 % of that SIMD's issue slots -- measured as the difference between the LIVE
+// and the non-LIVE instantiation before a single boundary is counted: 111 against 99.5 us per 1000 generations with four
+// boundaries a launch (profiles/r05q_live_fixed_cost.txt), and through the hand-off every chain keeps step with the slowest.  Now it
+// sleeps PS2_PUB_IDLE_SLEEP x 64 clocks and the chain wave that posts a row (or leaves) wakes it with s_wakeup -- which pings the
+// workgroup's sleeping waves and is ignored by the others.  A ping that arrives just before the publisher falls asleep is lost: the
+// row then waits out one sleep (0.4 us at 16), no longer.  (Two chains to a wave: the publisher also carries the history, a
+// pass's worth every pass -- it keeps the short sleep.)
+#ifndef PS2_PUB_IDLE_SLEEP
+#define PS2_PUB_IDLE_SLEEP 16
+#endif
+__device__ __forceinline__ void ps2_wake_publisher()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory");      // (the LDS words it will look at are written)
+}
 
 template <int TARGET, int D, bool LIVE, bool TEMPER>
 __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_kernel_ps2(const WindowParams P)
@@ -327,7 +342,8 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
 #ifdef DEMCZ_STAMPS
                 ++pb_sleep;
 #endif
-                __builtin_amdgcn_s_sleep(1);
+                if constexpr (HRING) __builtin_amdgcn_s_sleep(1);
+                else __builtin_amdgcn_s_sleep(PS2_PUB_IDLE_SLEEP);
             }
 #ifdef DEMCZ_STAMPS
             if (P.stamps && lane == 0 && (int)blockIdx.x < 2048) {       // the publisher's own account: second half of the stamp buffer
@@ -342,6 +358,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (LIVE) {
             if (lane == 0) __hip_atomic_store(&pub_exit[w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if constexpr (!HRING) ps2_wake_publisher();
         }
     };
     const int64_t c = (int64_t)bxs * PS_CHAINS + w;
@@ -663,7 +680,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
 #ifdef DEMCZ_STAMPS
     // diagnostic build (scripts/ps2_stamps.py): shader-clock sums per segment of a pass.  A stamp drains the wave's outstanding
     // LDS / scalar-memory operations, so the segments add up to MORE than an unstamped pass: read them as proportions.
-    unsigned long long sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sa_nbad = 0;
+    unsigned long long sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sa_nbad = 0, sa_wait = 0;
     const unsigned long long sa_start = __builtin_readcyclecounter();
     const unsigned long long sa_rt0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz, the same clock on every CU: start skew
 #define PS2_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); sa[i] += t_ - sa_t; sa_t = t_; } while (0)
@@ -837,6 +854,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
                 if (lane < D) pub_rows[(w * PS_PUB + (int)((unsigned int)nb % PS_PUB)) * D + lane] = v;
                 asm volatile("" ::: "memory");
                 if (lane == 0) __hip_atomic_store(&pub_seq[w], (unsigned int)nb + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if constexpr (!HRING) ps2_wake_publisher();
             } else {
                 if (lane < D && P.do_append) P.Zw[(P.M_append + nb * P.N + c) * P.ZS + lane] = v;
             }
@@ -851,11 +869,15 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             if (__builtin_amdgcn_ballot_w64(bad_n) != 0ull) {
 #ifdef DEMCZ_STAMPS
                 ++sa_nbad;
+                const unsigned long long sa_w0 = __builtin_readcyclecounter();
 #endif
                 if (reread(bad_n, SN, ip * R)) return 2;
+#ifdef DEMCZ_STAMPS
+                sa_wait += __builtin_readcyclecounter() - sa_w0;      // (the wait alone, timed only where there is one: round 5)
+#endif
             }
         }
-        PS2_T(6);                      // waiting for rows other waves had not published
+        PS2_T(6);                      // the test for rows not yet published (+ the wait where there is one; sa_wait: the waits alone)
         wave_lds_handoff();
         return 0;
     };
@@ -890,6 +912,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         unsigned long long* o = P.stamps + (size_t)c * 16;
         for (int i = 0; i < 7; ++i) o[i] = sa[i];
         o[8] = __builtin_readcyclecounter() - sa_start; o[7] = sa_hfull; o[11] = sa_nbad; o[12] = sa_spins; o[14] = (unsigned long long)npass; o[15] = 2;
+        o[6] = sa_wait;        // (round 5: the waits alone; the segment between stamps 5 and 6 -- the test, which every pass pays -- is only in the total)
         o[9] = sa_rt0; o[10] = __builtin_amdgcn_s_memrealtime();
         // where the wave ran: HW_REG_HW_ID (register 4: simd 5:4, cu 11:8, sh 12, se 15:13) and HW_REG_XCC_ID (register 20)
         o[13] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);

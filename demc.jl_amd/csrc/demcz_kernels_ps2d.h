@@ -243,7 +243,8 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
 #ifdef DEMCZ_STAMPS
                 ++pb_sleep;
 #endif
-                __builtin_amdgcn_s_sleep(1);
+                if constexpr (HRING) __builtin_amdgcn_s_sleep(1);
+                else __builtin_amdgcn_s_sleep(PS2_PUB_IDLE_SLEEP);
             }
 #ifdef DEMCZ_STAMPS
             if (P.stamps && lane == 0 && (int)blockIdx.x < 2048) {       // the publisher's own account: second half of the stamp buffer
@@ -258,6 +259,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (LIVE) {
             if (lane == 0) __hip_atomic_store(&pub_exit[w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if constexpr (!HRING) ps2_wake_publisher();
         }
     };
     const int64_t wv = (int64_t)bxs * PS_CHAINS + w;       // this wave among the chain waves; its chains: NCH * wv, NCH * wv + 1
@@ -596,7 +598,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
 #ifdef DEMCZ_STAMPS
     // diagnostic build (scripts/ps2_stamps.py): shader-clock sums per segment of a pass.  A stamp drains the wave's outstanding
     // LDS / scalar-memory operations, so the segments add up to MORE than an unstamped pass: read them as proportions.
-    unsigned long long sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sa_nbad = 0;
+    unsigned long long sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sa_nbad = 0, sa_wait = 0;
     const unsigned long long sa_start = __builtin_readcyclecounter();
     const unsigned long long sa_rt0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz, the same clock on every CU: start skew
 #define PS2_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); sa[i] += t_ - sa_t; sa_t = t_; } while (0)
@@ -772,6 +774,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
                 if (l5 < D) pub_rows[((w * PS_PUB + (int)((unsigned int)nb % PS_PUB)) * NCH + hh) * D + l5] = v;
                 asm volatile("" ::: "memory");
                 if (lane == 0) __hip_atomic_store(&pub_seq[w], (unsigned int)nb + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if constexpr (!HRING) ps2_wake_publisher();
             } else {
                 if (l5 < D && act && P.do_append) P.Zw[(P.M_append + nb * P.N + c) * P.ZS + l5] = v;
             }
@@ -786,11 +789,15 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
             if (__builtin_amdgcn_ballot_w64(bad_n) != 0ull) {
 #ifdef DEMCZ_STAMPS
                 ++sa_nbad;
+                const unsigned long long sa_w0 = __builtin_readcyclecounter();
 #endif
                 if (reread(bad_n, SN, ip * R)) return 2;
+#ifdef DEMCZ_STAMPS
+                sa_wait += __builtin_readcyclecounter() - sa_w0;      // (the wait alone, timed only where there is one: round 5)
+#endif
             }
         }
-        PS2_T(6);                      // waiting for rows other waves had not published
+        PS2_T(6);                      // the test for rows not yet published (+ the wait where there is one; sa_wait: the waits alone)
         wave_lds_handoff();
         return 0;
     };
@@ -825,6 +832,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         unsigned long long* o = P.stamps + (size_t)wv * 16;
         for (int i = 0; i < 7; ++i) o[i] = sa[i];
         o[8] = __builtin_readcyclecounter() - sa_start; o[7] = sa_hfull; o[11] = sa_nbad; o[12] = sa_spins; o[14] = (unsigned long long)npass; o[15] = 2;
+        o[6] = sa_wait;        // (round 5: the waits alone; the segment between stamps 5 and 6 -- the test, which every pass pays -- is only in the total)
         o[9] = sa_rt0; o[10] = __builtin_amdgcn_s_memrealtime();
         // where the wave ran: HW_REG_HW_ID (register 4: simd 5:4, cu 11:8, sh 12, se 15:13) and HW_REG_XCC_ID (register 20)
         o[13] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);

@@ -56,7 +56,8 @@ print(f"  whole launch: {s[:, 8].mean():.0f} shader clocks mean, {s[:, 8].max():
 names = ["history store, DMA wait, raw values asked for, candidate adds", "log-density, the next pass's increments",
          "bpermute asked for, table write, DMA issue, next pass's rows asked for", "accept tests, path (waits for the bpermute)",
          "winner, state + history values back from the table", "boundary: row to the publisher",
-         "waits for rows not yet published"]
+         "waits for rows not yet published (round 5: timed only in the passes that wait -- until round 4 this line was the whole segment "
+         "between two stamps, which every pass pays 100-200 clocks of stamp overhead for, and 'per waiting pass' divided THAT by the waiting passes)"]
 for i, nm in enumerate(names):
     print(f"  {(s[:, i] / n).mean():8.0f} per pass  ({100 * s[:, i].sum() / s[:, 8].sum():5.1f} %)  {nm}")
 print(f"  passes that waited for a row: {100 * (s[:, 11] / n).mean():.2f} %")
