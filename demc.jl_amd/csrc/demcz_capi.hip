@@ -2743,7 +2743,10 @@ extern "C" int32_t demcz_run(demcz_handle* h, int64_t g_from, int64_t g_to, doub
         }
         // boundaries whose rows generations of this same launch draw from.  With peers EVERY launch is of the LIVE kind: the rows
         // of the boundary that ended the launch before may still be on their way from another replica's publisher
-        const bool live = live_max > 0 && (((w_end - 1) / K - (g - 1) / K) > 0 || peer);
+        // (DEMCZ_FORCE_LIVE_KERNEL=1, diagnosis only: the LIVE instantiation also for launches with no boundary inside -- what the
+        //  instantiation itself costs, scripts/live_fixed_cost.py)
+        static const bool force_live = getenv("DEMCZ_FORCE_LIVE_KERNEL") != nullptr;
+        const bool live = live_max > 0 && (((w_end - 1) / K - (g - 1) / K) > 0 || peer || force_live);
         P.live_err = h->d_live_err;
         P.live_spin_limit = h->live_spin_limit ? (int32_t)h->live_spin_limit : LIVE_SPIN_LIMIT;
         if (h->live_fault_polls > 0 && g >= h->live_fault_g) P.live_spin_limit = h->live_fault_polls;

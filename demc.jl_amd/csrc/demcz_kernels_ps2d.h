@@ -540,9 +540,20 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         logu_n = *reinterpret_cast<const double*>(rw + lgo);
         if constexpr (TEMPER) temp_n = *reinterpret_cast<const double*>(rw + tko);
     };
-    auto front_bad = [&]() __attribute__((always_inline)) -> bool {
-        if constexpr (LIVE) return fl && (is_sentinel(za_f) | is_sentinel(zb_f));
-        return false;
+    // The test for rows other waves have not published yet, as a LANE MASK in scalar registers (round 5): two 64-bit compares
+    // straight into masks, OR, AND with the lanes that form increments.  As a per-lane bool fed to a ballot it compiled to
+    // v_cndmask + v_cmp -- a temporary VGPR, which the register allocator took from the destinations of LDS reads still in flight:
+    // an s_waitcnt lgkmcnt(0) at the end of EVERY pass.
+    const unsigned long long flmask = __builtin_amdgcn_ballot_w64(fl);
+    auto front_bad = [&]() __attribute__((always_inline)) -> unsigned long long {
+#ifndef PS2_EXP_NOBADTEST      // (timing experiment only: no test for unpublished rows -- results are garbage where a row was missing)
+        if constexpr (LIVE) {
+            const unsigned long long ma = __builtin_amdgcn_uicmpl((unsigned long long)__double_as_longlong(za_f), LIVE_SENTINEL, 32 /* EQ */);
+            const unsigned long long mb = __builtin_amdgcn_uicmpl((unsigned long long)__double_as_longlong(zb_f), LIVE_SENTINEL, 32);
+            return (ma | mb) & flmask;
+        }
+#endif
+        return 0ull;
     };
     auto front_rest = [&](int slot_dma) __attribute__((always_inline)) {
         issue(pr_f, slot_dma);
@@ -580,14 +591,14 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
 
     {
         front_reads(0, false);                           // the first pass's front end (its DMA: that of pass AHEAD)
-        const bool bad0 = front_bad();
+        const unsigned long long bad0 = front_bad();
         write_increment();
         front_rest(PS2_AHEAD);
         logu = logu_n;
         if constexpr (TEMPER) temp = temp_n;
         if constexpr (LIVE) {
-            if (__builtin_amdgcn_ballot_w64(bad0) != 0ull) {
-                if (reread(bad0, 0, 0)) { leave(); return; }
+            if (bad0 != 0ull) {
+                if (reread(((bad0 >> lane) & 1ull) != 0ull, 0, 0)) { leave(); return; }
             }
         }
     }
@@ -668,7 +679,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         if constexpr (HRING && !FIRST) store_history(0u);
 #endif
         write_increment();
-        const bool bad_n = front_bad();
+        const unsigned long long bad_n = front_bad();
         double lpp;
         if constexpr (TARGET == TARGET_MVNORMAL) {
             double q = 0.0;
@@ -786,12 +797,12 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
         if (++ip == npass) return 1;
         if constexpr (LIVE) {
             // only now -- this wave's own row is on its way -- may it wait for rows of other waves
-            if (__builtin_amdgcn_ballot_w64(bad_n) != 0ull) {
+            if (__builtin_expect(bad_n != 0ull, 0)) {
 #ifdef DEMCZ_STAMPS
                 ++sa_nbad;
                 const unsigned long long sa_w0 = __builtin_readcyclecounter();
 #endif
-                if (reread(bad_n, SN, ip * R)) return 2;
+                if (reread(((bad_n >> lane) & 1ull) != 0ull, SN, ip * R)) return 2;
 #ifdef DEMCZ_STAMPS
                 sa_wait += __builtin_readcyclecounter() - sa_w0;      // (the wait alone, timed only where there is one: round 5)
 #endif

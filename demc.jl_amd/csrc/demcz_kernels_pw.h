@@ -419,7 +419,10 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), pw_min_wave
             if (fl[t]) sd_w[fu[t] * DP + fp[t]] = t1 + t2;
         }
     };
-    auto front = [&](int slot, int Rn, int R2, int g2, int gix, bool counted) __attribute__((always_inline)) -> bool {
+    // (returns the lanes that found a sentinel as a MASK, taken here where the values are fresh: carried to the end of the pass as a
+    //  bool it became a v_cndmask + v_cmp there, on a temporary register the allocator took from LDS reads still in flight -- an
+    //  s_waitcnt lgkmcnt(0) in every pass: demcz_kernels_ps2.h, round 5)
+    auto front = [&](int slot, int Rn, int R2, int g2, int gix, bool counted) __attribute__((always_inline)) -> unsigned long long {
         const unsigned char* rw = raw_w + slot * SLOTB;
         if (counted) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VMW) : "memory");
         uint64_t pr[NDMA];
@@ -439,7 +442,8 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), pw_min_wave
         write_increment(za_f, zb_f, zt_f);
         const int s2 = (slot + 2 >= PS_SLOTS) ? slot + 2 - PS_SLOTS : slot + 2;
         issue(R2, g2, gix, s2, pr);
-        return bad;
+        if constexpr (LIVE) return __builtin_amdgcn_ballot_w64(bad);
+        return 0ull;
     };
     auto reread = [&](int slot, int Rn, int gpass) __attribute__((always_inline)) -> bool {
         const unsigned char* rw = raw_w + slot * SLOTB;
@@ -483,9 +487,9 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), pw_min_wave
     };
 
     {
-        const bool bad0 = front(0, qR(0), qR(2), gq2, gq4, false);
+        const unsigned long long bad0 = front(0, qR(0), qR(2), gq2, gq4, false);
         if constexpr (LIVE) {
-            if (__builtin_amdgcn_ballot_w64(bad0) != 0ull) {
+            if (bad0 != 0ull) {
                 if (reread(0, qR(0), 0)) { leave(); return; }
             }
         }
@@ -600,7 +604,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), pw_min_wave
         PW_T(0);                 // state row + candidate adds straight from LDS
         wave_lds_handoff();      // (the front end below rewrites the increments)
         store_history();
-        const bool bad_n = front(slot, qR(1), qR(3), g3, g5, true);
+        const unsigned long long bad_n = front(slot, qR(1), qR(3), g3, g5, true);
         PW_T(1);                 // history stores, DMA wait, next pass's increments, DMA issue
         // the candidates go to rows 1..31 of the table (row 0 keeps the state the pass started from); the log-density follows
         double lpp;
@@ -780,7 +784,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), pw_min_wave
             //  record buffer has past this launch's draws, which after a rollback, a demcz_set_state or a discarded slab are row
             //  indices of a LONGER archive than there is: never waited for.  Found in round 5 by the re-arming tests: a LIVE launch
             //  behind a redo polled 2^18 times for a row nobody was going to write.  Without REG that pass has length 0.)
-            if ((!REG || ip + 1 < npass) && __builtin_amdgcn_ballot_w64(bad_n) != 0ull) {
+            if ((!REG || ip + 1 < npass) && __builtin_expect(bad_n != 0ull, 0)) {
                 if (reread(slot, qR(1), g0 + R)) { leave(); return; }
             }
         }

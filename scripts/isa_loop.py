@@ -14,12 +14,23 @@ LLVM = Path("/opt/rocm/lib/llvm/bin")
 
 
 def disassemble(lib):
+    """The library is linked from several translation units (round 5): its .hip_fatbin section holds one offload bundle per unit,
+    each with a gfx950 code object -- all of them are disassembled."""
+    out = []
     with tempfile.TemporaryDirectory() as td:
-        co, fat = Path(td) / "gfx950.co", Path(td) / "fat.bin"
+        fat = Path(td) / "fat.bin"
         subprocess.run([str(LLVM / "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", str(lib), str(fat)], check=True)
-        subprocess.run([str(LLVM / "clang-offload-bundler"), "--type=o", "--unbundle", f"--input={fat}", f"--output={co}",
-                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], check=True, stderr=subprocess.DEVNULL)
-        return subprocess.run([str(LLVM / "llvm-objdump"), "-d", str(co)], check=True, capture_output=True, text=True).stdout
+        blob = fat.read_bytes()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        starts = [i for i in range(len(blob)) if blob.startswith(magic, i)]
+        for n, a in enumerate(starts):
+            part, co = Path(td) / f"b{n}.bin", Path(td) / f"b{n}.co"
+            part.write_bytes(blob[a:starts[n + 1] if n + 1 < len(starts) else len(blob)])
+            r = subprocess.run([str(LLVM / "clang-offload-bundler"), "--type=o", "--unbundle", f"--input={part}", f"--output={co}",
+                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], stderr=subprocess.DEVNULL)
+            if r.returncode == 0 and co.exists() and co.stat().st_size > 0:
+                out.append(subprocess.run([str(LLVM / "llvm-objdump"), "-d", str(co)], check=True, capture_output=True, text=True).stdout)
+    return "\n".join(out)
 
 
 def kernel_insts(text, needle):

@@ -12,12 +12,20 @@ LLVM = Path("/opt/rocm/lib/llvm/bin")
 
 
 def kernel_table(lib):
-    with tempfile.TemporaryDirectory() as td:
-        co, fat = Path(td) / "gfx950.co", Path(td) / "fat.bin"
+    notes = ""
+    with tempfile.TemporaryDirectory() as td:      # (one offload bundle per translation unit of the library: all of them)
+        fat = Path(td) / "fat.bin"
         subprocess.run([str(LLVM / "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", str(lib), str(fat)], check=True)
-        subprocess.run([str(LLVM / "clang-offload-bundler"), "--type=o", "--unbundle", f"--input={fat}", f"--output={co}",
-                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], check=True, stderr=subprocess.DEVNULL)
-        notes = subprocess.run([str(LLVM / "llvm-readelf"), "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+        blob = fat.read_bytes()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        starts = [i for i in range(len(blob)) if blob.startswith(magic, i)]
+        for n, a in enumerate(starts):
+            part, co = Path(td) / f"b{n}.bin", Path(td) / f"b{n}.co"
+            part.write_bytes(blob[a:starts[n + 1] if n + 1 < len(starts) else len(blob)])
+            r = subprocess.run([str(LLVM / "clang-offload-bundler"), "--type=o", "--unbundle", f"--input={part}", f"--output={co}",
+                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], stderr=subprocess.DEVNULL)
+            if r.returncode == 0 and co.exists() and co.stat().st_size > 0:
+                notes += subprocess.run([str(LLVM / "llvm-readelf"), "--notes", str(co)], check=True, capture_output=True, text=True).stdout
     rows = []
     for blk in re.split(r"\n\s*- \.agpr_count:", notes)[1:]:
         blk = ".agpr_count:" + blk
