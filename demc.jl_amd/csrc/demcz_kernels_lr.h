@@ -249,21 +249,24 @@ __global__ void __launch_bounds__(64 * LR16_WAVES) window_kernel_lr16(const Wind
         [[maybe_unused]] bool failed = false;
         if constexpr (LIVE) {
             // rows appended since the gather was issued read as the sentinel until they are published: ask again (sc1)
-            bool bad = false;
+            auto sentinel_mask = [&]() __attribute__((always_inline)) {        // (as a scalar lane mask: sentinel_lanes, demcz_kernels_rec.h)
+                unsigned long long mm = 0ull;
 #pragma unroll
-            for (int m = 0; m < NMF; ++m) bad |= is_sentinel(za[m]) | is_sentinel(zb[m]);
+                for (int m = 0; m < NMF; ++m) mm |= sentinel_lanes(za[m]) | sentinel_lanes(zb[m]);
+                return mm;
+            };
+            unsigned long long badm = sentinel_mask();
             int spins = 0;
-            while (__builtin_amdgcn_ballot_w64(bad) != 0ull) {       // wave-uniform
-                if (live_poll_abandon(P, spins, bad, (unsigned)(is_sentinel(za[0]) ? ra_c : rb_c), gi)) { failed = true; break; }
+            while (__builtin_expect(badm != 0ull, 0)) {       // wave-uniform
+                if (live_poll_abandon(P, spins, ((badm >> (threadIdx.x & 63)) & 1ull) != 0ull, (unsigned)(is_sentinel(za[0]) ? ra_c : rb_c), gi)) { failed = true; break; }
                 __builtin_amdgcn_s_sleep(1);
-                bad = false;
 #pragma unroll
                 for (int m = 0; m < NMF; ++m) {
                     const int k = own[m] ? 4 * m + q : 0;
                     if (is_sentinel(za[m])) za[m] = live_reload(P, &P.Z[ra_c * P.ZS + k]);
                     if (is_sentinel(zb[m])) zb[m] = live_reload(P, &P.Z[rb_c * P.ZS + k]);
-                    bad |= is_sentinel(za[m]) | is_sentinel(zb[m]);
                 }
+                badm = sentinel_mask();
             }
         }
         LR_TICK(4);

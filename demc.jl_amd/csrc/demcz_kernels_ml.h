@@ -194,22 +194,25 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
         if constexpr (LIVE) {
             // the gather was issued a generation ago; rows appended since then by other waves read as the
             // sentinel until they are published: ask again (demcz_kernels_rec.h)
-            bool bad = false;
+            auto sentinel_mask = [&]() __attribute__((always_inline)) {        // (as a scalar lane mask: sentinel_lanes, demcz_kernels_rec.h)
+                unsigned long long m = 0ull;
 #pragma unroll
-            for (int k = 0; k < NP; ++k) bad |= is_sentinel(za_c[k]) | is_sentinel(zb_c[k]);
+                for (int k = 0; k < NP; ++k) m |= sentinel_lanes(za_c[k]) | sentinel_lanes(zb_c[k]);
+                return m;
+            };
+            unsigned long long badm = sentinel_mask();
             int spins = 0;
-            while (__builtin_amdgcn_ballot_w64(bad) != 0ull) {       // wave-uniform
-                if (live_poll_abandon(P, spins, bad, is_sentinel(za_c[0]) ? ra_c : rb_c, gi)) return true;
+            while (__builtin_expect(badm != 0ull, 0)) {       // wave-uniform
+                if (live_poll_abandon(P, spins, ((badm >> (threadIdx.x & 63)) & 1ull) != 0ull, is_sentinel(za_c[0]) ? ra_c : rb_c, gi)) return true;
                 __builtin_amdgcn_s_sleep(1);
-                bad = false;
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
                     const int p = r + L * k;
                     const int pc = (p < D) ? p : 0;
                     if (is_sentinel(za_c[k])) za_c[k] = live_reload(P, &P.Z[(int64_t)ra_c * P.ZS + pc]);
                     if (is_sentinel(zb_c[k])) zb_c[k] = live_reload(P, &P.Z[(int64_t)rb_c * P.ZS + pc]);
-                    bad |= is_sentinel(za_c[k]) | is_sentinel(zb_c[k]);
                 }
+                badm = sentinel_mask();
             }
         }
         double delta[NP];
@@ -608,32 +611,39 @@ __global__ void __launch_bounds__(REC ? 64 * MLB_REC_WAVES : 64) window_kernel_m
                 // the gather was issued a block-step ago; rows appended since then by other waves read as the
                 // sentinel until they are published: ask again (demcz_kernels_rec.h)
                 row1_c = row1_n; row2_c = row2_n;
-                bool bad = false;
+                // (the lanes that read a sentinel, as a MASK in scalar registers: compares straight into masks, a scalar test -- as a
+                //  per-lane bool fed to a ballot it was a v_cndmask + v_cmp on a temporary register in every block-step: round 5,
+                //  demcz_kernels_ps2.h)
+                auto sentinel_mask = [&]() __attribute__((always_inline)) {
+                    unsigned long long m = 0ull;
 #pragma unroll
-                for (int k = 0; k < NP; ++k) bad |= is_sentinel(za[k]) | is_sentinel(zb[k]);
+                    for (int k = 0; k < NP; ++k)
+                        m |= sentinel_lanes(za[k]) | sentinel_lanes(zb[k]);
+                    return m;
+                };
+                unsigned long long badm = sentinel_mask();
                 int spins = 0;
                 MLB_TICK(4);
 #ifdef DEMCZ_STAMPS
                 // (the poll loop is timed only when it is entered: a stamp costs 100-200 clocks, more than an average step waits)
-                const bool sb_any = __builtin_amdgcn_ballot_w64(bad) != 0ull;
+                const bool sb_any = badm != 0ull;
                 unsigned long long sb_w0 = 0;
                 if (sb_any) { ++sb_waits; sb_w0 = __builtin_readcyclecounter(); }
 #endif
-                while (__builtin_amdgcn_ballot_w64(bad) != 0ull) {       // wave-uniform
+                while (__builtin_expect(badm != 0ull, 0)) {       // wave-uniform
 #ifdef DEMCZ_STAMPS
                     ++sb_polls;
 #endif
-                    if (live_poll_abandon(P, spins, bad, (unsigned)(is_sentinel(za[0]) ? row1_c : row2_c), gi)) return;
+                    if (live_poll_abandon(P, spins, ((badm >> lane) & 1ull) != 0ull, (unsigned)(is_sentinel(za[0]) ? row1_c : row2_c), gi)) return;
                     __builtin_amdgcn_s_sleep(1);
-                    bad = false;
 #pragma unroll
                     for (int k = 0; k < NP; ++k) {
                         const int p = r + L * k;
                         const int pc = (p < D) ? p : 0;
                         if (is_sentinel(za[k])) za[k] = live_reload(P, &P.Z[row1_c * P.ZS + pc]);
                         if (is_sentinel(zb[k])) zb[k] = live_reload(P, &P.Z[row2_c * P.ZS + pc]);
-                        bad |= is_sentinel(za[k]) | is_sentinel(zb[k]);
                     }
+                    badm = sentinel_mask();
                 }
 #ifdef DEMCZ_STAMPS
                 if (sb_any) sb[6] += __builtin_readcyclecounter() - sb_w0;

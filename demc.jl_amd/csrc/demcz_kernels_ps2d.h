@@ -548,9 +548,7 @@ __global__ void __launch_bounds__(64 * (PS_CHAINS + (LIVE ? 1 : 0)), 3) window_k
     auto front_bad = [&]() __attribute__((always_inline)) -> unsigned long long {
 #ifndef PS2_EXP_NOBADTEST      // (timing experiment only: no test for unpublished rows -- results are garbage where a row was missing)
         if constexpr (LIVE) {
-            const unsigned long long ma = __builtin_amdgcn_uicmpl((unsigned long long)__double_as_longlong(za_f), LIVE_SENTINEL, 32 /* EQ */);
-            const unsigned long long mb = __builtin_amdgcn_uicmpl((unsigned long long)__double_as_longlong(zb_f), LIVE_SENTINEL, 32);
-            return (ma | mb) & flmask;
+            return (sentinel_lanes(za_f) | sentinel_lanes(zb_f)) & flmask;
         }
 #endif
         return 0ull;

@@ -177,6 +177,15 @@ __device__ __forceinline__ void live_store(double* p, double v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ bool is_sentinel(double v) { return (unsigned long long)__double_as_longlong(v) == LIVE_SENTINEL; }
+// The lanes whose value is the sentinel, as a lane MASK in scalar registers (one v_cmp_eq_u64 straight into an SGPR pair).  Round 5:
+// the consumers' per-step test "did any lane read an unpublished row" used to OR per-lane bools and feed them to a ballot, which the
+// compiler lowers to v_cndmask + v_cmp on a temporary VGPR -- taken, at that point of a pass, from the destinations of LDS reads still
+// in flight: an s_waitcnt lgkmcnt(0) in every pass / block-step.  Masks OR-ed in scalar registers and one scalar test cost none of
+// that: window_kernel_ps2's LIVE launch 115-117 -> 108-109 us per 1000 generations, C3's block-step 39.6 -> 37.1 us per K-window.
+__device__ __forceinline__ unsigned long long sentinel_lanes(double v)
+{
+    return __builtin_amdgcn_uicmpl((unsigned long long)__double_as_longlong(v), LIVE_SENTINEL, 32 /* ICMP_EQ */);
+}
 
 // Replicated archives (a sharded run: every rank -- a GPU of the node, or for rehearsal another handle on the same GPU -- holds
 // the whole archive and runs its own shard of the chains).  The hand-off above needs nothing new on the READING side: a wave
