@@ -171,6 +171,12 @@ def d_sweep_rows(demc, seed, device_id, gens=1000):
             w = demc.workloads.iso_quad_problem(d, 1024)
             rows.append(config_row(demc, f"isotropic quadratic d={d}, N=1024, tempered T0=3 -> TN=1e-3", w, 1024, d, 10, [range(d)], seed,
                                    device_id, gens=gens, anneal=True))
+        # the reference's regression example at ITS dimension (test/example_linreg.jl:9: 25 regressors + intercept, nobs = 1000), annealed:
+        # window_kernel_ml<LINREG_SSE, 26, 16> -- FP64 vector fmas, priced against the FP64 rate like C5's matrix kernel
+        w = demc.workloads.linreg_problem(26, 1024)
+        nobs = w["design"].shape[0]
+        rows.append(config_row(demc, "linear-regression SSE d=26, nobs=1000, N=1024, tempered T0=3 -> TN=1e-3", w, 1024, 26, 10, [range(26)], seed,
+                               device_id, gens=min(gens, 400), anneal=True, flops_per_update=2.0 * nobs * 26 + 3.0 * nobs))
     except Exception as e:          # reporting only
         rows.append({"error": f"{type(e).__name__}: {e}"[:300]})
     return rows

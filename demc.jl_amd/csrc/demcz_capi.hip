@@ -994,7 +994,8 @@ extern "C" int32_t demcz_create(demcz_handle** out, const demcz_config* cfg)
             waves = wgs * ((h->split_kind == 2 && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE) ? LR16_WAVES : (h->split_kind == 4) ? PS_CHAINS : (h->split_kind == 3 || h->split_kind == 2) ? h->wpw : 1);
         } else if (h->lanes > 1) {
             const int per_wave = 64 / h->lanes;
-            const bool lr = h->full_block && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE;
+            const bool lr = h->full_block && cfg->target_kind == DEMCZ_TARGET_LINREG_SSE && d == 10 &&
+                            lr16_dynamic_lds<10>(cfg->nobs) <= ML_MAX_DYNAMIC_LDS;      // (uses_lr16: the handle's cfg is not complete yet)
             waves = lr ? ((N + LR16_CHAINS - 1) / LR16_CHAINS) * LR16_WAVES : (N + per_wave - 1) / per_wave;
         } else {
             waves = (N + WINDOW_BS - 1) / WINDOW_BS;
@@ -1296,6 +1297,9 @@ static int ml_lanes_available(int target_kind, int d, bool full_block, int64_t n
     if (target_kind == DEMCZ_TARGET_LINREG_SSE && d == 10 &&
         lr16_dynamic_lds<10>(nobs) <= ML_MAX_DYNAMIC_LDS)
         return 16;      // design + y resident in LDS
+    // (round 5: any other dimension whose draws fit one Philox block per lane, 2 + ceil(d / 2) <= 16 -- window_kernel_ml with the
+    //  sixteen lanes as the spec's sixteen partial sums, the design through L2)
+    if (target_kind == DEMCZ_TARGET_LINREG_SSE && d >= 2 && d <= 28) return 16;
     if (target_kind == DEMCZ_TARGET_MVNORMAL) {
         if (d >= 2 && d <= 10) return 8;
         if (d == 20) return 16;
@@ -1689,6 +1693,14 @@ static void launch_window_mlb(const demcz_handle* h, const WindowParams& P)
     else hipLaunchKernelGGL((window_kernel_mlb<TARGET, D, L>), dim3((unsigned)((P.N + G - 1) / G)), dim3(64), 0, h->stream, P);
 }
 
+// the regression target on the matrix-instruction kernels (demcz_kernels_lr.h): d = 10 with design + y resident in LDS; any other
+// regression shape with sixteen lanes per chain runs window_kernel_ml<LINREG_SSE, d, 16>
+static bool uses_lr16(const demcz_handle* h)
+{
+    return h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE && h->full_block && h->cfg.d == 10 &&
+           lr16_dynamic_lds<10>(h->cfg.nobs) <= ML_MAX_DYNAMIC_LDS;
+}
+
 static bool try_launch_ml(const demcz_handle* h, const WindowParams& P)
 {
     if (h->lanes <= 1 || h->lanes == DEMCZ_LAYOUT_SPLIT) return false;
@@ -1722,6 +1734,16 @@ static bool try_launch_ml(const demcz_handle* h, const WindowParams& P)
     } else if (h->cfg.target_kind == DEMCZ_TARGET_ISO_QUAD && d == 10) {
         launch_window_ml<TARGET_ISO_QUAD, 10, 8>(h, P);
         return true;
+    } else if (h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE && !uses_lr16(h)) {
+        switch (d) {
+#define DEMCZ_LRG_CASE(DD) case DD: launch_window_ml<TARGET_LINREG_SSE, DD, 16>(h, P); return true;
+        DEMCZ_LRG_CASE(2) DEMCZ_LRG_CASE(3) DEMCZ_LRG_CASE(4) DEMCZ_LRG_CASE(5) DEMCZ_LRG_CASE(6) DEMCZ_LRG_CASE(7) DEMCZ_LRG_CASE(8) DEMCZ_LRG_CASE(9)
+        DEMCZ_LRG_CASE(10) DEMCZ_LRG_CASE(11) DEMCZ_LRG_CASE(12) DEMCZ_LRG_CASE(13) DEMCZ_LRG_CASE(14) DEMCZ_LRG_CASE(15) DEMCZ_LRG_CASE(16)
+        DEMCZ_LRG_CASE(17) DEMCZ_LRG_CASE(18) DEMCZ_LRG_CASE(19) DEMCZ_LRG_CASE(20) DEMCZ_LRG_CASE(21) DEMCZ_LRG_CASE(22) DEMCZ_LRG_CASE(23)
+        DEMCZ_LRG_CASE(24) DEMCZ_LRG_CASE(25) DEMCZ_LRG_CASE(26) DEMCZ_LRG_CASE(27) DEMCZ_LRG_CASE(28)
+#undef DEMCZ_LRG_CASE
+        }
+        return false;
     } else if (h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE && d == 10) {
         {   // the regression target: 16 chains per workgroup of four waves on the 16x16x4 FP64 matrix instruction
             const size_t dyn = lr16_dynamic_lds<10>(P.tp.nobs);
@@ -4197,7 +4219,7 @@ extern "C" int32_t demcz_debug_kernel_name(const demcz_handle* h, char* buf, int
         else snprintf(tmp, sizeof tmp, "window_kernel_pc8<%s, %d, %s, %s>", tg, d, lv, tm);
     } else if (h->lanes > 1) {
         if (!h->full_block) snprintf(tmp, sizeof tmp, "window_kernel_mlb<%s, %d, %d>", tg, d, h->lanes);
-        else if (lr) snprintf(tmp, sizeof tmp, "window_kernel_lr16<%d, false, false>", d);
+        else if (lr && uses_lr16(h)) snprintf(tmp, sizeof tmp, "window_kernel_lr16<%d, false, false>", d);
         else snprintf(tmp, sizeof tmp, "window_kernel_ml<%s, %d, %d>", tg, d, h->lanes);
     } else {
         snprintf(tmp, sizeof tmp, "window_kernel<%s, %d, %s>", tg, d, h->full_block ? "true" : "false");

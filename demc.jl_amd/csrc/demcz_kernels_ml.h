@@ -49,7 +49,13 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
     const int wpw = (int)(blockDim.x >> 6);
     const int wv = (int)(threadIdx.x >> 6);
     const int64_t vb = (int64_t)xcd_block(P) * wpw + wv;        // this wave's index among the chain waves (XCD-aware: demcz_kernels.h)
-    static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD, "lane-cooperative layout: MvNormal / isotropic targets");
+    // Round 5: the regression target at ANY dimension (test/example_linreg.jl:9-32 runs d = 26; the matrix-instruction kernels of
+    // demcz_kernels_lr.h are d = 10 with the design resident in LDS).  Sixteen lanes per chain ARE the spec's sixteen interleaved
+    // partial sums: lane l takes the observations o = l, l + 16, ... in increasing order -- each residual a
+    // sequential fma chain in j, as target_logp does it -- and the partials meet in the spec's tree (l, l+8), (l, l+4), (l, l+2),
+    // (0, 1) by lane shuffles.  The design comes through L2 (208 KB at d = 26, nobs = 1000: the same rows for every chain).
+    static_assert(TARGET == TARGET_MVNORMAL || TARGET == TARGET_ISO_QUAD || TARGET == TARGET_LINREG_SSE, "lane-cooperative layout");
+    static_assert(TARGET != TARGET_LINREG_SSE || (L == LINREG_PARTIALS && !REC), "regression target: sixteen lanes per chain, fused form");
     static_assert(!LIVE || REC, "LIVE launches are a property of the split form");
     if constexpr (REC) {
         if ((int64_t)blockIdx.x >= P.consumer_blocks) {
@@ -73,9 +79,13 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
     const int lane = threadIdx.x & 63;
     const int r = lane % L;
     const int gq = wv * NG + lane / L;                     // the chain's slot in the workgroup's LDS arrays
-    const int64_t c = vb * NG + lane / L;
-    if (c >= P.N) return;
-    constexpr bool active = true;
+    const int64_t c_raw = vb * NG + lane / L;
+    // (the regression target's log-density is computed by ALL 64 lanes of a wave for its four chains together: the lanes of chains
+    //  beyond N stay -- as shadows of the last chain that store nothing -- while the wave has a chain at all)
+    if constexpr (TARGET == TARGET_LINREG_SSE) { if (vb * NG >= P.N) return; }
+    else { if (c_raw >= P.N) return; }
+    const bool active = c_raw < P.N;
+    const int64_t c = active ? c_raw : P.N - 1;
     const uint64_t chain = (uint64_t)(P.chain_id0 + c);
     const int role = (r < S) ? r : S - 1;
 
@@ -88,7 +98,8 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
         const int pc = own ? p : 0;
         x[k] = own ? P.Xcur[c + P.N * pc] : 0.0;
         epsv[k] = P.eps[pc];
-        muv[k] = P.tp.mu[pc];
+        if constexpr (TARGET == TARGET_LINREG_SSE) muv[k] = 0.0;        // (x - 0.0 is x, bit for bit: the staging row holds the proposal itself)
+        else muv[k] = P.tp.mu[pc];
         if constexpr (TARGET == TARGET_MVNORMAL) {
 #pragma unroll
             for (int j = 0; j < D; ++j) Wrow[k][j] = (own && j <= pc) ? P.tp.Wp[(pc * (pc + 1)) / 2 + j] : 0.0;
@@ -262,6 +273,90 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
                 if (2 * j + 1 < D) q = fma(t.y, t.y, q);
             }
             lpp = fma(-0.5, q, P.tp.c0);
+        } else if constexpr (TARGET == TARGET_LINREG_SSE) {
+            // The regression log-density of the wave's FOUR chains at once, a LANE PER OBSERVATION: lane l takes the observations
+            // o = l, l + 64, ... and, with the one row of the design it has loaded, forms the residual of each of the four chains
+            // (their proposals come out of the staging rows in LDS: wave-uniform addresses, broadcast reads) -- four times the
+            // arithmetic per byte of a lane-per-partial-sum mapping, whose lanes each fetched their own copy of every row: 16 bytes x
+            // 64 lanes through the CU's address path per load, 233 us per K-window at d = 26, nobs = 1000 (profiles/r05x_linreg_d26.txt).
+            // The spec's order survives: partial p = o mod 16 of a chain takes its terms in increasing o -- within a round of 64
+            // observations from lanes p, p + 16, p + 32, p + 48 in that order (four shuffles per chain), every 16-lane row keeping
+            // its own copy of the sixteen partials; then the spec's tree over a row, and each row takes its chain's value.
+            const double* __restrict__ des = P.tp.design;
+            const double* __restrict__ yo = P.tp.yobs;
+            const int64_t nobs = P.tp.nobs;
+            double bb[NG][D];                                  // the four proposals (this lane's own chain among them)
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int j = 0; j < DP / 2; ++j) {
+                    const double2 t = reinterpret_cast<const double2*>(rvec + (wv * NG + g) * DP)[j];
+                    bb[g][2 * j] = t.x;
+                    if (2 * j + 1 < D) bb[g][2 * j + 1] = t.y;
+                }
+            double part[NG];
+            bool first = true;                                 // (the same for the four chains: it depends on o alone)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) part[g] = 0.0;
+            const int pr = lane & (LINREG_PARTIALS - 1);       // the partial this lane keeps a copy of
+            // (a round is one L2 round trip for the lane's row, then its arithmetic.  Prefetching the next round's row into registers
+            //  was tried: 428 registers + 172 spilled, the same 200 us per K-window -- the round is bound by what it issues, the
+            //  four chains' proposals among it: 208 registers of them)
+            for (int64_t base = 0; base < nobs; base += 64) {
+                const int64_t o = base + lane;
+                const bool have = o < nobs;
+                const double* row = des + (have ? o : 0) * D;
+                double e[NG];
+                {
+                    double a[NG];
+                    if constexpr (D % 2 == 0) {
+                        const double2 u = reinterpret_cast<const double2*>(row)[0];
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) { a[g] = u.x * bb[g][0]; a[g] = fma(u.y, bb[g][1], a[g]); }
+#pragma unroll
+                        for (int j = 2; j < D; j += 2) {
+                            const double2 v = reinterpret_cast<const double2*>(row)[j / 2];
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) { a[g] = fma(v.x, bb[g][j], a[g]); a[g] = fma(v.y, bb[g][j + 1], a[g]); }
+                        }
+                    } else {
+                        const double u = row[0];
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) a[g] = u * bb[g][0];
+#pragma unroll
+                        for (int j = 1; j < D; ++j) {
+                            const double v = row[j];
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) a[g] = fma(v, bb[g][j], a[g]);
+                        }
+                    }
+                    const double yv = yo[have ? o : 0];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) e[g] = yv - a[g];
+                }
+                // partial pr: the residuals of observations base + pr + 16 q, q = 0..3, in that order
+#pragma unroll
+                for (int q = 0; q < 64 / LINREG_PARTIALS; ++q) {
+                    const bool ok = base + pr + LINREG_PARTIALS * q < nobs;
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const double eq = __shfl(e[g], pr + LINREG_PARTIALS * q, 64);
+                        const double nv = first ? eq * eq : fma(eq, eq, part[g]);
+                        part[g] = ok ? nv : part[g];
+                    }
+                    first = first && !ok;
+                }
+            }
+            // the spec's tree over a 16-lane row, per chain; then every row takes its own chain's sum
+            double sse = 0.0;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                for (int h = LINREG_PARTIALS / 2; h >= 1; h >>= 1) part[g] = part[g] + __shfl_down(part[g], h, LINREG_PARTIALS);
+                const double sg = __shfl(part[g], 0, LINREG_PARTIALS);
+                sse = (lane / L == g) ? sg : sse;
+            }
+            lpp = -0.5 * sse;
         } else {
             double q = 0.0;
 #pragma unroll

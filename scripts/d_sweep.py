@@ -12,4 +12,4 @@ for r in bench.d_sweep_rows(demc, 31953150, 0, gens=gens):
         print(r)
         continue
     print(f"{r['workload']:62s} {r['kernel']:62s} {r['us_per_K_window_kernels']:6.2f} us/K-window (kernels)  {r['value']:.3e} updates/s  "
-          f"{r['roofline']['achieved']:7.1f} GB/s = {100 * r['roofline']['frac']:5.2f} % of HBM  live {r['live_launches']} redos {r['live_redos']} launches {r['launches']}  max R-hat {r['max_rhat']:.3f}")
+          f"{r['roofline']['achieved']:7.1f} {r['roofline']['unit']} = {100 * r['roofline']['frac']:5.2f} % of {r['roofline']['bound']}  live {r['live_launches']} redos {r['live_redos']} launches {r['launches']}  max R-hat {r['max_rhat']:.3f}")

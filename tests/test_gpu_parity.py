@@ -93,6 +93,34 @@ def test_anneal_targets_bit_exact(demc, oracle, kind, d, N, G, lanes):
     assert np.array_equal(mc.chain, ref["chain"]) and np.array_equal(mc.log_obj, ref["log_obj"]) and np.array_equal(Z, ref["Z"])
 
 
+@pytest.mark.parametrize("d,N,nobs,lanes", [(26, 40, 1000, 0), (26, 33, 120, 16), (4, 50, 37, 16), (7, 64, 500, 0), (13, 20, 16, 16), (28, 17, 131, 0),
+                                            (2, 30, 5, 16), (21, 24, 15, 0)])
+def test_regression_target_any_dimension_sixteen_lanes(demc, oracle, d, N, nobs, lanes):
+    """Round 5: the regression SSE (test/example_linreg.jl:32) at dimensions other than 10 -- the reference's own example runs
+    d = 26 -- on window_kernel_ml<LINREG_SSE, d, 16>: sixteen lanes per chain = the spec's sixteen interleaved partial sums, the
+    spec's tree by lane shuffles.  Observation counts that are no multiple of sixteen (and fewer than sixteen), tempered, chosen
+    by the library (lanes_per_chain = 0) and by name; bit-exact against the oracle."""
+    G, K, seed = 40, 10, 23
+    w = demc.workloads.linreg_problem(d, N, nobs=nobs)
+    temps = np.array([demc.tempbaseline(g, G, 3, 1e-3) for g in range(1, G + 1)])
+    M0 = w["Zinit"].shape[0]
+    e = demc.HipEngine(N=N, d=d, K=K, Mcap=M0 + N * (G // K + 1), Gcap=G, blockindex=[range(d)], eps_scale=w["eps_scale"], seed=seed,
+                       target=w["target"], lanes_per_chain=lanes)
+    assert e.info()["lanes_per_chain"] == 16
+    e.set_state(w["Zinit"][-N:], None, w["Zinit"])
+    e.run(1, 17, w["gamma"], temps[:17])
+    e.run(18, G, w["gamma"], temps[17:])
+    assert "window_kernel_ml<LINREG_SSE" in e.kernel_name(), e.kernel_name()
+    ch, lo = e.get_history(1, G)
+    X, lp, Z, M = e.get_state()
+    tot = e.changed_total(1, G)
+    e.close()
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], w["gamma"], seed, temperature=temps)
+    assert np.array_equal(ch, ref["chain"]) and np.array_equal(lo, ref["log_obj"])
+    assert np.array_equal(X, ref["X"]) and np.array_equal(lp, ref["logp"]) and M == ref["M"] and np.array_equal(Z, ref["Z"])
+    assert tot == int(ref["changed"].sum())
+
+
 def test_anneal_gamma_adaptation_matches_host_logic_on_oracle(demc):
     """Same driver, HIP engine vs the oracle-backed test engine: identical, incl. adapted gamma."""
     from oracle_engine import OracleEngine
