@@ -164,17 +164,31 @@ accept_commit!(h, lp::Vector{Float64}) =
 accept_commit!(h, lp::Vector{Float64}, temperature::Real) =
     chk(ccall((:demcz_accept_commit, libdemcz), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ref{Float64}), h, lp, Float64(temperature)), h)
 end_generation!(h, g) = chk(ccall((:demcz_end_generation, libdemcz), Int32, (Ptr{Cvoid}, Int64), h, g), h)
+# Round 5: the same round trip without its copies.  The library owns pinned, device-mapped host buffers (Xprop: N x d, logp: N);
+# the propose kernel writes the proposals INTO Xprop and raises a flag the call spins on, accept_commit only enqueues its kernel,
+# which reads logp through the mapped pointer (include/demcz.h, demcz_closure_buffers).  The arrays are views of library memory:
+# valid until destroy(h); do not write logp between accept_commit!(h) and the return of the next propose!(h, g, ib, γ).
+function closure_buffers(h, N, d)
+    px = Ref{Ptr{Float64}}(C_NULL); pl = Ref{Ptr{Float64}}(C_NULL)
+    chk(ccall((:demcz_closure_buffers, libdemcz), Int32, (Ptr{Cvoid}, Ref{Ptr{Float64}}, Ref{Ptr{Float64}}), h, px, pl), h)
+    unsafe_wrap(Array, px[], (Int(N), Int(d))), unsafe_wrap(Array, pl[], Int(N))
+end
+propose!(h, g, ib, γ) =                                                                  # proposals land in closure_buffers' Xprop
+    chk(ccall((:demcz_propose, libdemcz), Int32, (Ptr{Cvoid}, Int64, Int32, Float64, Ptr{Float64}), h, g, ib - 1, γ, C_NULL), h)
+accept_commit!(h) =                                                                      # log-densities read from closure_buffers' logp
+    chk(ccall((:demcz_accept_commit, libdemcz), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h, C_NULL, C_NULL), h)
+accept_commit!(h, temperature::Real) =
+    chk(ccall((:demcz_accept_commit, libdemcz), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ref{Float64}), h, C_NULL, Float64(temperature)), h)
 
 function run_closure!(h, logobj::Function, N, d, Nblocks, g_from, g_to, γ, temperature=nothing)
-    Xp = Matrix{Float64}(undef, N, d)
-    lp = Vector{Float64}(undef, N)
+    Xp, lp = closure_buffers(h, N, d)                                                  # pinned, device-mapped (no copies, no syncs)
     for g in g_from:g_to                                                               # demcz.jl:30
         for ib in 1:Nblocks                                                            # update_blocks, demcz.jl:168
-            propose!(h, Xp, g, ib, γ)                                                  # demcz.jl:176-188 for all N chains
+            propose!(h, g, ib, γ)                                                      # demcz.jl:176-188 for all N chains -> Xp
             for ic in 1:N
                 lp[ic] = logobj(Xp[ic, :])                                             # demcz.jl:189
             end
-            temperature === nothing ? accept_commit!(h, lp) : accept_commit!(h, lp, temperature[g-g_from+1])
+            temperature === nothing ? accept_commit!(h) : accept_commit!(h, temperature[g-g_from+1])
         end
         end_generation!(h, g)                                                          # demcz.jl:84-91
     end
@@ -230,6 +244,21 @@ function live_status(h)
     chk(ccall((:demcz_get_live_status, libdemcz), Int32, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}), h, on, redos), h)
     on[] != 0, Int(redos[])
 end
+# a timed-out hand-off is redone and the handle goes LIVE again behind the failed boundary, at most `n` times (default 3)
+set_live_rearms(h, n) = chk(ccall((:demcz_set_live_rearms, libdemcz), Int32, (Ptr{Cvoid}, Int32), h, n), h)
+function live_rearms(h)
+    done = Ref{Int32}(0); left = Ref{Int32}(0)
+    chk(ccall((:demcz_get_live_rearms, libdemcz), Int32, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}), h, done, left), h)
+    Int(done[]), Int(left[])
+end
+# comm_init's first-contact check: (ok, wait_us) -- ok = 1 every rank saw every peer's token, 0 failed somewhere, -1 not made
+function peer_ping(h)
+    ok = Ref{Int32}(0); us = Ref{Float64}(0.0)
+    chk(ccall((:demcz_get_peer_ping, libdemcz), Int32, (Ptr{Cvoid}, Ref{Int32}, Ref{Float64}), h, ok, us), h)
+    Int(ok[]), us[]
+end
+# hosts that attached the peers themselves (peer_attach): barrier, peer_detach on every rank, barrier, then destroy
+peer_detach(h) = chk(ccall((:demcz_peer_detach, libdemcz), Int32, (Ptr{Cvoid},), h), h)
 warn_live_redos(h) = (r = live_status(h)[2]; r > 0 && @warn "DEMCz: $r in-launch row hand-off(s) timed out and were redone with one launch per K-window (results unchanged; is another process using this GPU?)"; nothing)
 
 """
