@@ -24,6 +24,9 @@
 
 #pragma clang fp contract(off)
 
+#ifndef ML_LRDPP
+#define ML_LRDPP 1        // regression target on sixteen lanes: the chains' proposals by lanes (DPP row_newbcast); 0: wave-uniform copies in registers
+#endif
 namespace demcz {
 
 // Workgroup geometry: one wave per workgroup (small N spreads over as many CUs as there are waves).  (The regression
@@ -285,6 +288,77 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
             const double* __restrict__ des = P.tp.design;
             const double* __restrict__ yo = P.tp.yobs;
             const int64_t nobs = P.tp.nobs;
+            const int pr = lane & (LINREG_PARTIALS - 1);       // the partial this lane keeps a copy of
+            double part[NG];
+#if ML_LRDPP
+            // The four proposals BY LANES (scripts/gen_ml_lrdpp.py): entry e = g * D + j in lane e % 16 of every 16-lane row of
+            // Bp[e / 16]; each fma of a residual names its entry (v_fmac_f64_dpp ... row_newbcast).  7 register pairs at D = 26
+            // where wave-uniform copies took 208 registers (70 of them parked in AGPRs, an instruction per use).
+            static_assert(NG == 4, "scripts/gen_ml_lrdpp.py: four chains per wave");
+            constexpr int NBP = (NG * D + 15) / 16;
+            double Bp[NBP];
+#pragma unroll
+            for (int k = 0; k < NBP; ++k) {
+                const int en = 16 * k + pr;
+                const int ec = (en < NG * D) ? en : 0;
+                const int eg = ec / D;
+                Bp[k] = rvec[(wv * NG + eg) * DP + (ec - eg * D)];
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) part[g] = -0.0;       // (fma(e, e, -0.0) is e * e: the first term needs no case of its own)
+            auto residuals = [&](const double* __restrict__ row, double yv, double (&e)[NG]) __attribute__((always_inline)) {
+                double rowv[D];
+                if constexpr (D % 2 == 0) {
+#pragma unroll
+                    for (int jj = 0; jj < D; jj += 2) {
+                        const double2 v = reinterpret_cast<const double2*>(row)[jj / 2];
+                        rowv[jj] = v.x;
+                        rowv[jj + 1] = v.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < D; ++jj) rowv[jj] = row[jj];
+                }
+                double a0 = -0.0, a1 = -0.0, a2 = -0.0, a3 = -0.0;
+#include "demcz_ml_lrdpp_sel.inc"
+                e[0] = yv - a0;
+                e[1] = yv - a1;
+                e[2] = yv - a2;
+                e[3] = yv - a3;
+            };
+            const int64_t nfull = nobs & ~(int64_t)63;         // whole rounds of 64 observations: no lane or term is missing
+            for (int64_t base = 0; base < nfull; base += 64) {
+                double e[NG];
+                residuals(des + (base + lane) * D, yo[base + lane], e);
+                // partial pr: the residuals of observations base + pr + 16 q, q = 0..3, in that order
+#pragma unroll
+                for (int q = 0; q < 64 / LINREG_PARTIALS; ++q) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const double eq = __shfl(e[g], pr + LINREG_PARTIALS * q, 64);
+                        part[g] = fma(eq, eq, part[g]);
+                    }
+                }
+            }
+            if (nfull < nobs) {
+                const int64_t o = nfull + lane;
+                const bool have = o < nobs;
+                double e[NG];
+                residuals(des + (have ? o : 0) * D, yo[have ? o : 0], e);
+#pragma unroll
+                for (int q = 0; q < 64 / LINREG_PARTIALS; ++q) {
+                    const bool ok = nfull + pr + LINREG_PARTIALS * q < nobs;
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const double eq = __shfl(e[g], pr + LINREG_PARTIALS * q, 64);
+                        const double nv = fma(eq, eq, part[g]);
+                        part[g] = ok ? nv : part[g];
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) part[g] = part[g] + 0.0;      // (a partial that never got a term is +0.0, as the spec starts it)
+#else
             double bb[NG][D];                                  // the four proposals (this lane's own chain among them)
 #pragma unroll
             for (int g = 0; g < NG; ++g)
@@ -294,11 +368,9 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
                     bb[g][2 * j] = t.x;
                     if (2 * j + 1 < D) bb[g][2 * j + 1] = t.y;
                 }
-            double part[NG];
             bool first = true;                                 // (the same for the four chains: it depends on o alone)
 #pragma unroll
             for (int g = 0; g < NG; ++g) part[g] = 0.0;
-            const int pr = lane & (LINREG_PARTIALS - 1);       // the partial this lane keeps a copy of
             // (a round is one L2 round trip for the lane's row, then its arithmetic.  Prefetching the next round's row into registers
             //  was tried: 428 registers + 172 spilled, the same 200 us per K-window -- the round is bound by what it issues, the
             //  four chains' proposals among it: 208 registers of them)
@@ -347,6 +419,7 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
                     first = first && !ok;
                 }
             }
+#endif
             // the spec's tree over a 16-lane row, per chain; then every row takes its own chain's sum
             double sse = 0.0;
 #pragma unroll

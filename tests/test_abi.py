@@ -65,3 +65,5 @@ def test_two_chain_kernel_is_what_its_generator_makes():
     assert r.returncode == 0, "demcz_pw_wdpp_*.inc differ from what scripts/gen_pw_wdpp.py generates: " + r.stderr[-500:]
     r = subprocess.run([sys.executable, str(ROOT / "scripts" / "gen_mlb_dpp.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, "demcz_mlb_dpp_*.inc differ from what scripts/gen_mlb_dpp.py generates: " + r.stderr[-500:]
+    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "gen_ml_lrdpp.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, "demcz_ml_lrdpp_*.inc differ from what scripts/gen_ml_lrdpp.py generates: " + r.stderr[-500:]

@@ -13,8 +13,9 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 FLIPPED = ROOT / "build_ab" / "flipped.so"
 # W / increments through scalar loads and LDS rows again in window_kernel_pw; the chain's hand-offs through LDS and the record's by
-# DPP in window_kernel_mlb; candidate adds by lanes in window_kernel_ps2 / ps2d; the one-chain kernel's history through the ring
-SWITCHES = ["-DPW_WDPP=0", "-DPW_DDPP=0", "-DMLB_DPP_RECORD=1", "-DPS2_DDPP=1", "-DPS2_HRING_ONE=1"]
+# DPP in window_kernel_mlb; candidate adds by lanes in window_kernel_ps2 / ps2d; the one-chain kernel's history through the ring;
+# the sixteen-lane regression kernel's proposals as wave-uniform register copies instead of by lanes
+SWITCHES = ["-DPW_WDPP=0", "-DPW_DDPP=0", "-DMLB_DPP_RECORD=1", "-DPS2_DDPP=1", "-DPS2_HRING_ONE=1", "-DML_LRDPP=0"]
 
 
 def test_flipped_switches_build():
@@ -32,7 +33,8 @@ def test_flipped_switches_are_bit_identical_to_the_oracle():
     env = dict(os.environ, DEMCZ_LIB=str(FLIPPED))
     sel = ["tests/test_gpu_long_oracle.py::test_wave_per_chain_regular_launches_equal_oracle",
            "tests/test_gpu_long_oracle.py::test_c3_block_updates_long_run_equals_oracle",
-           "tests/test_gpu_dual.py", "tests/test_gpu_live.py::test_forced_handoff_timeout_is_redone_bit_exact"]
+           "tests/test_gpu_dual.py", "tests/test_gpu_live.py::test_forced_handoff_timeout_is_redone_bit_exact",
+           "tests/test_gpu_parity.py::test_regression_target_any_dimension_sixteen_lanes"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + sel, cwd=str(ROOT), env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1000:])
