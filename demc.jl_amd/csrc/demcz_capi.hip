@@ -1701,6 +1701,15 @@ static bool uses_lr16(const demcz_handle* h)
            lr16_dynamic_lds<10>(h->cfg.nobs) <= ML_MAX_DYNAMIC_LDS;
 }
 
+// the regression target on sixteen lanes per chain: helper waves share the chain wave's log-density (demcz_kernels_ml.h, COOP) while
+// the residuals of a workgroup's four chains fit its LDS
+static bool ml_coop(const demcz_handle* h)
+{
+    static const bool off = getenv("DEMCZ_NO_ML_COOP") != nullptr;
+    return ML_LRDPP && !off && h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE && h->full_block && h->lanes == 16 && !uses_lr16(h) &&
+           h->cfg.nobs <= ML_COOP_MAX_OBS;
+}
+
 static bool try_launch_ml(const demcz_handle* h, const WindowParams& P)
 {
     if (h->lanes <= 1 || h->lanes == DEMCZ_LAYOUT_SPLIT) return false;
@@ -1736,7 +1745,14 @@ static bool try_launch_ml(const demcz_handle* h, const WindowParams& P)
         return true;
     } else if (h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE && !uses_lr16(h)) {
         switch (d) {
+#if ML_LRDPP
+#define DEMCZ_LRG_CASE(DD) case DD: \
+            if (ml_coop(h)) hipLaunchKernelGGL((window_kernel_ml<TARGET_LINREG_SSE, DD, 16, false, false, true>), dim3((unsigned)((P.N + 3) / 4)), dim3(64 * ML_COOP_WAVES), 0, h->stream, P); \
+            else launch_window_ml<TARGET_LINREG_SSE, DD, 16>(h, P); \
+            return true;
+#else
 #define DEMCZ_LRG_CASE(DD) case DD: launch_window_ml<TARGET_LINREG_SSE, DD, 16>(h, P); return true;
+#endif
         DEMCZ_LRG_CASE(2) DEMCZ_LRG_CASE(3) DEMCZ_LRG_CASE(4) DEMCZ_LRG_CASE(5) DEMCZ_LRG_CASE(6) DEMCZ_LRG_CASE(7) DEMCZ_LRG_CASE(8) DEMCZ_LRG_CASE(9)
         DEMCZ_LRG_CASE(10) DEMCZ_LRG_CASE(11) DEMCZ_LRG_CASE(12) DEMCZ_LRG_CASE(13) DEMCZ_LRG_CASE(14) DEMCZ_LRG_CASE(15) DEMCZ_LRG_CASE(16)
         DEMCZ_LRG_CASE(17) DEMCZ_LRG_CASE(18) DEMCZ_LRG_CASE(19) DEMCZ_LRG_CASE(20) DEMCZ_LRG_CASE(21) DEMCZ_LRG_CASE(22) DEMCZ_LRG_CASE(23)
@@ -4220,6 +4236,7 @@ extern "C" int32_t demcz_debug_kernel_name(const demcz_handle* h, char* buf, int
     } else if (h->lanes > 1) {
         if (!h->full_block) snprintf(tmp, sizeof tmp, "window_kernel_mlb<%s, %d, %d>", tg, d, h->lanes);
         else if (lr && uses_lr16(h)) snprintf(tmp, sizeof tmp, "window_kernel_lr16<%d, false, false>", d);
+        else if (lr && ml_coop(h)) snprintf(tmp, sizeof tmp, "window_kernel_ml<%s, %d, %d, false, false, true>", tg, d, h->lanes);
         else snprintf(tmp, sizeof tmp, "window_kernel_ml<%s, %d, %d>", tg, d, h->lanes);
     } else {
         snprintf(tmp, sizeof tmp, "window_kernel<%s, %d, %s>", tg, d, h->full_block ? "true" : "false");

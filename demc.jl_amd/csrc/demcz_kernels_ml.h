@@ -45,12 +45,113 @@ namespace demcz {
 #endif
 constexpr int ML_WAVES = DEMCZ_ML_WAVES;
 
-template <int TARGET, int D, int L, bool REC = false, bool LIVE = false>
-__global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowParams P)
+// COOP (regression target, sixteen lanes per chain): a workgroup is ONE chain wave -- four chains, everything as without COOP -- and
+// ML_COOP_WAVES - 1 helper waves that take the residuals of its log-density off it: helper w forms the residuals of the observations
+// of rounds w - 1, w - 1 + (ML_COOP_WAVES - 1), ... for all four chains and leaves them in LDS; the chain wave then folds them into the spec's sixteen partial sums
+// per chain -- lane r of a chain IS partial r and takes its terms in increasing o, as target_logp does.  ML_COOP_WAVES times the
+// waves on a chip that a population of 1024 chains otherwise fills to a quarter of its SIMDs with one FP64-issuing wave each.
+#ifndef ML_COOP_WAVES_N
+#define ML_COOP_WAVES_N 8
+#endif
+constexpr int ML_COOP_WAVES = ML_COOP_WAVES_N;
+constexpr int ML_COOP_MAX_OBS = 1536;       // residuals of a workgroup's four chains in LDS: 4 x 1536 doubles = 48 KB
+#if ML_LRDPP
+// A round's 64 design rows are 64 * D contiguous doubles (row-major design).  A lane reading ITS row straight from memory makes
+// every load instruction touch 64 different cache lines: with seven helper waves a CU that address path sets the pace (a round
+// per 650 clocks for the whole workgroup, whatever the number of waves).  Whole rounds therefore come in as the contiguous tile
+// they are (a lane's 16-byte pieces lane, lane + 64, ...: eight lines an instruction), go through a tile of the wave's own in LDS,
+// and each lane reads its row back from there (row stride D * 8 bytes: conflict-free for even D).
+#ifndef ML_COOP_TILE
+#define ML_COOP_TILE 1                      // (0: every lane reads its row from memory)
+#endif
+template <int D>
+__device__ __forceinline__ void lr_coop_rounds(const WindowParams& P, const double* __restrict__ rvec0, double* __restrict__ elds, double* __restrict__ tile, int lane, int w)
 {
-    constexpr int WPW = ML_WAVES;                               // at most; the launch says how many (blockDim.x / 64: 1 or ML_WAVES)
-    const int wpw = (int)(blockDim.x >> 6);
-    const int wv = (int)(threadIdx.x >> 6);
+    constexpr int NG = 4, DP = ((D + 1) / 2) * 2, NBP = (NG * D + 15) / 16;
+    const int pr = lane & (LINREG_PARTIALS - 1);
+    double Bp[NBP];                                            // the four proposals by lanes (scripts/gen_ml_lrdpp.py)
+#pragma unroll
+    for (int k = 0; k < NBP; ++k) {
+        const int en = 16 * k + pr;
+        const int ec = (en < NG * D) ? en : 0;
+        const int eg = ec / D;
+        Bp[k] = rvec0[eg * DP + (ec - eg * D)];
+    }
+    const double* __restrict__ des = P.tp.design;
+    const double* __restrict__ yo = P.tp.yobs;
+    const int64_t nobs = P.tp.nobs;
+    // (helper wave w = 1 .. ML_COOP_WAVES - 1 takes the rounds w - 1, w - 1 + (ML_COOP_WAVES - 1), ...: the chain wave takes none -- between
+    //  the two barriers it makes the next generation's draws, about two rounds' worth of instructions)
+    for (int64_t base = 64 * (int64_t)(w - 1); base < nobs; base += 64 * (ML_COOP_WAVES - 1)) {
+        const int64_t o = base + lane;
+        const bool have = o < nobs;
+        double rowv[D];
+        const double yv = yo[have ? o : 0];
+        if (ML_COOP_TILE && base + 64 <= nobs) {               // (wave-uniform)
+            constexpr int NPC = 32 * D, NK = (NPC + 63) / 64;  // 16-byte pieces of a tile; per lane
+            const double2* __restrict__ src = reinterpret_cast<const double2*>(des + base * D);
+            double2 pc[NK];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int pi = lane + 64 * k;
+                if (NPC % 64 == 0 || pi < NPC) pc[k] = src[pi];
+            }
+            // (all of the tile's loads in flight before the first is waited for: left alone the compiler sinks every load to its
+            //  store and runs them one by one through one register quad -- thirteen L2 round trips a round)
+#pragma unroll
+            for (int k = 0; k < NK; ++k) asm volatile("" :: "v"(pc[k].x), "v"(pc[k].y));
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int pi = lane + 64 * k;
+                if (NPC % 64 == 0 || pi < NPC) reinterpret_cast<double2*>(tile)[pi] = pc[k];
+            }
+            wave_lds_handoff();
+            if constexpr (D % 2 == 0) {
+#pragma unroll
+                for (int jj = 0; jj < D; jj += 2) {
+                    const double2 v = reinterpret_cast<const double2*>(tile + lane * D)[jj / 2];
+                    rowv[jj] = v.x;
+                    rowv[jj + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < D; ++jj) rowv[jj] = tile[lane * D + jj];
+            }
+            wave_lds_handoff();                                // (the tile is rewritten by the next round)
+        } else {
+        const double* __restrict__ row = des + (have ? o : 0) * D;
+        if constexpr (D % 2 == 0) {
+#pragma unroll
+            for (int jj = 0; jj < D; jj += 2) {
+                const double2 v = reinterpret_cast<const double2*>(row)[jj / 2];
+                rowv[jj] = v.x;
+                rowv[jj + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < D; ++jj) rowv[jj] = row[jj];
+        }
+        }
+        double a0 = -0.0, a1 = -0.0, a2 = -0.0, a3 = -0.0;
+#include "demcz_ml_lrdpp_sel.inc"
+        if (have) {
+            elds[0 * ML_COOP_MAX_OBS + o] = yv - a0;
+            elds[1 * ML_COOP_MAX_OBS + o] = yv - a1;
+            elds[2 * ML_COOP_MAX_OBS + o] = yv - a2;
+            elds[3 * ML_COOP_MAX_OBS + o] = yv - a3;
+        }
+    }
+}
+#endif
+
+template <int TARGET, int D, int L, bool REC = false, bool LIVE = false, bool COOP = false>
+__global__ void __launch_bounds__(COOP ? 64 * ML_COOP_WAVES : 64 * ML_WAVES) window_kernel_ml(const WindowParams P)
+{
+    static_assert(!COOP || (TARGET == TARGET_LINREG_SSE && ML_LRDPP), "COOP: the regression target's helper waves");
+    constexpr int WPW = COOP ? 1 : ML_WAVES;                    // chain waves per workgroup, at most; the launch says how many (blockDim.x / 64: 1 or ML_WAVES)
+    const int wpw = COOP ? 1 : (int)(blockDim.x >> 6);
+    [[maybe_unused]] const int wv_raw = (int)(threadIdx.x >> 6);
+    const int wv = COOP ? 0 : (int)(threadIdx.x >> 6);
     const int64_t vb = (int64_t)xcd_block(P) * wpw + wv;        // this wave's index among the chain waves (XCD-aware: demcz_kernels.h)
     // Round 5: the regression target at ANY dimension (test/example_linreg.jl:9-32 runs d = 26; the matrix-instruction kernels of
     // demcz_kernels_lr.h are d = 10 with the design resident in LDS).  Sixteen lanes per chain ARE the spec's sixteen interleaved
@@ -78,6 +179,8 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
     __shared__ double2 rec[WPW * NG * S];
     __shared__ __attribute__((aligned(16))) double rvec[WPW * NG * DP];
     __shared__ __attribute__((aligned(16))) double yvec[WPW * NG * YP];
+    [[maybe_unused]] __shared__ double elds[COOP ? NG * ML_COOP_MAX_OBS : 1];
+    [[maybe_unused]] __shared__ __attribute__((aligned(16))) double ctile[(COOP && ML_COOP_TILE) ? (ML_COOP_WAVES - 1) * 64 * D : 2];
 
     const int lane = threadIdx.x & 63;
     const int r = lane % L;
@@ -85,8 +188,20 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
     const int64_t c_raw = vb * NG + lane / L;
     // (the regression target's log-density is computed by ALL 64 lanes of a wave for its four chains together: the lanes of chains
     //  beyond N stay -- as shadows of the last chain that store nothing -- while the wave has a chain at all)
-    if constexpr (TARGET == TARGET_LINREG_SSE) { if (vb * NG >= P.N) return; }
+    if constexpr (TARGET == TARGET_LINREG_SSE) { if (vb * NG >= P.N) return; }      // (COOP: the whole workgroup)
     else { if (c_raw >= P.N) return; }
+#if ML_LRDPP
+    if constexpr (COOP) {
+        if (wv_raw != 0) {                  // helper wave: its share of every generation's residuals, between the chain wave's two barriers
+            for (int gi = 0; gi < P.ngen; ++gi) {
+                __syncthreads();
+                lr_coop_rounds<D>(P, rvec, elds, ctile + ((COOP && ML_COOP_TILE) ? (wv_raw - 1) * 64 * D : 0), lane, wv_raw);
+                __syncthreads();
+            }
+            return;
+        }
+    }
+#endif
     const bool active = c_raw < P.N;
     const int64_t c = active ? c_raw : P.N - 1;
     const uint64_t chain = (uint64_t)(P.chain_id0 + c);
@@ -204,7 +319,8 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
         for (int k = 0; k < NP; ++k) { za_c[k] = za[k]; zb_c[k] = zb[k]; zt_c[k] = zt[k]; }
         const double logu = logu_next;
         ra_c = ra; rb_c = rb;
-        if constexpr (decltype(prefetch)::value) issue_draws(gi + 1);
+        // (COOP: the next generation's draws are made once the helper waves have this generation's proposals -- beside their work)
+        if constexpr (decltype(prefetch)::value && !COOP) issue_draws(gi + 1);
         if constexpr (LIVE) {
             // the gather was issued a generation ago; rows appended since then by other waves read as the
             // sentinel until they are published: ask again (demcz_kernels_rec.h)
@@ -291,6 +407,38 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
             const int pr = lane & (LINREG_PARTIALS - 1);       // the partial this lane keeps a copy of
             double part[NG];
 #if ML_LRDPP
+            if constexpr (COOP) {
+                __syncthreads();                               // the four proposals are in rvec: helpers start
+                if constexpr (decltype(prefetch)::value) issue_draws(gi + 1);
+                __syncthreads();                               // every residual is in elds
+                // lane r of chain g = partial r: its terms in increasing o (target_logp's order), first term fma onto -0.0
+                const double* ev = elds + (lane / L) * ML_COOP_MAX_OBS + pr;
+                double pt = -0.0;
+                const int nt = (int)(nobs / LINREG_PARTIALS);
+                int t = 0;
+                if (nt >= 8) {                                 // (the next eight terms are asked for before the chain of eight dependent fmas on these)
+                    double ee[8], en[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) ee[u] = ev[u * LINREG_PARTIALS];
+                    for (; t + 8 <= nt; t += 8) {
+                        const bool more = t + 16 <= nt;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) en[u] = ev[(more ? t + 8 + u : u) * LINREG_PARTIALS];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) pt = fma(ee[u], ee[u], pt);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) ee[u] = en[u];
+                    }
+                }
+                for (; t < nt; ++t) { const double e1 = ev[t * LINREG_PARTIALS]; pt = fma(e1, e1, pt); }
+                if ((int64_t)nt * LINREG_PARTIALS + pr < nobs) { const double e1 = ev[nt * LINREG_PARTIALS]; pt = fma(e1, e1, pt); }
+                pt = pt + 0.0;                                 // (a partial that never got a term is +0.0, as the spec starts it)
+#pragma unroll
+                for (int h = LINREG_PARTIALS / 2; h >= 1; h >>= 1) pt = pt + __shfl_down(pt, h, LINREG_PARTIALS);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) part[g] = 0.0;
+                lpp = -0.5 * __shfl(pt, 0, LINREG_PARTIALS);
+            } else {
             // The four proposals BY LANES (scripts/gen_ml_lrdpp.py): entry e = g * D + j in lane e % 16 of every 16-lane row of
             // Bp[e / 16]; each fma of a residual names its entry (v_fmac_f64_dpp ... row_newbcast).  7 register pairs at D = 26
             // where wave-uniform copies took 208 registers (70 of them parked in AGPRs, an instruction per use).
@@ -306,8 +454,7 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
             }
 #pragma unroll
             for (int g = 0; g < NG; ++g) part[g] = -0.0;       // (fma(e, e, -0.0) is e * e: the first term needs no case of its own)
-            auto residuals = [&](const double* __restrict__ row, double yv, double (&e)[NG]) __attribute__((always_inline)) {
-                double rowv[D];
+            auto load_row = [&](const double* __restrict__ row, double (&rowv)[D]) __attribute__((always_inline)) {
                 if constexpr (D % 2 == 0) {
 #pragma unroll
                     for (int jj = 0; jj < D; jj += 2) {
@@ -319,6 +466,8 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
 #pragma unroll
                     for (int jj = 0; jj < D; ++jj) rowv[jj] = row[jj];
                 }
+            };
+            auto residuals = [&](const double (&rowv)[D], double yv, double (&e)[NG]) __attribute__((always_inline)) {
                 double a0 = -0.0, a1 = -0.0, a2 = -0.0, a3 = -0.0;
 #include "demcz_ml_lrdpp_sel.inc"
                 e[0] = yv - a0;
@@ -327,9 +476,14 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
                 e[3] = yv - a3;
             };
             const int64_t nfull = nobs & ~(int64_t)63;         // whole rounds of 64 observations: no lane or term is missing
+            // (Asking for a round's row a round ahead -- a second copy of the row in registers, the loads pinned in front of the round's
+            //  arithmetic -- was measured with the proposals by lanes too: 140.8 against 111.1 us per K-window.  The row's L2 round trip is
+            //  not what a round waits for.)
+            double rowc[D];
             for (int64_t base = 0; base < nfull; base += 64) {
                 double e[NG];
-                residuals(des + (base + lane) * D, yo[base + lane], e);
+                load_row(des + (base + lane) * D, rowc);
+                residuals(rowc, yo[base + lane], e);
                 // partial pr: the residuals of observations base + pr + 16 q, q = 0..3, in that order
 #pragma unroll
                 for (int q = 0; q < 64 / LINREG_PARTIALS; ++q) {
@@ -344,7 +498,8 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
                 const int64_t o = nfull + lane;
                 const bool have = o < nobs;
                 double e[NG];
-                residuals(des + (have ? o : 0) * D, yo[have ? o : 0], e);
+                load_row(des + (have ? o : 0) * D, rowc);
+                residuals(rowc, yo[have ? o : 0], e);
 #pragma unroll
                 for (int q = 0; q < 64 / LINREG_PARTIALS; ++q) {
                     const bool ok = nfull + pr + LINREG_PARTIALS * q < nobs;
@@ -358,6 +513,7 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
             }
 #pragma unroll
             for (int g = 0; g < NG; ++g) part[g] = part[g] + 0.0;      // (a partial that never got a term is +0.0, as the spec starts it)
+            }
 #else
             double bb[NG][D];                                  // the four proposals (this lane's own chain among them)
 #pragma unroll
@@ -420,16 +576,18 @@ __global__ void __launch_bounds__(64 * ML_WAVES) window_kernel_ml(const WindowPa
                 }
             }
 #endif
-            // the spec's tree over a 16-lane row, per chain; then every row takes its own chain's sum
-            double sse = 0.0;
+            if constexpr (!COOP) {
+                // the spec's tree over a 16-lane row, per chain; then every row takes its own chain's sum
+                double sse = 0.0;
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
+                for (int g = 0; g < NG; ++g) {
 #pragma unroll
-                for (int h = LINREG_PARTIALS / 2; h >= 1; h >>= 1) part[g] = part[g] + __shfl_down(part[g], h, LINREG_PARTIALS);
-                const double sg = __shfl(part[g], 0, LINREG_PARTIALS);
-                sse = (lane / L == g) ? sg : sse;
+                    for (int h = LINREG_PARTIALS / 2; h >= 1; h >>= 1) part[g] = part[g] + __shfl_down(part[g], h, LINREG_PARTIALS);
+                    const double sg = __shfl(part[g], 0, LINREG_PARTIALS);
+                    sse = (lane / L == g) ? sg : sse;
+                }
+                lpp = -0.5 * sse;
             }
-            lpp = -0.5 * sse;
         } else {
             double q = 0.0;
 #pragma unroll
