@@ -61,6 +61,10 @@ constexpr int ML_COOP_MAX_OBS = 1536;       // residuals of a workgroup's four c
 // per 650 clocks for the whole workgroup, whatever the number of waves).  Whole rounds therefore come in as the contiguous tile
 // they are (a lane's 16-byte pieces lane, lane + 64, ...: eight lines an instruction), go through a tile of the wave's own in LDS,
 // and each lane reads its row back from there (row stride D * 8 bytes: conflict-free for even D).
+// What a generation then waits for is the CU's share of the L2's bandwidth: every workgroup reads the whole design (208 KB at d = 26,
+// nobs = 1000) every generation -- 3.6 us per generation = 54 GB/s per CU, where the guide's L2-served gather reaches 66-73.
+// Measured and dropped on top of this (profiles/r05_linreg_coop.txt): asking for a wave's next tile a round ahead (61.1 against
+// 60.3 us per K-window); a dedicated folding wave working through the rounds as their flags come up, six helpers (69.7).
 #ifndef ML_COOP_TILE
 #define ML_COOP_TILE 1                      // (0: every lane reads its row from memory)
 #endif
