@@ -55,6 +55,9 @@ constexpr int ML_WAVES = DEMCZ_ML_WAVES;
 #endif
 constexpr int ML_COOP_WAVES = ML_COOP_WAVES_N;
 constexpr int ML_COOP_MAX_OBS = 1536;       // residuals of a workgroup's four chains in LDS: 4 x 1536 doubles = 48 KB
+#ifndef ML_COOP_TILE
+#define ML_COOP_TILE 1                      // whole rounds of the design through a tile in LDS (0: every lane reads its row from memory)
+#endif
 #if ML_LRDPP
 // A round's 64 design rows are 64 * D contiguous doubles (row-major design).  A lane reading ITS row straight from memory makes
 // every load instruction touch 64 different cache lines: with seven helper waves a CU that address path sets the pace (a round
@@ -65,9 +68,6 @@ constexpr int ML_COOP_MAX_OBS = 1536;       // residuals of a workgroup's four c
 // nobs = 1000) every generation -- 3.6 us per generation = 54 GB/s per CU, where the guide's L2-served gather reaches 66-73.
 // Measured and dropped on top of this (profiles/r05_linreg_coop.txt): asking for a wave's next tile a round ahead (61.1 against
 // 60.3 us per K-window); a dedicated folding wave working through the rounds as their flags come up, six helpers (69.7).
-#ifndef ML_COOP_TILE
-#define ML_COOP_TILE 1                      // (0: every lane reads its row from memory)
-#endif
 template <int D>
 __device__ __forceinline__ void lr_coop_rounds(const WindowParams& P, const double* __restrict__ rvec0, double* __restrict__ elds, double* __restrict__ tile, int lane, int w)
 {
