@@ -72,9 +72,11 @@ HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-W
 
 
 def sources() -> list:
-    """The library's translation units: the C ABI with most kernels (demcz_capi.hip) and the eight units that instantiate
-    window_kernel_pw for every dimension from 6 to 32 (demcz_pw_inst_<g>.hip, csrc/demcz_pw_dispatch.h)."""
-    return [PKG_DIR / "csrc" / "demcz_capi.hip"] + sorted((PKG_DIR / "csrc").glob("demcz_pw_inst_*.hip"))
+    """The library's translation units: the C ABI with most kernels (demcz_capi.hip), the eight units that instantiate
+    window_kernel_pw for every dimension from 6 to 32 (demcz_pw_inst_<g>.hip, csrc/demcz_pw_dispatch.h) and the two with the
+    sixteen-lane regression kernels for every dimension from 2 to 28 (demcz_mlr_inst_<g>.hip, csrc/demcz_mlr_dispatch.h)."""
+    csrc = PKG_DIR / "csrc"
+    return [csrc / "demcz_capi.hip"] + sorted(csrc.glob("demcz_pw_inst_*.hip")) + sorted(csrc.glob("demcz_mlr_inst_*.hip"))
 
 
 def build_command(out: Path = LIB_PATH) -> list:

@@ -11,6 +11,7 @@
 #include "demcz_kernels_ps2.h"
 #include "demcz_kernels_ps2d.h"
 #include "demcz_pw_dispatch.h"
+#include "demcz_mlr_dispatch.h"
 
 #include <rccl/rccl.h>
 
@@ -1744,22 +1745,11 @@ static bool try_launch_ml(const demcz_handle* h, const WindowParams& P)
         launch_window_ml<TARGET_ISO_QUAD, 10, 8>(h, P);
         return true;
     } else if (h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE && !uses_lr16(h)) {
-        switch (d) {
-#if ML_LRDPP
-#define DEMCZ_LRG_CASE(DD) case DD: \
-            if (ml_coop(h)) hipLaunchKernelGGL((window_kernel_ml<TARGET_LINREG_SSE, DD, 16, false, false, true>), dim3((unsigned)((P.N + 3) / 4)), dim3(64 * ML_COOP_WAVES), 0, h->stream, P); \
-            else launch_window_ml<TARGET_LINREG_SSE, DD, 16>(h, P); \
-            return true;
-#else
-#define DEMCZ_LRG_CASE(DD) case DD: launch_window_ml<TARGET_LINREG_SSE, DD, 16>(h, P); return true;
-#endif
-        DEMCZ_LRG_CASE(2) DEMCZ_LRG_CASE(3) DEMCZ_LRG_CASE(4) DEMCZ_LRG_CASE(5) DEMCZ_LRG_CASE(6) DEMCZ_LRG_CASE(7) DEMCZ_LRG_CASE(8) DEMCZ_LRG_CASE(9)
-        DEMCZ_LRG_CASE(10) DEMCZ_LRG_CASE(11) DEMCZ_LRG_CASE(12) DEMCZ_LRG_CASE(13) DEMCZ_LRG_CASE(14) DEMCZ_LRG_CASE(15) DEMCZ_LRG_CASE(16)
-        DEMCZ_LRG_CASE(17) DEMCZ_LRG_CASE(18) DEMCZ_LRG_CASE(19) DEMCZ_LRG_CASE(20) DEMCZ_LRG_CASE(21) DEMCZ_LRG_CASE(22) DEMCZ_LRG_CASE(23)
-        DEMCZ_LRG_CASE(24) DEMCZ_LRG_CASE(25) DEMCZ_LRG_CASE(26) DEMCZ_LRG_CASE(27) DEMCZ_LRG_CASE(28)
-#undef DEMCZ_LRG_CASE
-        }
-        return false;
+        // sixteen lanes per chain at any dimension 2..28 (demcz_mlr_dispatch.h: the kernels live in translation units of their own)
+        const bool coop = ml_coop(h);
+        const int waves = h->wpw;
+        const unsigned blocks = coop ? (unsigned)((P.N + 3) / 4) : (unsigned)((P.N + 4 * waves - 1) / (4 * waves));
+        return mlr_launch(d, coop, blocks, waves, h->stream, P) == 0;
     } else if (h->cfg.target_kind == DEMCZ_TARGET_LINREG_SSE && d == 10) {
         {   // the regression target: 16 chains per workgroup of four waves on the 16x16x4 FP64 matrix instruction
             const size_t dyn = lr16_dynamic_lds<10>(P.tp.nobs);
