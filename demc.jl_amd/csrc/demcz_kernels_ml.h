@@ -67,7 +67,8 @@ constexpr int ML_COOP_MAX_OBS = 1536;       // residuals of a workgroup's four c
 // What a generation then waits for is the CU's share of the L2's bandwidth: every workgroup reads the whole design (208 KB at d = 26,
 // nobs = 1000) every generation -- 3.6 us per generation = 54 GB/s per CU, where the guide's L2-served gather reaches 66-73.
 // Measured and dropped on top of this (profiles/r05_linreg_coop.txt): asking for a wave's next tile a round ahead (61.1 against
-// 60.3 us per K-window); a dedicated folding wave working through the rounds as their flags come up, six helpers (69.7).
+// 60.3 us per K-window); a dedicated folding wave working through the rounds as their flags come up, six helpers (69.7); the chain
+// wave itself folding round by round as the flags come up, one barrier a generation (64.4).
 template <int D>
 __device__ __forceinline__ void lr_coop_rounds(const WindowParams& P, const double* __restrict__ rvec0, double* __restrict__ elds, double* __restrict__ tile, int lane, int w)
 {
