@@ -94,12 +94,14 @@ def test_anneal_targets_bit_exact(demc, oracle, kind, d, N, G, lanes):
 
 
 @pytest.mark.parametrize("d,N,nobs,lanes", [(26, 40, 1000, 0), (26, 33, 120, 16), (4, 50, 37, 16), (7, 64, 500, 0), (13, 20, 16, 16), (28, 17, 131, 0),
-                                            (2, 30, 5, 16), (21, 24, 15, 0)])
+                                            (2, 30, 5, 16), (21, 24, 15, 0), (6, 10, 1600, 0), (9, 7, 1537, 16), (12, 9, 1536, 0)])
 def test_regression_target_any_dimension_sixteen_lanes(demc, oracle, d, N, nobs, lanes):
     """Round 5: the regression SSE (test/example_linreg.jl:32) at dimensions other than 10 -- the reference's own example runs
     d = 26 -- on window_kernel_ml<LINREG_SSE, d, 16>: sixteen lanes per chain = the spec's sixteen interleaved partial sums, the
     spec's tree by lane shuffles.  Observation counts that are no multiple of sixteen (and fewer than sixteen), tempered, chosen
-    by the library (lanes_per_chain = 0) and by name; bit-exact against the oracle."""
+    by the library (lanes_per_chain = 0) and by name; bit-exact against the oracle.  Up to 1536 observations the chain wave has
+    helper waves (COOP: residuals of a workgroup's four chains in LDS), beyond that it forms the residuals itself: both sides of
+    the limit are here."""
     G, K, seed = 40, 10, 23
     w = demc.workloads.linreg_problem(d, N, nobs=nobs)
     temps = np.array([demc.tempbaseline(g, G, 3, 1e-3) for g in range(1, G + 1)])
@@ -111,6 +113,7 @@ def test_regression_target_any_dimension_sixteen_lanes(demc, oracle, d, N, nobs,
     e.run(1, 17, w["gamma"], temps[:17])
     e.run(18, G, w["gamma"], temps[17:])
     assert "window_kernel_ml<LINREG_SSE" in e.kernel_name(), e.kernel_name()
+    assert e.kernel_name().endswith("false, false, true>") == (nobs <= 1536), e.kernel_name()      # (helper waves while the residuals fit LDS)
     ch, lo = e.get_history(1, G)
     X, lp, Z, M = e.get_state()
     tot = e.changed_total(1, G)
