@@ -1,5 +1,7 @@
 """GPU parity: the HIP path through the C ABI vs the CPU oracle on the same seeded inputs.
 Bit-exact: the arithmetic spec makes every double identical."""
+import os
+
 import numpy as np
 import pytest
 
@@ -113,7 +115,10 @@ def test_regression_target_any_dimension_sixteen_lanes(demc, oracle, d, N, nobs,
     e.run(1, 17, w["gamma"], temps[:17])
     e.run(18, G, w["gamma"], temps[17:])
     assert "window_kernel_ml<LINREG_SSE" in e.kernel_name(), e.kernel_name()
-    assert e.kernel_name().endswith("false, false, true>") == (nobs <= 1536), e.kernel_name()      # (helper waves while the residuals fit LDS)
+    if nobs > 1536:             # (helper waves only while the residuals fit LDS; the -DML_LRDPP=0 build has none at all)
+        assert not e.kernel_name().endswith("false, false, true>"), e.kernel_name()
+    elif "flipped" not in os.environ.get("DEMCZ_LIB", ""):
+        assert e.kernel_name().endswith("false, false, true>"), e.kernel_name()
     ch, lo = e.get_history(1, G)
     X, lp, Z, M = e.get_state()
     tot = e.changed_total(1, G)
