@@ -95,7 +95,9 @@ typedef struct demcz_config {
                                      K boundaries (small N); DEMCZ_LAYOUT_SPLIT_WAVE = the same with
                                      one wavefront per chain that resolves five generations per pass
                                      (smallest N; MvNormal at every d in 2..32, the isotropic quadratic
-                                     at d in 6..32).  Results are bit-identical. */
+                                     at d in 6..32).  The regression target: d = 10 on the FP64 matrix
+                                     instruction (split layouts), any other d in 2..28 on sixteen
+                                     lanes per chain with helper waves.  Results are bit-identical. */
     int32_t reserved0;
 } demcz_config;
 
