@@ -146,6 +146,21 @@ def test_c5_regression_two_generations_per_pass_long_run_equals_oracle(demc, ora
     assert (0.1 < acc < 0.45) if gamma == 0.5 else (acc < 0.1), acc
 
 
+@pytest.mark.parametrize("gamma,G", [(0.5, 300), (2.38, 200)])
+def test_regression_at_the_reference_example_shape_equals_oracle(demc, oracle, gamma, G):
+    """Round 5: test/example_linreg.jl's own shape -- 25 regressors + intercept = 26 parameters, nobs = 1000 (:9-32) -- at N = 1024
+    chains, annealed: window_kernel_ml<LINREG_SSE, 26, 16, ..., COOP> (sixteen lanes per chain, seven helper waves per chain wave
+    forming the residuals from tiles of the design, proposals by DPP, the chain wave's fold in the spec's order), cut into
+    irregular pieces, at an acceptance the annealer steers for and at the example's gamma."""
+    d, N, K, seed = 26, 1024, 10, 2605
+    w = demc.workloads.linreg_problem(d, N, nobs=1000)
+    T = np.array([demc.tempbaseline(g, 5000, 3, 1e-3) for g in range(1, G + 1)])
+    a = _hip(demc, w, N, d, K, G, [range(d)], seed, gamma, temperature=T, pieces=[G // 2 + 7, 1, G - G // 2 - 8])
+    assert a["lanes"] == 16, a["lanes"]
+    ref = oracle_sample(oracle, w["target"], w["Zinit"], N, K, G, None, w["eps_scale"], gamma, seed, temperature=T, threads=THREADS)
+    _same(a, ref)
+
+
 def test_c3_block_updates_long_run_equals_oracle(demc, oracle):
     """window_kernel_mlb<0, 20, 16, REC, LIVE> with four-wave workgroups at C3 (d = 20 in four blocks of five, N = 4096)."""
     d, N, K, G, seed = 20, 4096, 10, 1000, 31953150
