@@ -56,8 +56,16 @@ constexpr int ML_WAVES = DEMCZ_ML_WAVES;
 constexpr int ML_COOP_WAVES = ML_COOP_WAVES_N;
 constexpr int ML_COOP_MAX_OBS = 1536;       // residuals of a workgroup's four chains in LDS: 4 x 1536 doubles = 48 KB
 #ifndef ML_COOP_TILE
-#define ML_COOP_TILE 1                      // whole rounds of the design through a tile in LDS (0: every lane reads its row from memory)
+#define ML_COOP_TILE 1                      // whole rounds of the design resident in LDS tiles (0: every lane reads its row from memory, every generation)
 #endif
+#ifndef ML_COOP_RES_BYTES
+#define ML_COOP_RES_BYTES 102400            // LDS for the resident tiles: 100 KB beside the 48 KB of residuals
+#endif
+constexpr int ml_coop_resident_tiles(int D)
+{
+    const int fit = ML_COOP_RES_BYTES / (512 * D), all = ML_COOP_MAX_OBS / 64;
+    return ML_COOP_TILE ? (fit < all ? fit : all) : 0;
+}
 #if ML_LRDPP
 // A round's 64 design rows are 64 * D contiguous doubles (row-major design).  A lane reading ITS row straight from memory makes
 // every load instruction touch 64 different cache lines: with seven helper waves a CU that address path sets the pace (a round
@@ -65,12 +73,16 @@ constexpr int ML_COOP_MAX_OBS = 1536;       // residuals of a workgroup's four c
 // they are (a lane's 16-byte pieces lane, lane + 64, ...: eight lines an instruction), go through a tile of the wave's own in LDS,
 // and each lane reads its row back from there (row stride D * 8 bytes: conflict-free for even D).
 // What a generation then waits for is the CU's share of the L2's bandwidth: every workgroup reads the whole design (208 KB at d = 26,
-// nobs = 1000) every generation -- 3.6 us per generation = 54 GB/s per CU, where the guide's L2-served gather reaches 66-73.
+// nobs = 1000) every generation -- 3.6 us per generation = 54 GB/s per CU, where the guide's L2-served gather reaches 66-73
+// (profiles/r05zb_linreg_pmc.txt: 574 MB of L2 traffic a launch at a 98.5 % hit rate, 61 % of wave-cycles in s_waitcnt).
+// So the tiles STAY: the first ML_COOP_RES_BYTES / (512 D) rounds' tiles are resident in LDS for the whole launch -- filled in its
+// first generation by the helper that owns the round, read from LDS in every later one (7 of 16 rounds at d = 26, nobs = 1000; the
+// whole design up to nobs = 1280 at d = 10) -- and only the rounds behind them are fetched again, every lane its row.
 // Measured and dropped on top of this (profiles/r05_linreg_coop.txt): asking for a wave's next tile a round ahead (61.1 against
 // 60.3 us per K-window); a dedicated folding wave working through the rounds as their flags come up, six helpers (69.7); the chain
 // wave itself folding round by round as the flags come up, one barrier a generation (64.4).
 template <int D>
-__device__ __forceinline__ void lr_coop_rounds(const WindowParams& P, const double* __restrict__ rvec0, double* __restrict__ elds, double* __restrict__ tile, int lane, int w)
+__device__ __forceinline__ void lr_coop_rounds(const WindowParams& P, const double* __restrict__ rvec0, double* __restrict__ elds, double* __restrict__ tiles, bool first, int lane, int w)
 {
     constexpr int NG = 4, DP = ((D + 1) / 2) * 2, NBP = (NG * D + 15) / 16;
     const int pr = lane & (LINREG_PARTIALS - 1);
@@ -87,30 +99,35 @@ __device__ __forceinline__ void lr_coop_rounds(const WindowParams& P, const doub
     const int64_t nobs = P.tp.nobs;
     // (helper wave w = 1 .. ML_COOP_WAVES - 1 takes the rounds w - 1, w - 1 + (ML_COOP_WAVES - 1), ...: the chain wave takes none -- between
     //  the two barriers it makes the next generation's draws, about two rounds' worth of instructions)
-    for (int64_t base = 64 * (int64_t)(w - 1); base < nobs; base += 64 * (ML_COOP_WAVES - 1)) {
+    constexpr int NRES = ml_coop_resident_tiles(D);
+    int rd = w - 1;
+    for (int64_t base = 64 * (int64_t)(w - 1); base < nobs; base += 64 * (ML_COOP_WAVES - 1), rd += ML_COOP_WAVES - 1) {
         const int64_t o = base + lane;
         const bool have = o < nobs;
         double rowv[D];
         const double yv = yo[have ? o : 0];
-        if (ML_COOP_TILE && base + 64 <= nobs) {               // (wave-uniform)
-            constexpr int NPC = 32 * D, NK = (NPC + 63) / 64;  // 16-byte pieces of a tile; per lane
-            const double2* __restrict__ src = reinterpret_cast<const double2*>(des + base * D);
-            double2 pc[NK];
+        if (ML_COOP_TILE && rd < NRES && base + 64 <= nobs) {  // (wave-uniform) a resident round: its tile belongs to this wave alone
+            double* __restrict__ tile = tiles + rd * (64 * D);
+            if (first) {                                       // the launch's first generation: the tile comes in, as the contiguous piece of memory it is
+                constexpr int NPC = 32 * D, NK = (NPC + 63) / 64;  // 16-byte pieces of a tile; per lane
+                const double2* __restrict__ src = reinterpret_cast<const double2*>(des + base * D);
+                double2 pc[NK];
 #pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                const int pi = lane + 64 * k;
-                if (NPC % 64 == 0 || pi < NPC) pc[k] = src[pi];
+                for (int k = 0; k < NK; ++k) {
+                    const int pi = lane + 64 * k;
+                    if (NPC % 64 == 0 || pi < NPC) pc[k] = src[pi];
+                }
+                // (all of the tile's loads in flight before the first is waited for: left alone the compiler sinks every load to its
+                //  store and runs them one by one through one register quad -- thirteen L2 round trips a round)
+#pragma unroll
+                for (int k = 0; k < NK; ++k) asm volatile("" :: "v"(pc[k].x), "v"(pc[k].y));
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int pi = lane + 64 * k;
+                    if (NPC % 64 == 0 || pi < NPC) reinterpret_cast<double2*>(tile)[pi] = pc[k];
+                }
+                wave_lds_handoff();
             }
-            // (all of the tile's loads in flight before the first is waited for: left alone the compiler sinks every load to its
-            //  store and runs them one by one through one register quad -- thirteen L2 round trips a round)
-#pragma unroll
-            for (int k = 0; k < NK; ++k) asm volatile("" :: "v"(pc[k].x), "v"(pc[k].y));
-#pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                const int pi = lane + 64 * k;
-                if (NPC % 64 == 0 || pi < NPC) reinterpret_cast<double2*>(tile)[pi] = pc[k];
-            }
-            wave_lds_handoff();
             if constexpr (D % 2 == 0) {
 #pragma unroll
                 for (int jj = 0; jj < D; jj += 2) {
@@ -122,7 +139,6 @@ __device__ __forceinline__ void lr_coop_rounds(const WindowParams& P, const doub
 #pragma unroll
                 for (int jj = 0; jj < D; ++jj) rowv[jj] = tile[lane * D + jj];
             }
-            wave_lds_handoff();                                // (the tile is rewritten by the next round)
         } else {
         const double* __restrict__ row = des + (have ? o : 0) * D;
         if constexpr (D % 2 == 0) {
@@ -185,7 +201,7 @@ __global__ void __launch_bounds__(COOP ? 64 * ML_COOP_WAVES : 64 * ML_WAVES) win
     __shared__ __attribute__((aligned(16))) double rvec[WPW * NG * DP];
     __shared__ __attribute__((aligned(16))) double yvec[WPW * NG * YP];
     [[maybe_unused]] __shared__ double elds[COOP ? NG * ML_COOP_MAX_OBS : 1];
-    [[maybe_unused]] __shared__ __attribute__((aligned(16))) double ctile[(COOP && ML_COOP_TILE) ? (ML_COOP_WAVES - 1) * 64 * D : 2];
+    [[maybe_unused]] __shared__ __attribute__((aligned(16))) double ctile[(COOP && ML_COOP_TILE) ? ml_coop_resident_tiles(D) * 64 * D : 2];
 
     const int lane = threadIdx.x & 63;
     const int r = lane % L;
@@ -200,7 +216,7 @@ __global__ void __launch_bounds__(COOP ? 64 * ML_COOP_WAVES : 64 * ML_WAVES) win
         if (wv_raw != 0) {                  // helper wave: its share of every generation's residuals, between the chain wave's two barriers
             for (int gi = 0; gi < P.ngen; ++gi) {
                 __syncthreads();
-                lr_coop_rounds<D>(P, rvec, elds, ctile + ((COOP && ML_COOP_TILE) ? (wv_raw - 1) * 64 * D : 0), lane, wv_raw);
+                lr_coop_rounds<D>(P, rvec, elds, ctile, gi == 0, lane, wv_raw);
                 __syncthreads();
             }
             return;
