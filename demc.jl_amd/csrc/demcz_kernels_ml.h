@@ -82,7 +82,7 @@ constexpr int ml_coop_resident_tiles(int D)
 // 60.3 us per K-window); a dedicated folding wave working through the rounds as their flags come up, six helpers (69.7); the chain
 // wave itself folding round by round as the flags come up, one barrier a generation (64.4).
 template <int D>
-__device__ __forceinline__ void lr_coop_rounds(const WindowParams& P, const double* __restrict__ rvec0, double* __restrict__ elds, double* __restrict__ tiles, bool first, int lane, int w)
+__device__ __forceinline__ void lr_coop_rounds(const WindowParams& P, const double* __restrict__ rvec0, double* __restrict__ elds, double* __restrict__ tiles, unsigned int* ready, unsigned int tag, bool first, int lane, int w)
 {
     constexpr int NG = 4, DP = ((D + 1) / 2) * 2, NBP = (NG * D + 15) / 16;
     const int pr = lane & (LINREG_PARTIALS - 1);
@@ -161,6 +161,10 @@ __device__ __forceinline__ void lr_coop_rounds(const WindowParams& P, const doub
             elds[2 * ML_COOP_MAX_OBS + o] = yv - a2;
             elds[3 * ML_COOP_MAX_OBS + o] = yv - a3;
         }
+        if (rd < NRES) {       // a resident round is done early (no trip to L2): the chain wave may fold it while the others are still being fetched
+            asm volatile("" ::: "memory");         // (a wave's LDS operations are carried out in order: whoever sees the flag sees the residuals)
+            if (lane == 0) __hip_atomic_store(&ready[rd], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
 }
 #endif
@@ -202,6 +206,7 @@ __global__ void __launch_bounds__(COOP ? 64 * ML_COOP_WAVES : 64 * ML_WAVES) win
     __shared__ __attribute__((aligned(16))) double yvec[WPW * NG * YP];
     [[maybe_unused]] __shared__ double elds[COOP ? NG * ML_COOP_MAX_OBS : 1];
     [[maybe_unused]] __shared__ __attribute__((aligned(16))) double ctile[(COOP && ML_COOP_TILE) ? ml_coop_resident_tiles(D) * 64 * D : 2];
+    [[maybe_unused]] __shared__ unsigned int cready[COOP ? ML_COOP_MAX_OBS / 64 : 1];      // a resident round's flag: the tag (gi + 1) of the generation whose residuals are in
 
     const int lane = threadIdx.x & 63;
     const int r = lane % L;
@@ -214,9 +219,10 @@ __global__ void __launch_bounds__(COOP ? 64 * ML_COOP_WAVES : 64 * ML_WAVES) win
 #if ML_LRDPP
     if constexpr (COOP) {
         if (wv_raw != 0) {                  // helper wave: its share of every generation's residuals, between the chain wave's two barriers
+            if (wv_raw == 1 && lane < ML_COOP_MAX_OBS / 64) cready[lane] = 0u;          // (in front of the first barrier)
             for (int gi = 0; gi < P.ngen; ++gi) {
                 __syncthreads();
-                lr_coop_rounds<D>(P, rvec, elds, ctile, gi == 0, lane, wv_raw);
+                lr_coop_rounds<D>(P, rvec, elds, ctile, cready, (unsigned int)gi + 1u, gi == 0, lane, wv_raw);
                 __syncthreads();
             }
             return;
@@ -431,20 +437,34 @@ __global__ void __launch_bounds__(COOP ? 64 * ML_COOP_WAVES : 64 * ML_WAVES) win
             if constexpr (COOP) {
                 __syncthreads();                               // the four proposals are in rvec: helpers start
                 if constexpr (decltype(prefetch)::value) issue_draws(gi + 1);
-                __syncthreads();                               // every residual is in elds
                 // lane r of chain g = partial r: its terms in increasing o (target_logp's order), first term fma onto -0.0
                 const double* ev = elds + (lane / L) * ML_COOP_MAX_OBS + pr;
                 double pt = -0.0;
                 const int nt = (int)(nobs / LINREG_PARTIALS);
                 int t = 0;
-                if (nt >= 8) {                                 // (the next eight terms are asked for before the chain of eight dependent fmas on these)
+                {   // the resident rounds come first in o and are done first (LDS-fed): folded while the other rounds are still being fetched
+                    constexpr int NRES = ml_coop_resident_tiles(D);
+                    const int nearly = (int)((nobs / 64 < NRES) ? nobs / 64 : NRES);
+                    for (int rdr = 0; rdr < nearly; ++rdr) {
+                        while (__hip_atomic_load(&cready[rdr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned int)gi + 1u) __builtin_amdgcn_s_sleep(2);
+                        asm volatile("" ::: "memory");
+                        double e4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) e4[u] = ev[(t + u) * LINREG_PARTIALS];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) pt = fma(e4[u], e4[u], pt);
+                        t += 4;
+                    }
+                }
+                __syncthreads();                               // every residual is in elds
+                if (t + 8 <= nt) {                             // (the next eight terms are asked for before the chain of eight dependent fmas on these)
                     double ee[8], en[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) ee[u] = ev[u * LINREG_PARTIALS];
+                    for (int u = 0; u < 8; ++u) ee[u] = ev[(t + u) * LINREG_PARTIALS];
                     for (; t + 8 <= nt; t += 8) {
                         const bool more = t + 16 <= nt;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) en[u] = ev[(more ? t + 8 + u : u) * LINREG_PARTIALS];
+                        for (int u = 0; u < 8; ++u) en[u] = ev[(more ? t + 8 + u : t + u) * LINREG_PARTIALS];
 #pragma unroll
                         for (int u = 0; u < 8; ++u) pt = fma(ee[u], ee[u], pt);
 #pragma unroll
